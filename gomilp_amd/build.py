@@ -1,0 +1,47 @@
+"""In-tree build of the gfx950 engine: gomilp_amd/libgomilp_hip.so (hipcc cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libgomilp_hip.so")
+SOURCES = ["simplex_kernels.hip", "engine.cpp", "c_api.cpp"]
+HEADERS = ["device_types.h", "engine.hpp", os.path.join(ROOT, "include", "gomilp_lp.h")]
+# -ffp-contract=off: the final basis solve must round every multiply and add separately, like the
+# reference's SSE2 kernels (DESIGN.md "bit-exact final solve"); the streaming kernels are HBM-bound
+# and do not miss the FMAs.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-Wno-unused-result", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include")]
+
+
+def _hipcc() -> str | None:
+    return shutil.which("hipcc") or (os.path.exists("/opt/rocm/bin/hipcc") and "/opt/rocm/bin/hipcc") or None
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not (force or stale()):
+        return LIB
+    hipcc = _hipcc()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found and %s is missing or out of date" % LIB)
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

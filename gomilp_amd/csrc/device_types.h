@@ -1,0 +1,82 @@
+// Shared host/device plain structs for the gfx950 simplex engine.
+#pragma once
+#include <stdint.h>
+
+namespace gomilp {
+
+// loop status written by the kernels (DevState::status)
+enum : int32_t {
+    ST_RUNNING = 0,
+    ST_OPTIMAL = 1,     // min r >= -tol                      (simplex.go:248)
+    ST_UNBOUNDED = 2,   // no d_i < 0                         (simplex.go:328-330)
+    ST_NEED_BLAND = 3,  // move[replace] <= 0: degenerate     (simplex.go:269)
+    ST_MAX_PIVOTS = 4,  // safety cap hit
+    ST_LU_SINGULAR = 5  // exact zero pivot in the final gonum-order LU
+};
+
+constexpr int kMaxPartials = 1024;  // per-workgroup partial arg-reductions (grid <= 1024 workgroups)
+constexpr int kBlock = 256;         // threads per workgroup (4 waves of 64)
+constexpr int kWavesPerBlock = 4;
+
+// One per solve, lives in device memory; a pinned host mirror is copied after every chunk.
+struct DevState {
+    int32_t done;      // 0 while pivoting; kernels become no-ops once set
+    int32_t status;    // ST_*
+    int64_t pivots;    // pivots performed since the phase started
+    int32_t q;         // entering position (index into nonbasic[])
+    int32_t p;         // leaving position  (index into basic[])
+    double rq;         // reduced cost of the entering column
+    double dp;         // pivot element (B^-1 a_q)[p]
+    double mv;         // winning ratio x_B[p] / |d_p|
+    int64_t trace_len; // pivots appended to the device trace since the solve started
+    int64_t max_pivots;
+    int32_t lu_singular;
+    int32_t pad;
+};
+
+struct DevPivot {  // mirrors gomilp_pivot
+    int32_t phase, bland;
+    int64_t min_idx, replace, entering, leaving;
+};
+
+// Kernel argument block (passed by value).
+struct LPArgs {
+    int32_t m;         // rows
+    int32_t ld;        // padded row length (doubles) of At rows and Binv rows; multiple of 2, zero padded
+    int32_t nn;        // number of nonbasic positions in this phase
+    int32_t phase;     // 1 / 2 (trace only)
+    double tol;
+    const double *At;      // (ncols) x ld, row j = column j of A   (row n = artificial column in Phase I)
+    const double *cost;    // cost vector of the current phase
+    const double *b;       // right-hand side, padded to ld
+    const double *binv_cur;  // m x ld
+    double *binv_next;       // m x ld (ping-pong target of the rank-1 update)
+    double *xb;            // m
+    double *y;             // ld (padded with zeros)
+    double *dvec;          // m   d' = B^-1 a_q (unrounded)
+    double *move;          // m   ratio vector (simplex.go:334-340)
+    double *rvec;          // nn  reduced costs (simplex.go:243)
+    int32_t *basic;        // m   variable id per basis position
+    int32_t *nonbasic;     // nn  variable id per nonbasic position
+    unsigned long long *pk_price;  // kMaxPartials
+    unsigned int *pi_price;
+    unsigned long long *pk_ratio;
+    unsigned int *pi_ratio;
+    DevState *st;
+    DevPivot *trace;
+    int64_t trace_cap;
+};
+
+// Arguments of the gonum-order LU kernels (final basis solve).
+struct LUArgs {
+    double *W;          // m x ldw working copy of ab (simplex.go:144), overwritten by L\U in place (rows never move)
+    int32_t ldw, m;
+    int32_t *lpos;      // logical (LAPACK) position of each physical row
+    int32_t *rowstep;   // -1 while active, else the step at which the row became the pivot row
+    unsigned long long *pk[2];  // partial argmax keys, double buffered by step parity
+    unsigned int *pl[2];        // logical position of the candidate
+    unsigned int *pr[2];        // physical row of the candidate
+    DevState *st;
+};
+
+}  // namespace gomilp

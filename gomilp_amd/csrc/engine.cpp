@@ -1,0 +1,699 @@
+// Host-side engine: see engine.hpp.  Control flow mirrors gonum's simplex()
+// (vendor/gonum.org/v1/gonum/optimize/convex/lp/simplex.go:93-302); all O(m^2)/O(m*n) work is
+// enqueued as gfx950 kernels (simplex_kernels.hip).  No CPU fallback exists: any HIP failure
+// surfaces as GOMILP_ERR_DEVICE.
+#include "engine.hpp"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <limits>
+
+namespace gomilp {
+
+namespace {
+
+double now_s() {
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return GOMILP_ERR_DEVICE; \
+    } while (0)
+
+// floats.MinIdx (floats/floats.go:458-474)
+int64_t min_idx(const double *s, int64_t n) {
+    double mn = std::numeric_limits<double>::quiet_NaN();
+    int64_t ind = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const double v = s[i];
+        if (v != v) continue;
+        if (v < mn || mn != mn) { mn = v; ind = i; }
+    }
+    return ind;
+}
+
+// f64.DotUnitary (internal/asm/f64/dot_amd64.s:43-92): 4 interleaved partial sums, tail into lane 0.
+// Used for z = cb.xb (simplex.go:296) so the objective is bit-identical given identical xb.
+double dot_unitary(const double *x, const double *y, int64_t n) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int64_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        s0 += x[i] * y[i];
+        s1 += x[i + 1] * y[i + 1];
+        s2 += x[i + 2] * y[i + 2];
+        s3 += x[i + 3] * y[i + 3];
+    }
+    for (; i < n; i++) s0 += x[i] * y[i];
+    return (s0 + s2) + (s1 + s3);
+}
+
+template <typename T>
+hipError_t dmalloc(T **p, size_t count) {
+    return hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T));
+}
+
+}  // namespace
+
+struct Engine::Work {
+    int cap_m = 0, cap_ld = 0, cap_cols = 0;
+    double *binv[2] = {nullptr, nullptr};
+    double *xb = nullptr, *y = nullptr, *dvec = nullptr, *move = nullptr, *rvec = nullptr, *yscratch = nullptr, *W = nullptr;
+    int32_t *basic = nullptr, *nonbasic = nullptr, *lpos = nullptr, *rowstep = nullptr, *rho = nullptr;
+    unsigned long long *pk_price = nullptr, *pk_ratio = nullptr, *lpk[2] = {nullptr, nullptr};
+    unsigned int *pi_price = nullptr, *pi_ratio = nullptr, *lpl[2] = {nullptr, nullptr}, *lpr[2] = {nullptr, nullptr};
+    DevState *st = nullptr;
+    DevState *st_host = nullptr;  // pinned
+    DevPivot *trace = nullptr;
+    int64_t trace_cap = 0;
+    double *h_W = nullptr;  // pinned, cap_m * cap_ld
+    double *h_vec = nullptr;  // pinned, max(cap_ld, cap_cols)
+    int32_t *h_idx = nullptr; // pinned, max(cap_m, cap_cols)
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> sample_ev;  // pairs around sampled kernels
+
+    void release() {
+        for (auto &p : binv) { if (p) hipFree(p); p = nullptr; }
+        for (double **p : {&xb, &y, &dvec, &move, &rvec, &yscratch, &W}) { if (*p) hipFree(*p); *p = nullptr; }
+        for (int32_t **p : {&basic, &nonbasic, &lpos, &rowstep, &rho}) { if (*p) hipFree(*p); *p = nullptr; }
+        if (h_W) hipHostFree(h_W); h_W = nullptr;
+        if (h_vec) hipHostFree(h_vec); h_vec = nullptr;
+        if (h_idx) hipHostFree(h_idx); h_idx = nullptr;
+        cap_m = cap_ld = cap_cols = 0;
+    }
+    void release_all() {
+        release();
+        for (auto **p : {&pk_price, &pk_ratio, &lpk[0], &lpk[1]}) { if (*p) hipFree(*p); *p = nullptr; }
+        for (auto **p : {&pi_price, &pi_ratio, &lpl[0], &lpl[1], &lpr[0], &lpr[1]}) { if (*p) hipFree(*p); *p = nullptr; }
+        if (st) hipFree(st); st = nullptr;
+        if (st_host) hipHostFree(st_host); st_host = nullptr;
+        if (trace) hipFree(trace); trace = nullptr;
+        for (auto &e : ev) { if (e) hipEventDestroy(e); e = nullptr; }
+        for (auto &e : sample_ev) hipEventDestroy(e);
+        sample_ev.clear();
+    }
+};
+
+int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *compiled_arch() { return "gfx950"; }
+
+Engine::Engine(int device) : device_(device), w_(new Work) {}
+
+Engine::~Engine() {
+    hipSetDevice(device_);
+    for (auto &p : problems_) {
+        if (!p) continue;
+        hipFree(p->dAt); hipFree(p->dc); hipFree(p->dc1); hipFree(p->db);
+    }
+    w_->release_all();
+    if (stream_) hipStreamDestroy(stream_);
+}
+
+int Engine::set(const std::string &key, int64_t v) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (key == "chunk") { if (v < 1) return GOMILP_ERR_BAD_SHAPE; chunk_ = v; }
+    else if (key == "refresh") { if (v < 0) return GOMILP_ERR_BAD_SHAPE; refresh_ = v; }
+    else if (key == "trace") trace_on_ = v ? 1 : 0;
+    else if (key == "max_pivots") max_pivots_ = v < 0 ? 0 : v;
+    else if (key == "sample_events") sample_events_ = v < 0 ? 0 : v;
+    else return GOMILP_ERR_BAD_SHAPE;
+    return GOMILP_OK;
+}
+
+int Engine::ensure_work(int m, int ncols) {
+    HIP_TRY(hipSetDevice(device_));
+    if (!stream_) HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    Work &w = *w_;
+    if (!w.st) {
+        HIP_TRY(dmalloc(&w.pk_price, kMaxPartials)); HIP_TRY(dmalloc(&w.pk_ratio, kMaxPartials));
+        HIP_TRY(dmalloc(&w.pi_price, kMaxPartials)); HIP_TRY(dmalloc(&w.pi_ratio, kMaxPartials));
+        for (int t = 0; t < 2; t++) {
+            HIP_TRY(dmalloc(&w.lpk[t], kMaxPartials)); HIP_TRY(dmalloc(&w.lpl[t], kMaxPartials)); HIP_TRY(dmalloc(&w.lpr[t], kMaxPartials));
+        }
+        HIP_TRY(dmalloc(&w.st, 1));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.st_host), sizeof(DevState), hipHostMallocDefault));
+        w.trace_cap = 1 << 18;
+        HIP_TRY(dmalloc(&w.trace, (size_t)w.trace_cap));
+        HIP_TRY(hipEventCreate(&w.ev[0])); HIP_TRY(hipEventCreate(&w.ev[1]));
+    }
+    const int ld = (m + 1) & ~1;
+    if (m <= w.cap_m && ncols <= w.cap_cols) return GOMILP_OK;
+    const int nm = std::max(m, w.cap_m), nc = std::max(ncols, w.cap_cols);
+    const int nld = std::max(ld, w.cap_ld);
+    w.release();
+    for (auto &p : w.binv) HIP_TRY(dmalloc(&p, (size_t)nm * nld));
+    HIP_TRY(dmalloc(&w.W, (size_t)nm * nld));
+    HIP_TRY(dmalloc(&w.xb, (size_t)nld)); HIP_TRY(dmalloc(&w.y, (size_t)nld)); HIP_TRY(dmalloc(&w.dvec, (size_t)nld));
+    HIP_TRY(dmalloc(&w.move, (size_t)nld)); HIP_TRY(dmalloc(&w.rvec, (size_t)nc));
+    HIP_TRY(dmalloc(&w.yscratch, (size_t)64 * nld));
+    HIP_TRY(dmalloc(&w.basic, (size_t)nm)); HIP_TRY(dmalloc(&w.nonbasic, (size_t)nc));
+    HIP_TRY(dmalloc(&w.lpos, (size_t)nm)); HIP_TRY(dmalloc(&w.rowstep, (size_t)nm)); HIP_TRY(dmalloc(&w.rho, (size_t)nm));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_W), (size_t)nm * nld * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_vec), (size_t)std::max(nld, nc) * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_idx), (size_t)std::max(nm, nc) * sizeof(int32_t), hipHostMallocDefault));
+    w.cap_m = nm; w.cap_ld = nld; w.cap_cols = nc;
+    return GOMILP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// upload: A (row-major m x n) -> At ((n+1) x ld) in HBM, column statistics for verifyInputs and for
+// the unit-column fast path of findLinearlyIndependent (simplex.go:385-439, :611-637)
+// ------------------------------------------------------------------------------------------------
+int64_t Engine::upload(const double *c, const double *A, int64_t lda, const double *b, int64_t m64, int64_t n64) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!c || !A || !b || m64 <= 0 || n64 <= 0 || lda < n64 || m64 > (1 << 20) || n64 > (1 << 22)) return -GOMILP_ERR_BAD_SHAPE;
+    const int m = (int)m64, n = (int)n64;
+    const int ld = (m + 1) & ~1;
+    if ((size_t)ld * sizeof(double) > 64 * 1024) return -GOMILP_ERR_UNSUPPORTED;  // LDS staging of one row
+    if (hipSetDevice(device_) != hipSuccess) return -GOMILP_ERR_DEVICE;
+    if (!stream_ && hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) return -GOMILP_ERR_DEVICE;
+    const double t0 = now_s();
+    std::unique_ptr<Problem> P(new Problem);
+    P->m = m; P->n = n; P->ld = ld;
+    double *dA = nullptr;
+    int32_t *dstats = nullptr;
+    auto fail = [&](int code) -> int64_t {
+        if (dA) hipFree(dA);
+        if (dstats) hipFree(dstats);
+        if (P->dAt) hipFree(P->dAt);
+        if (P->dc) hipFree(P->dc);
+        if (P->dc1) hipFree(P->dc1);
+        if (P->db) hipFree(P->db);
+        return -code;
+    };
+#define UP_TRY(expr) do { if ((expr) != hipSuccess) return fail(GOMILP_ERR_DEVICE); } while (0)
+    UP_TRY(dmalloc(&dA, (size_t)m * n));
+    UP_TRY(dmalloc(&P->dAt, (size_t)(n + 1) * ld));
+    UP_TRY(dmalloc(&P->dc, (size_t)n + 1));
+    UP_TRY(dmalloc(&P->dc1, (size_t)n + 1));
+    UP_TRY(dmalloc(&P->db, (size_t)ld));
+    UP_TRY(dmalloc(&dstats, (size_t)3 * n + m));
+    UP_TRY(hipMemcpy2DAsync(dA, (size_t)n * sizeof(double), A, (size_t)lda * sizeof(double), (size_t)n * sizeof(double), m,
+                            hipMemcpyHostToDevice, stream_));
+    UP_TRY(hipMemsetAsync(P->dAt, 0, (size_t)(n + 1) * ld * sizeof(double), stream_));
+    UP_TRY(hipMemsetAsync(P->dc, 0, ((size_t)n + 1) * sizeof(double), stream_));
+    UP_TRY(hipMemsetAsync(P->dc1, 0, ((size_t)n + 1) * sizeof(double), stream_));
+    UP_TRY(hipMemsetAsync(P->db, 0, (size_t)ld * sizeof(double), stream_));
+    UP_TRY(hipMemsetAsync(dstats, 0, ((size_t)3 * n + m) * sizeof(int32_t), stream_));
+    UP_TRY(hipMemcpyAsync(P->dc, c, (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream_));
+    UP_TRY(hipMemcpyAsync(P->db, b, (size_t)m * sizeof(double), hipMemcpyHostToDevice, stream_));
+    const double one = 1.0;
+    UP_TRY(hipMemcpyAsync(P->dc1 + n, &one, sizeof(double), hipMemcpyHostToDevice, stream_));
+    launch_transpose_in(dA, n, m, n, P->dAt, ld, stream_);
+    launch_col_stats(P->dAt, ld, m, n, dstats, dstats + n, dstats + 2 * n, dstats + 3 * n, stream_);
+    std::vector<int32_t> hs((size_t)3 * n + m);
+    UP_TRY(hipMemcpyAsync(hs.data(), dstats, hs.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    UP_TRY(hipStreamSynchronize(stream_));
+    UP_TRY(hipGetLastError());
+#undef UP_TRY
+    hipFree(dA); dA = nullptr;
+    hipFree(dstats); dstats = nullptr;
+    P->nnz.assign(hs.begin(), hs.begin() + n);
+    P->lastrow.assign(hs.begin() + n, hs.begin() + 2 * n);
+    P->allone.assign(hs.begin() + 2 * n, hs.begin() + 3 * n);
+    P->hb.assign(b, b + m);
+    P->hc.assign(c, c + n);
+    // verifyInputs (simplex.go:404-438): rows first, then columns, first offender decides
+    P->verify_status = GOMILP_OK;
+    for (int i = 0; i < m && P->verify_status == GOMILP_OK; i++)
+        if (!hs[(size_t)3 * n + i]) P->verify_status = (b[i] != 0) ? GOMILP_ERR_INFEASIBLE : GOMILP_ERR_ZERO_ROW;
+    for (int j = 0; j < n && P->verify_status == GOMILP_OK; j++)
+        if (P->nnz[j] == 0) P->verify_status = (c[j] < 0) ? GOMILP_ERR_UNBOUNDED : GOMILP_ERR_ZERO_COLUMN;
+    P->seconds_upload = now_s() - t0;
+    for (size_t i = 0; i < problems_.size(); i++)
+        if (!problems_[i]) { problems_[i] = std::move(P); return (int64_t)i; }
+    problems_.push_back(std::move(P));
+    return (int64_t)problems_.size() - 1;
+}
+
+int Engine::free_problem(int64_t id) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (id < 0 || (size_t)id >= problems_.size() || !problems_[id]) return GOMILP_ERR_BAD_SHAPE;
+    hipSetDevice(device_);
+    Problem &P = *problems_[id];
+    hipFree(P.dAt); hipFree(P.dc); hipFree(P.dc1); hipFree(P.db);
+    problems_[id].reset();
+    return GOMILP_OK;
+}
+
+LPArgs Engine::make_args(const Problem &P, int phase, double tol, int nn, const double *cost) {
+    Work &w = *w_;
+    LPArgs a;
+    memset(&a, 0, sizeof(a));
+    a.m = P.m; a.ld = P.ld; a.nn = nn; a.phase = phase; a.tol = tol;
+    a.At = P.dAt; a.cost = cost; a.b = P.db;
+    a.binv_cur = w.binv[cur_]; a.binv_next = w.binv[cur_ ^ 1];
+    a.xb = w.xb; a.y = w.y; a.dvec = w.dvec; a.move = w.move; a.rvec = w.rvec;
+    a.basic = w.basic; a.nonbasic = w.nonbasic;
+    a.pk_price = w.pk_price; a.pi_price = w.pi_price; a.pk_ratio = w.pk_ratio; a.pi_ratio = w.pi_ratio;
+    a.st = w.st;
+    a.trace = trace_on_ ? w.trace : nullptr;
+    a.trace_cap = w.trace_cap;
+    return a;
+}
+
+void Engine::sync_state_to_device() {
+    hipMemcpyAsync(w_->st, w_->st_host, sizeof(DevState), hipMemcpyHostToDevice, stream_);
+}
+
+int Engine::refresh_xb_y(const Problem &P, const double *cost) {
+    Work &w = *w_;
+    launch_matvec_rows(w.binv[cur_], P.ld, P.m, P.db, w.xb, stream_);
+    launch_y_from_binv(w.binv[cur_], P.ld, P.m, cost, w.basic, w.yscratch, w.y, stream_);
+    launches_ += 3;
+    return GOMILP_OK;
+}
+
+int Engine::upload_index_lists(const std::vector<int32_t> &basic, const std::vector<int32_t> &nonbasic) {
+    Work &w = *w_;
+    if (!basic.empty()) HIP_TRY(hipMemcpyAsync(w.basic, basic.data(), basic.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    if (!nonbasic.empty()) HIP_TRY(hipMemcpyAsync(w.nonbasic, nonbasic.data(), nonbasic.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));  // the vectors are pageable host memory
+    return GOMILP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// replaceBland (simplex.go:347-383), host-driven: candidates are tried one at a time with the FTRAN
+// kernel.  Deviation: the `mat.Cond(abTmp,1) < 1e16` guard of :377 is replaced by the
+// pivot-magnitude guard |d_replace| >= dRoundTol that move[replace] < +Inf already implies.
+// ------------------------------------------------------------------------------------------------
+int Engine::host_bland(const Problem &P, LPArgs &a, gomilp_lp_stats *st) {
+    Work &w = *w_;
+    const int m = P.m, nn = a.nn;
+    std::vector<double> r(nn), move(m);
+    HIP_TRY(hipMemcpyAsync(w.h_vec, w.rvec, (size_t)nn * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    for (int j = 0; j < nn; j++) { r[j] = w.h_vec[j]; if (fabs(r[j]) < 1e-13) r[j] = 0; }  // rRoundTol, :252-256
+    for (int i = 0; i < nn; i++) {
+        if (r[i] > -1e-14) continue;  // blandNegTol, :352
+        w.st_host->done = 0; w.st_host->status = ST_RUNNING;
+        sync_state_to_device();
+        launch_ftran(a, 0, i, -1, stream_);
+        launches_++;
+        HIP_TRY(hipMemcpyAsync(w.h_vec, w.move, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        for (int k = 0; k < m; k++) move[k] = w.h_vec[k];
+        int64_t replace = min_idx(move.data(), m);
+        if (move[replace] == std::numeric_limits<double>::infinity()) return GOMILP_ERR_UNBOUNDED;  // computeMove :328
+        if (!(fabs(move[replace]) > 1e-12)) {  // blandZeroTol, :362
+            replace = -1;
+            for (int rp = 0; rp < m; rp++)
+                if (!(move[rp] > 1e-12)) { replace = rp; break; }  // :368-379 (cond guard: see header comment)
+            if (replace < 0) continue;
+        }
+        launch_update(a, 0, (int)replace, 0, 1, stream_);
+        launches_++;
+        cur_ ^= 1;
+        if (st) st->bland_steps++;
+        // pivots counter is advanced on device by the update kernel
+        return GOMILP_OK;
+    }
+    return GOMILP_ERR_BLAND;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pivot loop (simplex.go:233-293): chunks of (price, ftran, update) launches; the kernels stop
+// themselves through DevState::done, the host looks at the state after each chunk.
+// returns GOMILP_OK when the loop ended at an optimum, else the reference's error class.
+// ------------------------------------------------------------------------------------------------
+int Engine::run_loop(const Problem &P, int phase, double tol, int nn, const double *cost, gomilp_lp_stats *st) {
+    Work &w = *w_;
+    DevState &hs = *w.st_host;
+    hs.done = 0; hs.status = ST_RUNNING; hs.pivots = 0; hs.q = hs.p = -1; hs.rq = hs.dp = hs.mv = 0;
+    hs.max_pivots = max_pivots_;
+    hs.lu_singular = 0;
+    // trace_len is cumulative over the solve
+    sync_state_to_device();
+    int64_t since_refresh = 0;
+    HIP_TRY(hipEventRecord(w.ev[0], stream_));
+    int ret = GOMILP_OK;
+    const bool sampling = sample_events_ > 0;
+    for (;;) {
+        const int64_t before = hs.pivots;
+        std::vector<int64_t> sample_t;  // chunk-local pivot index of every sampled pivot
+        for (int64_t t = 0; t < chunk_; t++) {
+            LPArgs a = make_args(P, phase, tol, nn, cost);
+            a.binv_cur = w.binv[(cur_ + t) & 1];
+            a.binv_next = w.binv[(cur_ + t + 1) & 1];
+            const bool sample = sampling && ((before + t) % sample_events_ == 0);
+            const size_t e0 = sample_t.size() * 4;
+            if (sample) {
+                while (w.sample_ev.size() < e0 + 4) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); w.sample_ev.push_back(e); }
+                HIP_TRY(hipEventRecord(w.sample_ev[e0 + 0], stream_));
+            }
+            const int gp = launch_price(a, stream_);
+            if (sample) HIP_TRY(hipEventRecord(w.sample_ev[e0 + 1], stream_));
+            const int gr = launch_ftran(a, gp, -1, -1, stream_);
+            if (sample) HIP_TRY(hipEventRecord(w.sample_ev[e0 + 2], stream_));
+            launch_update(a, gr, -1, 0, 0, stream_);
+            if (sample) { HIP_TRY(hipEventRecord(w.sample_ev[e0 + 3], stream_)); sample_t.push_back(t); }
+            launches_ += 3;
+        }
+        HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(hipGetLastError());
+        const int64_t executed = hs.pivots - before;
+        cur_ = (int)((cur_ + executed) & 1);
+        since_refresh += executed;
+        if (st) {
+            // only pivots that really executed (kernels not yet stopped by DevState::done) are meaningful samples
+            for (size_t s = 0; s < sample_t.size(); s++) {
+                if (sample_t[s] >= executed) break;
+                float ms[3];
+                bool ok = true;
+                for (int k = 0; k < 3; k++)
+                    ok = ok && hipEventElapsedTime(&ms[k], w.sample_ev[s * 4 + k], w.sample_ev[s * 4 + k + 1]) == hipSuccess;
+                if (!ok) continue;
+                st->pivot_kernel_seconds[0] += ms[0] * 1e-3;
+                st->pivot_kernel_seconds[1] += ms[1] * 1e-3;
+                st->pivot_kernel_seconds[2] += ms[2] * 1e-3;
+                st->pivot_kernel_seconds[3] += 1.0;  // number of sampled pivots
+            }
+        }
+        if (!hs.done) {
+            if (refresh_ > 0 && since_refresh >= refresh_) {
+                refresh_xb_y(P, cost);
+                since_refresh = 0;
+                if (st) st->refreshes++;
+            }
+            continue;
+        }
+        if (hs.status == ST_OPTIMAL) break;
+        if (hs.status == ST_UNBOUNDED) { ret = GOMILP_ERR_UNBOUNDED; break; }
+        if (hs.status == ST_MAX_PIVOTS) { ret = GOMILP_ERR_UNSUPPORTED; break; }
+        if (hs.status == ST_NEED_BLAND) {
+            LPArgs a = make_args(P, phase, tol, nn, cost);
+            int rc = host_bland(P, a, st);
+            if (rc != GOMILP_OK) { ret = rc; break; }
+            // resume: the update kernel of the Bland step has been enqueued; read the state back after it
+            HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipStreamSynchronize(stream_));
+            hs.done = 0; hs.status = ST_RUNNING;
+            sync_state_to_device();
+            continue;
+        }
+        ret = GOMILP_ERR_DEVICE;
+        break;
+    }
+    HIP_TRY(hipEventRecord(w.ev[1], stream_));
+    HIP_TRY(hipEventSynchronize(w.ev[1]));
+    float ms = 0;
+    hipEventElapsedTime(&ms, w.ev[0], w.ev[1]);
+    if (st) {
+        st->seconds_pivot_loop += ms * 1e-3;
+        if (phase == 1) st->pivots_phase1 += hs.pivots; else st->pivots_phase2 += hs.pivots;
+    }
+    return ret;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Final solve x_B = ab^-1 b in gonum's order: LU on the device (k_lu_*), the two triangular solves
+// of Dgetrs (lapack/gonum/dgetrs.go:37-45 -> blas/gonum/level3double.go:75-118) on the host, because
+// the upper solve is one sequential dependency chain of m^2/2 rounded operations.
+// ------------------------------------------------------------------------------------------------
+int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *singular) {
+    Work &w = *w_;
+    const int m = P.m, ldw = P.ld;
+    launch_gather_w(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
+    LUArgs a;
+    a.W = w.W; a.ldw = ldw; a.m = m; a.lpos = w.lpos; a.rowstep = w.rowstep;
+    for (int t = 0; t < 2; t++) { a.pk[t] = w.lpk[t]; a.pl[t] = w.lpl[t]; a.pr[t] = w.lpr[t]; }
+    a.st = w.st;
+    w.st_host->lu_singular = 0;
+    sync_state_to_device();
+    launch_lu(a, stream_);
+    launches_ += m + 2;
+    HIP_TRY(hipMemcpyAsync(w.h_W, w.W, (size_t)m * ldw * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(w.h_idx, w.lpos, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> phys(m);
+    for (int R = 0; R < m; R++) phys[w.h_idx[R]] = R;
+    // LU.Det() == 0 (mat/lu.go:301, :118-135): exp(sum log|u_ii|) == 0
+    double logdet = 0;
+    for (int i = 0; i < m; i++) logdet += log(fabs(w.h_W[(size_t)phys[i] * ldw + i]));
+    *singular = w.st_host->lu_singular != 0 || exp(logdet) == 0;
+    x.assign(m, 0.0);
+    if (*singular) return GOMILP_OK;
+    // Dlaswp: b in logical row order
+    for (int i = 0; i < m; i++) x[i] = P.hb[phys[i]];
+    // Dtrsm(Left, Lower, NoTrans, Unit): ascending k, zero multipliers skipped, (-l)*b_k + b_i
+    for (int i = 0; i < m; i++) {
+        const double *row = w.h_W + (size_t)phys[i] * ldw;
+        double bi = x[i];
+        for (int k = 0; k < i; k++) {
+            const double va = row[k];
+            if (va != 0) bi = (-va) * x[k] + bi;
+        }
+        x[i] = bi;
+    }
+    // Dtrsm(Left, Upper, NoTrans, NonUnit): rows from the bottom, ascending k, then * (1/u_ii)
+    for (int i = m - 1; i >= 0; i--) {
+        const double *row = w.h_W + (size_t)phys[i] * ldw;
+        double bi = x[i];
+        for (int k = i + 1; k < m; k++) {
+            const double va = row[k];
+            if (va != 0) bi = (-va) * x[k] + bi;
+        }
+        const double t = 1 / row[i];
+        x[i] = bi * t;
+    }
+    return GOMILP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// simplex() — simplex.go:93-302
+// ------------------------------------------------------------------------------------------------
+int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *opt_f, double *opt_x, int32_t *has_x,
+                  int64_t *basis_out, gomilp_lp_stats *stats) {
+    std::lock_guard<std::mutex> g(mu_);
+    const double t0 = now_s();
+    gomilp_lp_stats local;
+    gomilp_lp_stats *st = stats ? stats : &local;
+    memset(st, 0, sizeof(*st));
+    st->device_id = device_;
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    const double inf = std::numeric_limits<double>::infinity();
+    if (has_x) *has_x = 0;
+    if (opt_f) *opt_f = nan;
+    if (id < 0 || (size_t)id >= problems_.size() || !problems_[id] || !opt_f || !opt_x || !has_x) return GOMILP_ERR_BAD_SHAPE;
+    const Problem &P = *problems_[id];
+    st->seconds_upload = P.seconds_upload;
+    auto finish = [&](int code) { st->seconds_total = now_s() - t0; st->kernel_launches = launches_; return code; };
+    launches_ = 0;
+    last_trace_.clear();
+    last_trace_total_ = 0;
+    if (P.verify_status != GOMILP_OK) {  // simplex.go:94-100
+        if (P.verify_status == GOMILP_ERR_UNBOUNDED) *opt_f = -inf;
+        return finish(P.verify_status);
+    }
+    const int m = P.m, n = P.n;
+    if (initial_basic) return finish(GOMILP_ERR_UNSUPPORTED);  // GoMILP always passes nil (subproblem.go:154,172)
+    int rc = ensure_work(m, n + 1);
+    if (rc != GOMILP_OK) return finish(rc);
+    Work &w = *w_;
+    w.st_host->trace_len = 0;
+    std::vector<double> xb_exact;
+    bool singular = false;
+
+    if (m == n) {  // simplex.go:103-119: exactly constrained, one linear solve
+        std::vector<int32_t> ident(n);
+        for (int j = 0; j < n; j++) ident[j] = j;
+        if ((rc = upload_index_lists(ident, {})) != GOMILP_OK) return finish(rc);
+        const double t1 = now_s();
+        if ((rc = final_solve(P, n, xb_exact, &singular)) != GOMILP_OK) return finish(rc);
+        st->seconds_final_solve = now_s() - t1;
+        if (singular) return finish(GOMILP_ERR_SINGULAR);
+        for (int j = 0; j < n; j++)
+            if (xb_exact[j] < 0) return finish(GOMILP_ERR_INFEASIBLE);
+        *opt_f = dot_unitary(xb_exact.data(), P.hc.data(), n);
+        memcpy(opt_x, xb_exact.data(), sizeof(double) * (size_t)n);
+        *has_x = 1;
+        return finish(GOMILP_OK);
+    }
+    if (m > n) return finish(GOMILP_ERR_SINGULAR);  // findLinearlyIndependent cannot reach m columns (:495-497)
+
+    // findLinearlyIndependent (simplex.go:611-637), unit-column fast path: the descending scan meets m distinct
+    // unit vectors (always true for GoMILP's [.. | I] standard forms, subproblem.go:81-139); cond == 1 there.
+    std::vector<int32_t> basic(m), rho(m);
+    {
+        std::vector<char> used(m, 0);
+        for (int pos = 0; pos < m; pos++) {
+            const int j = n - 1 - pos;
+            if (!(P.nnz[j] == 1 && P.allone[j]) || used[P.lastrow[j]]) return finish(GOMILP_ERR_UNSUPPORTED);
+            rho[pos] = P.lastrow[j]; used[rho[pos]] = 1; basic[pos] = j;
+        }
+    }
+    // ab = permutation, xb = ab^-1 b exactly (initializeFromBasic, simplex.go:447-471)
+    std::vector<double> xb(m);
+    bool feasible = true;
+    for (int pos = 0; pos < m; pos++) { xb[pos] = P.hb[rho[pos]]; if (xb[pos] < -1e-13) feasible = false; }
+    cur_ = 0;
+    HIP_TRY(hipMemsetAsync(w.binv[0], 0, (size_t)m * P.ld * sizeof(double), stream_));
+    HIP_TRY(hipMemcpyAsync(w.rho, rho.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    launch_set_binv_perm(w.binv[0], P.ld, m, w.rho, stream_);
+    HIP_TRY(hipMemsetAsync(w.xb, 0, (size_t)P.ld * sizeof(double), stream_));
+    HIP_TRY(hipMemsetAsync(w.y, 0, (size_t)P.ld * sizeof(double), stream_));
+    HIP_TRY(hipMemcpyAsync(w.xb, xb.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+
+    std::vector<int32_t> nonbasic;
+    auto build_nonbasic = [&](int ncols) {  // simplex.go:174-184: ascending ids not in the basis
+        std::vector<char> inb(ncols, 0);
+        for (int i = 0; i < m; i++) inb[basic[i]] = 1;
+        nonbasic.clear();
+        for (int j = 0; j < ncols; j++) if (!inb[j]) nonbasic.push_back(j);
+    };
+
+    if (!feasible) {
+        // ---- Phase I (simplex.go:529-606) ----
+        st->phase1_used = 1;
+        const int64_t minidx = min_idx(xb.data(), m);
+        // a_{n+1} = b - sum_{i != minidx} a_{basic_i}: for unit columns one exact "- 1" per row (floats.Sub, :536-542)
+        std::vector<double> art(P.ld, 0.0);
+        for (int k = 0; k < m; k++) art[k] = P.hb[k];
+        for (int i = 0; i < m; i++) { if (i == minidx) continue; art[rho[i]] = -1 * 1.0 + art[rho[i]]; }
+        bool art_zero = true;
+        for (int k = 0; k < m; k++) if (art[k] != 0) { art_zero = false; break; }
+        if (art_zero) { st->wrapped_status = GOMILP_ERR_ZERO_COLUMN; return finish(GOMILP_ERR_PHASE1_WRAPPED); }  // verifyInputs of the recursive call
+        HIP_TRY(hipMemcpyAsync(P.dAt + (size_t)n * P.ld, art.data(), (size_t)P.ld * sizeof(double), hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        // basis := slack basis with position minidx replaced by the artificial: one forced pivot builds its inverse
+        w.st_host->done = 0; w.st_host->status = ST_RUNNING; w.st_host->pivots = 0; w.st_host->max_pivots = 0; w.st_host->rq = 0;
+        sync_state_to_device();
+        {
+            LPArgs a = make_args(P, 1, 1e-10, 0, P.dc1);
+            launch_ftran(a, 0, -1, n, stream_);
+            launch_update(a, 0, (int)minidx, 1, 0, stream_);
+            launches_ += 2;
+            cur_ ^= 1;
+        }
+        basic[minidx] = n;
+        build_nonbasic(n + 1);
+        if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return finish(rc);
+        refresh_xb_y(P, P.dc1);  // xb = ab^-1 b (initializeFromBasic of the recursive call), y = ab^-T cb
+        HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        for (int i = 0; i < m; i++) if (w.h_vec[i] < -1e-13) return finish(GOMILP_ERR_PANIC);  // simplex.go:155-158
+        rc = run_loop(P, 1, 1e-10, (int)nonbasic.size(), P.dc1, st);
+        if (rc == GOMILP_ERR_DEVICE) return finish(rc);
+        if (rc != GOMILP_OK) { st->wrapped_status = rc; return finish(GOMILP_ERR_PHASE1_WRAPPED); }  // :557-559
+        HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        int added = -1;
+        for (int i = 0; i < m; i++) { basic[i] = w.h_idx[i]; xb[i] = w.h_vec[i]; if (basic[i] == n) added = i; }
+        double xart = added >= 0 ? xb[added] : 0.0;
+        if (added >= 0 && fabs(xart) > 1e-13 && fabs(xart) < 1e-11) {
+            // too close to phaseIZeroTol to trust the updated x_B: take the reference's own value (fresh gonum-order solve)
+            if ((rc = final_solve(P, n + 1, xb_exact, &singular)) != GOMILP_OK) return finish(rc);
+            if (!singular) xart = xb_exact[added];
+        }
+        if (fabs(xart) > 1e-12) return finish(GOMILP_ERR_INFEASIBLE);  // phaseIZeroTol, :563-565
+        if (added >= 0) {
+            // :581-606 the artificial stayed basic at zero: exchange it for the first nonbasic column that keeps
+            // the basis nonsingular and feasible.  Guard on the pivot element instead of the LU condition estimate.
+            bool exchanged = false;
+            std::vector<char> inb(n + 1, 0);
+            for (int i = 0; i < m; i++) inb[basic[i]] = 1;
+            for (int j = 0; j < n && !exchanged; j++) {
+                if (inb[j]) continue;
+                w.st_host->done = 0; w.st_host->status = ST_RUNNING; w.st_host->rq = 0;
+                sync_state_to_device();
+                LPArgs a = make_args(P, 1, 1e-10, 0, P.dc1);
+                launch_ftran(a, 0, -1, j, stream_);
+                launches_++;
+                HIP_TRY(hipMemcpyAsync(w.h_vec, w.dvec, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+                HIP_TRY(hipStreamSynchronize(stream_));
+                double dmax = 0;
+                for (int i = 0; i < m; i++) dmax = std::max(dmax, fabs(w.h_vec[i]));
+                const double dpv = w.h_vec[added];
+                if (!(fabs(dpv) > 1e-9 * std::max(1.0, dmax))) continue;
+                const double theta = xb[added] / dpv;
+                bool feas = true;
+                for (int i = 0; i < m && feas; i++) {
+                    const double v = (i == added) ? theta : xb[i] - theta * w.h_vec[i];
+                    if (v < -1e-13) feas = false;
+                }
+                if (!feas) continue;
+                launch_update(a, 0, added, 1, 0, stream_);
+                launches_++;
+                cur_ ^= 1;
+                basic[added] = j;
+                exchanged = true;
+            }
+            if (!exchanged) return finish(GOMILP_ERR_INFEASIBLE);  // :606
+        }
+    }
+
+    // ---- Phase II (simplex.go:169-293) ----
+    build_nonbasic(n);
+    if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return finish(rc);
+    if (st->phase1_used) {
+        refresh_xb_y(P, P.dc);
+    } else {
+        launch_y_from_binv(w.binv[cur_], P.ld, m, P.dc, w.basic, w.yscratch, w.y, stream_);
+        launches_ += 2;
+    }
+    int loop_rc = run_loop(P, 2, tol, (int)nonbasic.size(), P.dc, st);
+    if (loop_rc == GOMILP_ERR_DEVICE) return finish(loop_rc);
+    if (loop_rc == GOMILP_ERR_UNBOUNDED) { *opt_f = -inf; return finish(loop_rc); }  // :261-263, :272-274
+
+    // ---- epilogue (simplex.go:296-301): x_B from a fresh gonum-order solve on the final basis ----
+    HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    for (int i = 0; i < m; i++) { basic[i] = w.h_idx[i]; xb[i] = w.h_vec[i]; }
+    const double t1 = now_s();
+    if ((rc = final_solve(P, n, xb_exact, &singular)) != GOMILP_OK) return finish(rc);
+    st->seconds_final_solve = now_s() - t1;
+    if (singular) {
+        xb_exact = xb;  // the reference keeps its previous x_B when Det()==0 (mat/lu.go:301); ours is the updated one
+        if (loop_rc == GOMILP_OK) loop_rc = GOMILP_ERR_CONDITION;
+    }
+    double drift = 0;
+    for (int i = 0; i < m; i++) drift = std::max(drift, fabs(xb[i] - xb_exact[i]));
+    st->drift_xb = drift;
+    std::vector<double> cb(m);
+    for (int i = 0; i < m; i++) cb[i] = P.hc[basic[i]];
+    *opt_f = dot_unitary(cb.data(), xb_exact.data(), m);
+    for (int j = 0; j < n; j++) opt_x[j] = 0;
+    for (int i = 0; i < m; i++) opt_x[basic[i]] = xb_exact[i];
+    *has_x = 1;
+    if (basis_out) for (int i = 0; i < m; i++) basis_out[i] = basic[i];
+    if (trace_on_) {
+        HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        last_trace_total_ = w.st_host->trace_len;
+        const int64_t cnt = std::min<int64_t>(last_trace_total_, w.trace_cap);
+        std::vector<DevPivot> tmp((size_t)cnt);
+        if (cnt) HIP_TRY(hipMemcpy(tmp.data(), w.trace, (size_t)cnt * sizeof(DevPivot), hipMemcpyDeviceToHost));
+        last_trace_.resize((size_t)cnt);
+        for (int64_t i = 0; i < cnt; i++) {
+            last_trace_[i].phase = tmp[i].phase; last_trace_[i].bland = tmp[i].bland;
+            last_trace_[i].min_idx = tmp[i].min_idx; last_trace_[i].replace = tmp[i].replace;
+            last_trace_[i].entering = tmp[i].entering; last_trace_[i].leaving = tmp[i].leaving;
+        }
+    }
+    return finish(loop_rc);
+}
+
+int64_t Engine::last_trace(gomilp_pivot *out, int64_t cap) {
+    std::lock_guard<std::mutex> g(mu_);
+    const int64_t cnt = std::min<int64_t>((int64_t)last_trace_.size(), cap);
+    if (out && cnt > 0) memcpy(out, last_trace_.data(), (size_t)cnt * sizeof(gomilp_pivot));
+    return last_trace_total_;
+}
+
+}  // namespace gomilp

@@ -1,0 +1,88 @@
+// Host-side engine of the gfx950 LP-relaxation path: owns the HBM-resident problem and work buffers,
+// enqueues the pivot kernels in chunks on one HIP stream, and reproduces the control flow of
+// gonum's simplex() (vendor/gonum.org/v1/gonum/optimize/convex/lp/simplex.go:93-302) around them.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gomilp_lp.h"
+#include "device_types.h"
+
+namespace gomilp {
+
+// A standard-form LP resident in HBM.
+struct Problem {
+    int m = 0, n = 0, ld = 0;
+    double *dAt = nullptr;    // (n+1) x ld : row j = column j of A; row n is reserved for the Phase-I artificial column
+    double *dc = nullptr;     // n+1 : c, then 0
+    double *dc1 = nullptr;    // n+1 : Phase-I cost e_n
+    double *db = nullptr;     // ld  : b, zero padded
+    std::vector<double> hb, hc;
+    std::vector<int32_t> nnz, lastrow, allone;  // per column of A
+    int verify_status = GOMILP_OK;              // verifyInputs, simplex.go:385-439
+    double seconds_upload = 0;
+};
+
+class Engine {
+   public:
+    explicit Engine(int device);
+    ~Engine();
+    int device() const { return device_; }
+    int set(const std::string &key, int64_t v);
+
+    int64_t upload(const double *c, const double *A, int64_t lda, const double *b, int64_t m, int64_t n);
+    int free_problem(int64_t id);
+    int solve(int64_t id, double tol, const int64_t *initial_basic, double *opt_f, double *opt_x, int32_t *has_x,
+              int64_t *basis_out, gomilp_lp_stats *stats);
+    int64_t last_trace(gomilp_pivot *out, int64_t cap);
+
+   private:
+    struct Work;  // device work buffers, sized for the largest problem seen
+    int ensure_work(int m, int ncols);
+    LPArgs make_args(const Problem &P, int phase, double tol, int nn, const double *cost);
+    int run_loop(const Problem &P, int phase, double tol, int nn, const double *cost, gomilp_lp_stats *st);
+    int host_bland(const Problem &P, LPArgs &a, gomilp_lp_stats *st);
+    int refresh_xb_y(const Problem &P, const double *cost);
+    int final_solve(const Problem &P, int ncols_rows, std::vector<double> &xb_exact, bool *singular);
+    int upload_index_lists(const std::vector<int32_t> &basic, const std::vector<int32_t> &nonbasic);
+    void sync_state_to_device();
+
+    int device_;
+    hipStream_t stream_ = nullptr;
+    std::mutex mu_;
+    std::vector<std::unique_ptr<Problem>> problems_;
+    std::unique_ptr<Work> w_;
+    // knobs
+    int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0;
+    // per-solve state
+    int cur_ = 0;  // which Binv buffer is current
+    int64_t launches_ = 0;
+    std::vector<gomilp_pivot> last_trace_;
+    int64_t last_trace_total_ = 0;
+};
+
+int device_count();
+const char *compiled_arch();
+
+// launch wrappers implemented in simplex_kernels.hip
+int launch_price(const LPArgs &a, hipStream_t s);
+int launch_ftran(const LPArgs &a, int nparts_price, int forced_pos, int forced_var, hipStream_t s);
+void launch_update(const LPArgs &a, int nparts_ratio, int forced_p, int no_swap, int bland, hipStream_t s);
+void launch_transpose_in(const double *A, int64_t lda, int m, int n, double *At, int ld, hipStream_t s);
+void launch_col_stats(const double *At, int ld, int m, int n, int32_t *nnz, int32_t *lastrow, int32_t *allone,
+                      int32_t *rowflag, hipStream_t s);
+void launch_set_binv_perm(double *binv, int ld, int m, const int32_t *rho, hipStream_t s);
+void launch_matvec_rows(const double *M, int ld, int m, const double *vec, double *out, hipStream_t s);
+int y_chunks(int m);
+void launch_y_from_binv(const double *binv, int ld, int m, const double *cost, const int32_t *basic, double *scratch,
+                        double *y, hipStream_t s);
+void launch_gather_w(const double *At, int ld, int m, const int32_t *basic, double *W, int ldw, hipStream_t s);
+int lu_grid(int m);
+void launch_lu(const LUArgs &a, hipStream_t s);
+
+}  // namespace gomilp

@@ -1,0 +1,205 @@
+"""Host-side mirror of the reference interface for the hot path, over the C-ABI.
+
+``simplex(c, A, b, tol, initial_basic)`` has the argument meaning and error behaviour of gonum's
+``lp.Simplex`` (/root/reference/vendor/gonum.org/v1/gonum/optimize/convex/lp/simplex.go:88) as GoMILP calls
+it (/root/reference/subproblem.go:154,172).  Everything runs in libgomilp_hip.so on the MI355X; there is no
+CPU fallback: a missing library or device raises / returns ERR_DEVICE.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import build as _build
+
+# status codes — include/gomilp_lp.h
+OK, ERR_BLAND, ERR_INFEASIBLE, ERR_LINSOLVE, ERR_UNBOUNDED, ERR_SINGULAR = 0, 1, 2, 3, 4, 5
+ERR_ZERO_COLUMN, ERR_ZERO_ROW, ERR_CONDITION, ERR_PHASE1_WRAPPED, ERR_BAD_SHAPE, ERR_PANIC = 6, 7, 8, 9, 10, 11
+ERR_DEVICE, ERR_UNSUPPORTED = 12, 13
+
+STATUS_NAMES = {
+    OK: "ok", ERR_BLAND: "ErrBland", ERR_INFEASIBLE: "ErrInfeasible", ERR_LINSOLVE: "ErrLinSolve",
+    ERR_UNBOUNDED: "ErrUnbounded", ERR_SINGULAR: "ErrSingular", ERR_ZERO_COLUMN: "ErrZeroColumn",
+    ERR_ZERO_ROW: "ErrZeroRow", ERR_CONDITION: "mat.Condition", ERR_PHASE1_WRAPPED: "phase1-wrapped",
+    ERR_BAD_SHAPE: "panic:badShape", ERR_PANIC: "panic", ERR_DEVICE: "device", ERR_UNSUPPORTED: "unsupported",
+}
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("pivots_phase1", C.c_int64), ("pivots_phase2", C.c_int64), ("bland_steps", C.c_int64),
+        ("refreshes", C.c_int64), ("kernel_launches", C.c_int64),
+        ("phase1_used", C.c_int32), ("device_id", C.c_int32), ("wrapped_status", C.c_int32), ("reserved", C.c_int32),
+        ("seconds_total", C.c_double), ("seconds_upload", C.c_double), ("seconds_pivot_loop", C.c_double),
+        ("seconds_final_solve", C.c_double), ("drift_xb", C.c_double), ("pivot_kernel_seconds", C.c_double * 4),
+    ]
+
+
+class Pivot(C.Structure):
+    _fields_ = [("phase", C.c_int32), ("bland", C.c_int32), ("min_idx", C.c_int64), ("replace", C.c_int64),
+                ("entering", C.c_int64), ("leaving", C.c_int64)]
+
+
+EXPORTS = [
+    "gomilp_lp_simplex", "gomilp_ctx_create", "gomilp_ctx_destroy", "gomilp_ctx_device", "gomilp_ctx_set",
+    "gomilp_lp_upload", "gomilp_lp_free", "gomilp_lp_solve_resident", "gomilp_lp_last_trace", "gomilp_version",
+    "gomilp_device_count", "gomilp_compiled_arch",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libgomilp_hip.so (building it in-tree if hipcc is present and it is stale).  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build()
+    L = C.CDLL(path)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int64)
+    L.gomilp_version.restype = C.c_char_p
+    L.gomilp_compiled_arch.restype = C.c_char_p
+    L.gomilp_device_count.restype = C.c_int
+    L.gomilp_ctx_create.restype = C.c_void_p
+    L.gomilp_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    L.gomilp_ctx_destroy.argtypes = [C.c_void_p]
+    L.gomilp_ctx_device.argtypes = [C.c_void_p]
+    L.gomilp_ctx_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.gomilp_lp_upload.restype = C.c_int64
+    L.gomilp_lp_upload.argtypes = [C.c_void_p, dp, dp, C.c_int64, dp, C.c_int64, C.c_int64]
+    L.gomilp_lp_free.argtypes = [C.c_void_p, C.c_int64]
+    L.gomilp_lp_solve_resident.argtypes = [C.c_void_p, C.c_int64, C.c_double, ip, dp, dp, C.POINTER(C.c_int32), ip,
+                                           C.POINTER(Stats)]
+    L.gomilp_lp_last_trace.restype = C.c_int64
+    L.gomilp_lp_last_trace.argtypes = [C.c_void_p, C.POINTER(Pivot), C.c_int64]
+    L.gomilp_lp_simplex.argtypes = [dp, dp, C.c_int64, dp, C.c_int64, C.c_int64, C.c_double, ip, dp, dp,
+                                    C.POINTER(C.c_int32), ip, C.POINTER(Stats)]
+    _lib = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+@dataclass
+class LPResult:
+    status: int
+    z: float
+    x: Optional[np.ndarray]
+    basis: Optional[np.ndarray]
+    stats: dict = field(default_factory=dict)
+    pivots: List[tuple] = field(default_factory=list)
+
+    @property
+    def ok(self) -> bool:
+        return self.status == OK
+
+
+def _stats_dict(s: Stats) -> dict:
+    d = {k: getattr(s, k) for k, _ in Stats._fields_ if k not in ("pivot_kernel_seconds", "reserved")}
+    d["pivot_kernel_seconds"] = list(s.pivot_kernel_seconds)
+    return d
+
+
+def simplex(c, A, b, tol: float = 0.0, initial_basic=None) -> LPResult:
+    """lp.Simplex drop-in through the flat C-ABI call (host buffers in, host buffers out)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    m, n = A.shape
+    if c.shape != (n,) or b.shape != (m,):
+        return LPResult(ERR_BAD_SHAPE, math.nan, None, None)  # the reference panics (simplex.go:387-398)
+    x = np.zeros(n)
+    basis = np.zeros(m, dtype=np.int64)
+    z = C.c_double(math.nan)
+    has_x = C.c_int32(0)
+    st = Stats()
+    ib = None if initial_basic is None else np.ascontiguousarray(initial_basic, dtype=np.int64)
+    rc = lib().gomilp_lp_simplex(_dp(c), _dp(A), n, _dp(b), m, n, float(tol), None if ib is None else _ip(ib),
+                                 C.byref(z), _dp(x), C.byref(has_x), _ip(basis), C.byref(st))
+    return LPResult(rc, z.value, x if has_x.value else None, basis if has_x.value and m != n else None, _stats_dict(st))
+
+
+class Context:
+    """One engine context (HIP stream + work buffers) on one GPU; problems stay resident in HBM."""
+
+    def __init__(self, device: int = -1, **knobs):
+        st = C.c_int(0)
+        self._h = lib().gomilp_ctx_create(int(device), C.byref(st))
+        if not self._h:
+            raise RuntimeError("gomilp_ctx_create failed: %s (no HIP device or libgomilp_hip.so not usable)"
+                               % STATUS_NAMES.get(st.value, st.value))
+        for k, v in knobs.items():
+            self.set(k, v)
+
+    def set(self, key: str, value: int) -> None:
+        rc = lib().gomilp_ctx_set(self._h, key.encode(), int(value))
+        if rc != OK:
+            raise ValueError("bad knob %s=%s" % (key, value))
+
+    @property
+    def device(self) -> int:
+        return lib().gomilp_ctx_device(self._h)
+
+    def upload(self, c, A, b) -> "ResidentLP":
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        c = np.ascontiguousarray(c, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        m, n = A.shape
+        if c.shape != (n,) or b.shape != (m,):
+            raise ValueError("lp: size mismatch")
+        pid = lib().gomilp_lp_upload(self._h, _dp(c), _dp(A), n, _dp(b), m, n)
+        if pid < 0:
+            raise RuntimeError("gomilp_lp_upload failed: %s" % STATUS_NAMES.get(-pid, -pid))
+        return ResidentLP(self, pid, m, n)
+
+    def close(self) -> None:
+        if self._h:
+            lib().gomilp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ResidentLP:
+    def __init__(self, ctx: Context, pid: int, m: int, n: int):
+        self.ctx, self.pid, self.m, self.n = ctx, pid, m, n
+
+    def solve(self, tol: float = 0.0, trace: bool = False) -> LPResult:
+        L = lib()
+        x = np.zeros(self.n)
+        basis = np.zeros(self.m, dtype=np.int64)
+        z = C.c_double(math.nan)
+        has_x = C.c_int32(0)
+        st = Stats()
+        self.ctx.set("trace", 1 if trace else 0)
+        rc = L.gomilp_lp_solve_resident(self.ctx._h, self.pid, float(tol), None, C.byref(z), _dp(x), C.byref(has_x),
+                                        _ip(basis), C.byref(st))
+        piv = []
+        if trace:
+            total = L.gomilp_lp_last_trace(self.ctx._h, None, 0)
+            if total > 0:
+                buf = (Pivot * total)()
+                L.gomilp_lp_last_trace(self.ctx._h, buf, total)
+                piv = [(p.phase, p.bland, p.min_idx, p.replace, p.entering, p.leaving) for p in buf]
+        return LPResult(rc, z.value, x if has_x.value else None,
+                        basis if has_x.value and self.m != self.n else None, _stats_dict(st), piv)
+
+    def free(self) -> None:
+        if self.pid >= 0:
+            lib().gomilp_lp_free(self.ctx._h, self.pid)
+            self.pid = -1

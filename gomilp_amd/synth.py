@@ -1,0 +1,56 @@
+"""Synthetic inputs for the LP-relaxation hot path.
+
+PRNG: splitmix64(seed) -> u = (x >> 11) * 2**-53, reproducible in C/Go/Python.
+Dense LP(m, seed): G[i][j] = u (row-major fill order), h[i] = 1 + u, c[j] = -u, then the
+standard form A = [G | I_m], c = [c, 0], b = h is assembled exactly like
+convertToEqualities (/root/reference/subproblem.go:81-139) with A = nil.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def splitmix64_uniform(seed: int, count: int, offset: int = 0) -> np.ndarray:
+    """`count` uniforms in [0,1) from the splitmix64 stream of `seed`, starting at draw `offset`."""
+    with np.errstate(over="ignore"):
+        i = np.arange(offset + 1, offset + count + 1, dtype=np.uint64)
+        z = np.uint64(seed) + i * _GOLDEN
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
+
+
+def dense_lp_inequality_form(m: int, seed: int, nv: int | None = None):
+    """(c, G, h) with nv structural variables and m rows: minimise c.x s.t. G x <= h, x >= 0."""
+    nv = m if nv is None else nv
+    u = splitmix64_uniform(seed, m * nv + m + nv)
+    G = u[: m * nv].reshape(m, nv).copy()
+    h = 1.0 + u[m * nv : m * nv + m]
+    c = -u[m * nv + m :]
+    return c, G, h
+
+
+def dense_lp_standard_form(m: int, seed: int, nv: int | None = None):
+    """(c, A, b): A = [G | I_m] (m x (nv+m)), c = [c, 0], b = h — what lp.Simplex receives."""
+    c, G, h = dense_lp_inequality_form(m, seed, nv)
+    nv = G.shape[1]
+    A = np.zeros((m, nv + m))
+    A[:, :nv] = G
+    A[np.arange(m), nv + np.arange(m)] = 1.0
+    return np.concatenate([c, np.zeros(m)]), A, h.copy()
+
+
+def integrality_mask(nv: int, m: int) -> np.ndarray:
+    """C3/C5: structural variables with j % 4 == 0 are integer (25 %), slacks are not."""
+    mask = np.zeros(nv + m, dtype=bool)
+    mask[:nv:4] = True
+    return mask
+
+
+# BASELINE.json configs: name -> (m, seed)
+CONFIGS = {"C2": (1024, 1), "M": (2048, 2), "C4": (4096, 4), "C3": (512, 3), "C5": (512, 3)}

@@ -1,0 +1,123 @@
+/*
+ * gomilp_lp.h — C-ABI of the MI355X-native LP-relaxation engine.
+ *
+ * Drop-in boundary for GoMILP's one hot path: the call
+ *     z, x, err = lp.Simplex(c, A, b, 0, nil)
+ * at /root/reference/subproblem.go:154 (branch-and-bound child) and :172 (root), i.e.
+ * /root/reference/vendor/gonum.org/v1/gonum/optimize/convex/lp/simplex.go:88.
+ * The Go side binds these entry points through cgo (INTEGRATION.md shows the stub); all
+ * arguments are plain pointers and sizes, the caller owns every host buffer, nothing is
+ * retained after return (cgo pointer rules), and every entry point is thread-safe.
+ *
+ * There is no CPU fallback: without a usable HIP device every solve returns
+ * GOMILP_ERR_DEVICE.
+ */
+#ifndef GOMILP_LP_H
+#define GOMILP_LP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Status codes.  1..7 are the lp.Err* sentinels of simplex.go:26-34 that the Go wrapper maps
+ * back to the SAME sentinel values (GoMILP tests them by identity: ilp.go:37-40, tree.go:77,266-273). */
+typedef enum {
+    GOMILP_OK = 0,
+    GOMILP_ERR_BLAND = 1,          /* lp.ErrBland       simplex.go:27 */
+    GOMILP_ERR_INFEASIBLE = 2,     /* lp.ErrInfeasible  simplex.go:28 */
+    GOMILP_ERR_LINSOLVE = 3,       /* lp.ErrLinSolve    simplex.go:29 */
+    GOMILP_ERR_UNBOUNDED = 4,      /* lp.ErrUnbounded   simplex.go:30 — opt_f = -Inf, no x */
+    GOMILP_ERR_SINGULAR = 5,       /* lp.ErrSingular    simplex.go:31 */
+    GOMILP_ERR_ZERO_COLUMN = 6,    /* lp.ErrZeroColumn  simplex.go:32 */
+    GOMILP_ERR_ZERO_ROW = 7,       /* lp.ErrZeroRow     simplex.go:33 */
+    GOMILP_ERR_CONDITION = 8,      /* mat.Condition out of a mid-loop solve, simplex.go:236-239,289-292 */
+    GOMILP_ERR_PHASE1_WRAPPED = 9, /* fmt.Errorf("lp: error finding feasible basis: %s"), simplex.go:558 */
+    GOMILP_ERR_BAD_SHAPE = 10,     /* the reference panics: simplex.go:387-398 */
+    GOMILP_ERR_PANIC = 11,         /* any other reference panic (simplex.go:150,157) */
+    GOMILP_ERR_DEVICE = 12,        /* HIP runtime failure / no device / extension not built for it */
+    GOMILP_ERR_UNSUPPORTED = 13    /* input outside what this round's device path covers */
+} gomilp_status;
+
+/* Per-solve statistics (all optional output). */
+typedef struct gomilp_lp_stats {
+    int64_t pivots_phase1;      /* pivots of the Phase-I recursive simplex (simplex.go:556) */
+    int64_t pivots_phase2;      /* pivots of the Phase-II loop (simplex.go:233-293) */
+    int64_t bland_steps;        /* degenerate steps routed through replaceBland (simplex.go:269-277) */
+    int64_t refreshes;          /* times x_B / y were recomputed from B^-1 */
+    int64_t kernel_launches;    /* pivot-loop kernel launches enqueued */
+    int32_t phase1_used;        /* 1 when the initial basis was infeasible and Phase I ran */
+    int32_t device_id;
+    int32_t wrapped_status;     /* inner status when the result is GOMILP_ERR_PHASE1_WRAPPED */
+    int32_t reserved;
+    double seconds_total;       /* host wall clock of the call (upload included for the flat call) */
+    double seconds_upload;      /* host->device copies + layout conversion */
+    double seconds_pivot_loop;  /* HIP-event time of all pivot-loop kernels (Phase I + II) */
+    double seconds_final_solve; /* gonum-order LU on device + host triangular solves */
+    double drift_xb;            /* max |x_B(updated) - x_B(fresh LU)| at termination: accuracy of the B^-1 updates */
+    double pivot_kernel_seconds[4]; /* HIP-event time per kernel class: price, ftran, update, other */
+} gomilp_lp_stats;
+
+/* One record per pivot, execution order (Phase I first).  Same fields as the oracle's trace. */
+typedef struct gomilp_pivot {
+    int32_t phase;    /* 1 = Phase I, 2 = Phase II */
+    int32_t bland;    /* 1 when chosen by the Bland rule */
+    int64_t min_idx;  /* position in nonBasicIdx (simplex.go:247) */
+    int64_t replace;  /* position in basicIdxs   (simplex.go:268) */
+    int64_t entering; /* variable id entering */
+    int64_t leaving;  /* variable id leaving */
+} gomilp_pivot;
+
+/* ------------------------------------------------------------------------------------------
+ * Flat drop-in: signature-isomorphic to
+ *   func Simplex(c []float64, A mat.Matrix, b []float64, tol float64, initialBasic []int)
+ *        (optF float64, optX []float64, err error)                          — simplex.go:88
+ * A is the RawMatrix() of the *mat.Dense GoMILP always passes: row-major m x n, stride lda.
+ * opt_x (length n, caller-owned) is written only when *has_x = 1 (the reference returns nil x on
+ * most errors); a mid-loop failure returns the error AND the current point, like the reference.
+ * basis_out (nullable, length m) receives the final basicIdxs in positional order.
+ * ---------------------------------------------------------------------------------------- */
+int gomilp_lp_simplex(const double *c, const double *A, int64_t lda, const double *b, int64_t m, int64_t n,
+                      double tol, const int64_t *initial_basic, double *opt_f, double *opt_x, int32_t *has_x,
+                      int64_t *basis_out, gomilp_lp_stats *stats);
+
+/* ------------------------------------------------------------------------------------------
+ * Handle API: one context per (thread, GPU); problems stay resident in HBM so that a B&B
+ * frontier uploads the root (c, A0, b0) once (subproblem.go:20-29 shares them by pointer).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gomilp_ctx gomilp_ctx;
+
+/* device < 0: current HIP device.  Returns NULL (and *status) on failure. */
+gomilp_ctx *gomilp_ctx_create(int device, int *status);
+void gomilp_ctx_destroy(gomilp_ctx *ctx);
+int gomilp_ctx_device(const gomilp_ctx *ctx);
+/* knobs: "chunk" (pivots enqueued between host checks), "refresh" (pivots between x_B/y recomputations, 0 = never),
+ * "trace" (1 = record pivots), "max_pivots" (safety cap, 0 = none).  Returns GOMILP_OK or GOMILP_ERR_BAD_SHAPE. */
+int gomilp_ctx_set(gomilp_ctx *ctx, const char *key, int64_t value);
+
+/* Upload a standard-form LP (row-major A, stride lda) and keep it resident.  Returns a problem id >= 0, or
+ * -(gomilp_status) on failure.  Replaces the per-call operands of simplex.go:88. */
+int64_t gomilp_lp_upload(gomilp_ctx *ctx, const double *c, const double *A, int64_t lda, const double *b, int64_t m,
+                         int64_t n);
+int gomilp_lp_free(gomilp_ctx *ctx, int64_t problem);
+
+/* Solve a resident problem (inputs already in HBM: the timed region of bench.py).  Same outputs as the flat call. */
+int gomilp_lp_solve_resident(gomilp_ctx *ctx, int64_t problem, double tol, const int64_t *initial_basic,
+                             double *opt_f, double *opt_x, int32_t *has_x, int64_t *basis_out,
+                             gomilp_lp_stats *stats);
+
+/* Pivot trace of the last solve on this context (needs "trace" = 1).  Copies up to cap records, returns the
+ * total number of pivots performed. */
+int64_t gomilp_lp_last_trace(gomilp_ctx *ctx, gomilp_pivot *out, int64_t cap);
+
+/* Library / device probes (no compute): used by the loader checks and by __graft_entry__. */
+const char *gomilp_version(void);
+int gomilp_device_count(void);
+/* Name of the gfx target the kernels were compiled for ("gfx950"). */
+const char *gomilp_compiled_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOMILP_LP_H */

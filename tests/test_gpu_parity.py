@@ -1,0 +1,160 @@
+"""GPU parity tests: the HIP path (through the C-ABI of include/gomilp_lp.h) against the CPU oracle
+on the same seeded inputs, and against the reference's golden vectors.  Bar: identical status,
+identical pivot sequence, identical final basis, x and z BIT-IDENTICAL (fp64)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from gomilp_amd import lp, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = json.load(open(os.path.join(HERE, "golden", "reference_kats.json")))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = lp.Context()
+    yield c
+    c.close()
+
+
+def _same_trace(g, o):
+    return [(p[0], p[2], p[3], p[4], p[5]) for p in g] == [(p[0], p[2], p[3], p[4], p[5]) for p in o]
+
+
+def _check_against_oracle(ctx, c, A, b, tol=0.0, expect_bitwise=True):
+    o = O.simplex(c, A, b, tol, None, fast_initial_basis=True, trace=True)
+    rl = ctx.upload(c, A, b)
+    g = rl.solve(tol, trace=True)
+    rl.free()
+    assert g.status == o.status, (lp.STATUS_NAMES[g.status], O.STATUS_NAMES[o.status], g.stats)
+    if o.x is None:
+        assert g.x is None
+        assert (math.isnan(g.z) and math.isnan(o.z)) or g.z == o.z
+        return g, o
+    assert _same_trace(g.pivots, o.pivots), "pivot sequence differs"
+    assert g.stats["pivots_phase1"] == o.pivots_phase1 and g.stats["pivots_phase2"] == o.pivots_phase2
+    assert np.array_equal(g.basis, o.basis)
+    if expect_bitwise:
+        assert np.array_equal(g.x, o.x), float(np.max(np.abs(g.x - o.x)))
+        assert g.z == o.z
+    return g, o
+
+
+def test_loaded_native_library():
+    L = lp.lib()
+    assert L.gomilp_device_count() >= 1
+    assert L.gomilp_compiled_arch() == b"gfx950"
+
+
+def test_golden_k1_flat_call():
+    kat = [k for k in KATS["lp"] if k["id"] == "K1-lp"][0]
+    r = lp.simplex(kat["c"], kat["A"], kat["b"], 0.0, None)
+    assert r.status == lp.OK
+    assert np.array_equal(r.x, np.array(kat["want_x"], dtype=float)) and r.z == kat["want_z"]
+
+
+def test_golden_k9_singular():
+    kat = [k for k in KATS["lp"] if k["id"] == "K9"][0]
+    r = lp.simplex(kat["c"], kat["A"], kat["b"], 0.0, None)
+    assert r.status == lp.ERR_SINGULAR and r.x is None and math.isnan(r.z)
+
+
+@pytest.mark.parametrize("m,seed", [(3, 11), (8, 5), (16, 7), (33, 9), (64, 7), (128, 7), (256, 7)])
+def test_dense_lp_matches_oracle_bitwise(ctx, m, seed):
+    c, A, b = synth.dense_lp_standard_form(m, seed)
+    g, o = _check_against_oracle(ctx, c, A, b)
+    assert g.stats["pivots_phase2"] > 0
+
+
+def test_rectangular_more_columns(ctx):
+    c, A, b = synth.dense_lp_standard_form(40, 21, nv=90)
+    _check_against_oracle(ctx, c, A, b)
+
+
+def _child(m, seed, signs):
+    """root LP + bnb rows like subproblem.go:141-159: returns (c, A, b) of a child relaxation"""
+    c0, A0, b0 = synth.dense_lp_standard_form(m, seed)
+    root = O.simplex(c0, A0, b0, 0.0, None, fast_initial_basis=True)
+    frac = [j for j in range(m) if root.x[j] != math.floor(root.x[j])]
+    cons = []
+    for k, s in enumerate(signs):
+        j = frac[-1 - k]
+        fl = math.floor(root.x[j])
+        cons.append((j, 1, float(fl)) if s > 0 else (j, -1, float(-(fl + 1))))
+    return O.child_standard_form(c0, A0, b0, cons)
+
+
+@pytest.mark.parametrize("signs", [(-1,), (1,), (-1, -1), (1, -1, 1)])
+def test_bnb_children_phase1_and_bland(ctx, signs):
+    c, A, b = _child(24, 3, signs)
+    _check_against_oracle(ctx, c, A, b)
+
+
+def test_infeasible_child(ctx):
+    # x_0 >= 5 against rows that cap every x below ~2: Phase I ends with the artificial positive
+    c0, A0, b0 = synth.dense_lp_standard_form(12, 4)
+    c, A, b = O.child_standard_form(c0, A0, b0, [(0, -1, -50.0)])
+    g, o = _check_against_oracle(ctx, c, A, b)
+    assert g.status == lp.ERR_INFEASIBLE
+
+
+def test_unbounded(ctx):
+    # minimise -x0 with x0 - x1 + s = 1: ray along (1,1)
+    c = np.array([-1.0, 0.0, 0.0])
+    A = np.array([[1.0, -1.0, 1.0]])
+    b = np.array([1.0])
+    g, o = _check_against_oracle(ctx, c, A, b)
+    assert g.status == lp.ERR_UNBOUNDED and g.z == -math.inf
+
+
+def test_verify_inputs_errors(ctx):
+    c = np.array([-1.0, 0.0, 0.0, 0.0])
+    A = np.array([[1.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    b = np.array([1.0, 1.0])
+    g, o = _check_against_oracle(ctx, c, A, b)  # zero column with c >= 0 -> ErrZeroColumn
+    assert g.status == lp.ERR_ZERO_COLUMN
+    A2 = np.array([[1.0, 1.0, 1.0, 0.0], [0.0, 0.0, 0.0, 0.0]])
+    g, o = _check_against_oracle(ctx, c, A2, np.array([1.0, 1.0]))
+    assert g.status == lp.ERR_INFEASIBLE
+    g, o = _check_against_oracle(ctx, c, A2, np.array([1.0, 0.0]))
+    assert g.status == lp.ERR_ZERO_ROW
+
+
+def test_exactly_constrained_m_equals_n(ctx):
+    rng = np.random.default_rng(5)
+    A = rng.uniform(0.1, 1.0, size=(9, 9)) + 4 * np.eye(9)
+    x = rng.uniform(0.5, 1.5, size=9)
+    b = A @ x
+    c = rng.uniform(-1, 1, size=9)
+    _check_against_oracle(ctx, c, A, b)
+
+
+def test_full_size_properties_C2(ctx):
+    """1024x2048 (BASELINE config C2): size-independent checks — primal/dual feasibility, complementary
+    slackness through an independent LAPACK solve, objective against HiGHS."""
+    from scipy.optimize import linprog
+    m, seed = synth.CONFIGS["C2"]
+    cc, G, h = synth.dense_lp_inequality_form(m, seed)
+    c, A, b = synth.dense_lp_standard_form(m, seed)
+    rl = ctx.upload(c, A, b)
+    g = rl.solve(0.0)
+    rl.free()
+    assert g.status == lp.OK
+    x = g.x
+    assert np.all(x >= 0)
+    assert np.max(np.abs(A @ x - b)) <= 1e-9
+    B = A[:, g.basis]
+    y = np.linalg.solve(B.T, c[g.basis])
+    r = c - A.T @ y
+    assert r.min() >= -1e-9            # optimality of the final basis (simplex.go:248 with tol = 0, up to rounding)
+    assert abs(c @ x - g.z) <= 1e-12 * max(1, abs(g.z))
+    ref = linprog(cc, A_ub=G, b_ub=h, method="highs")
+    assert abs(ref.fun - g.z) <= 1e-9 * max(1.0, abs(g.z))
+    assert g.stats["drift_xb"] < 1e-8
