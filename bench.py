@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the LP-relaxation hot path (BASELINE.json `metric`).
+
+One "step" = one complete pass of the hot path over one synthetic input: a full dense-simplex solve of the
+metric workload (2048x4096 fp64 dense LP, SURVEY.md §8d generator, seed 2 + rank) from HBM-resident inputs
+(c, A, b uploaded before the timed region), through the C-ABI of include/gomilp_lp.h.
+value = simplex pivots per second, whole job (all ranks' pivots / max-over-ranks wall time).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload M|C2|C4|C3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_update: rank-1 update of B^-1) against
+the HBM roof with HIP-event timings sampled inside the timed region; `cpu_baseline` times the CPU oracle
+(the reference algorithm: 3 fresh LU per pivot) on a bounded sample of the same workload on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="M")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pivots", type=int, default=3, help="Phase-II pivots timed on the CPU oracle")
+    ap.add_argument("--sample-events", type=int, default=8, help="time the kernels of every k-th pivot with HIP events")
+    ap.add_argument("--chunk", type=int, default=64)
+    ap.add_argument("--refresh", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU: the product path has no CPU fallback", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    from gomilp_amd import lp, synth
+
+    m, seed = synth.CONFIGS[args.workload]
+    seed = seed + rank  # weak scaling: every rank owns an independent relaxation of the same shape
+    c, A, b = synth.dense_lp_standard_form(m, seed)
+    n = A.shape[1]
+    ctx = lp.Context(device=local_rank, chunk=args.chunk, refresh=args.refresh, sample_events=args.sample_events)
+    prob = ctx.upload(c, A, b)  # inputs resident in HBM before the timed region
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    incumbent = torch.full((1,), float("inf"), dtype=torch.float64, device="cuda")
+
+    def step():
+        r = prob.solve(0.0)
+        if r.status != lp.OK:
+            raise RuntimeError("solve failed: %s" % lp.STATUS_NAMES.get(r.status, r.status))
+        if dist is not None:
+            # the only exchange of the frontier-parallel path: incumbent bound, one all-reduce(min) over xGMI
+            incumbent[0] = min(float(incumbent[0]), r.z)
+            dist.all_reduce(incumbent, op=dist.ReduceOp.MIN)
+        return r
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    pivots = 0
+    ksec = [0.0, 0.0, 0.0, 0.0]
+    loop_s = final_s = 0.0
+    last = None
+    for _ in range(args.steps):
+        last = step()
+        pivots += last.stats["pivots_phase1"] + last.stats["pivots_phase2"]
+        for i in range(4):
+            ksec[i] += last.stats["pivot_kernel_seconds"][i]
+        loop_s += last.stats["seconds_pivot_loop"]
+        final_s += last.stats["seconds_final_solve"]
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt, float(pivots)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        dt_max, piv_all = float(tmax[0]), float(tt[1])
+    else:
+        dt_max, piv_all = dt, float(pivots)
+
+    if rank == 0:
+        value = piv_all / dt_max
+        nn = n - m
+        bytes_pivot = 8.0 * (m * nn + 3.0 * m * m)      # pricing m(n-m) + FTRAN m^2 + update 2 m^2
+        bytes_update = 16.0 * m * m                      # the dominant kernel's share: read + write B^-1
+        nsamp = max(ksec[3], 1.0)
+        t_upd = ksec[2] / nsamp
+        achieved = bytes_update / t_upd / 1e9 if t_upd > 0 else 0.0
+        out = {
+            "metric": "simplex pivots/sec on %dx%d fp64 dense LP" % (m, n),
+            "value": value,
+            "unit": "pivots/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt_max / max(args.steps, 1),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%s: %dx%d dense LP, splitmix64 seed %d (+rank), one full solve per step"
+                                   % (args.workload, m, n, synth.CONFIGS[args.workload][1]),
+                       "pivots_per_solve": int(last.stats["pivots_phase2"]), "parallelism": "1 relaxation per GPU",
+                       "chunk": args.chunk, "refresh": args.refresh},
+            "roofline": {"bound": "hbm", "kernel": "k_update", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": bytes_update, "avg_launch_us": 1e6 * t_upd,
+                         "avg_us": {"k_price": 1e6 * ksec[0] / nsamp, "k_ftran": 1e6 * ksec[1] / nsamp,
+                                    "k_update": 1e6 * ksec[2] / nsamp, "sampled_pivots": int(ksec[3])},
+                         "per_pivot": {"bytes": bytes_pivot, "achieved_GBs": value / world * bytes_pivot / 1e9,
+                                       "frac": value / world * bytes_pivot / 1e9 / HBM_PEAK_GBS}},
+            "breakdown": {"pivot_loop_s": loop_s, "final_solve_s": final_s, "wall_s": dt, "drift_xb": last.stats["drift_xb"],
+                          "z": last.z},
+        }
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O   # the checker, timed as the CPU baseline (never the product path)
+            cores = os.cpu_count() or 1
+            O.set_threads(cores)
+            tcb = time.perf_counter()
+            ro = O.simplex(c, A, b, 0.0, None, fast_initial_basis=True, stop_after_pivots=args.cpu_pivots)
+            tcb = time.perf_counter() - tcb
+            out["cpu_baseline"] = {
+                "value": ro.pivots_phase2 / ro.seconds_loop if ro.seconds_loop > 0 else 0.0,
+                "unit": "pivots/s", "cores": cores, "kind": "port",
+                "sample": "first %d Phase-II pivots of the same %dx%d LP from the slack basis (reference algorithm: "
+                          "3 fresh LU + cond estimate per pivot, gonum order); unit-column initial-basis fast path; "
+                          "%.1f s wall" % (ro.pivots_phase2, m, n, tcb)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    prob.free()
+    ctx.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
