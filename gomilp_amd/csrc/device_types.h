@@ -32,6 +32,12 @@ struct DevState {
     int64_t max_pivots;
     int32_t lu_singular;
     int32_t pad;
+    // fused two-kernel pipeline: pivot t is committed by the pricing kernel of pivot t+1
+    double theta;      // x_B[p] / d_p of the pivot being committed
+    int32_t ent_cur;   // variable entering in the pivot whose FTRAN ran last
+    int32_t ent_prev;  // variable entering in the pivot being committed
+    int32_t lea;       // variable leaving in the pivot being committed
+    int32_t pad2;
 };
 
 struct DevPivot {  // mirrors gomilp_pivot

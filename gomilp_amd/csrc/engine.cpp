@@ -63,7 +63,8 @@ hipError_t dmalloc(T **p, size_t count) {
 struct Engine::Work {
     int cap_m = 0, cap_ld = 0, cap_cols = 0;
     double *binv[2] = {nullptr, nullptr};
-    double *xb = nullptr, *y = nullptr, *dvec = nullptr, *move = nullptr, *rvec = nullptr, *yscratch = nullptr, *W = nullptr;
+    double *yb[2] = {nullptr, nullptr};
+    double *xb = nullptr, *dvec = nullptr, *move = nullptr, *rvec = nullptr, *yscratch = nullptr, *W = nullptr;
     int32_t *basic = nullptr, *nonbasic = nullptr, *lpos = nullptr, *rowstep = nullptr, *rho = nullptr;
     unsigned long long *pk_price = nullptr, *pk_ratio = nullptr, *lpk[2] = {nullptr, nullptr};
     unsigned int *pi_price = nullptr, *pi_ratio = nullptr, *lpl[2] = {nullptr, nullptr}, *lpr[2] = {nullptr, nullptr};
@@ -79,7 +80,7 @@ struct Engine::Work {
 
     void release() {
         for (auto &p : binv) { if (p) hipFree(p); p = nullptr; }
-        for (double **p : {&xb, &y, &dvec, &move, &rvec, &yscratch, &W}) { if (*p) hipFree(*p); *p = nullptr; }
+        for (double **p : {&xb, &yb[0], &yb[1], &dvec, &move, &rvec, &yscratch, &W}) { if (*p) hipFree(*p); *p = nullptr; }
         for (int32_t **p : {&basic, &nonbasic, &lpos, &rowstep, &rho}) { if (*p) hipFree(*p); *p = nullptr; }
         if (h_W) hipHostFree(h_W); h_W = nullptr;
         if (h_vec) hipHostFree(h_vec); h_vec = nullptr;
@@ -126,6 +127,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "trace") trace_on_ = v ? 1 : 0;
     else if (key == "max_pivots") max_pivots_ = v < 0 ? 0 : v;
     else if (key == "sample_events") sample_events_ = v < 0 ? 0 : v;
+    else if (key == "fused") fused_ = v ? 1 : 0;
     else return GOMILP_ERR_BAD_SHAPE;
     return GOMILP_OK;
 }
@@ -153,7 +155,8 @@ int Engine::ensure_work(int m, int ncols) {
     w.release();
     for (auto &p : w.binv) HIP_TRY(dmalloc(&p, (size_t)nm * nld));
     HIP_TRY(dmalloc(&w.W, (size_t)nm * nld));
-    HIP_TRY(dmalloc(&w.xb, (size_t)nld)); HIP_TRY(dmalloc(&w.y, (size_t)nld)); HIP_TRY(dmalloc(&w.dvec, (size_t)nld));
+    HIP_TRY(dmalloc(&w.xb, (size_t)nld)); HIP_TRY(dmalloc(&w.yb[0], (size_t)nld)); HIP_TRY(dmalloc(&w.yb[1], (size_t)nld));
+    HIP_TRY(dmalloc(&w.dvec, (size_t)nld));
     HIP_TRY(dmalloc(&w.move, (size_t)nld)); HIP_TRY(dmalloc(&w.rvec, (size_t)nc));
     HIP_TRY(dmalloc(&w.yscratch, (size_t)64 * nld));
     HIP_TRY(dmalloc(&w.basic, (size_t)nm)); HIP_TRY(dmalloc(&w.nonbasic, (size_t)nc));
@@ -253,7 +256,7 @@ LPArgs Engine::make_args(const Problem &P, int phase, double tol, int nn, const 
     a.m = P.m; a.ld = P.ld; a.nn = nn; a.phase = phase; a.tol = tol;
     a.At = P.dAt; a.cost = cost; a.b = P.db;
     a.binv_cur = w.binv[cur_]; a.binv_next = w.binv[cur_ ^ 1];
-    a.xb = w.xb; a.y = w.y; a.dvec = w.dvec; a.move = w.move; a.rvec = w.rvec;
+    a.xb = w.xb; a.y = w.yb[ycur_]; a.dvec = w.dvec; a.move = w.move; a.rvec = w.rvec;
     a.basic = w.basic; a.nonbasic = w.nonbasic;
     a.pk_price = w.pk_price; a.pi_price = w.pi_price; a.pk_ratio = w.pk_ratio; a.pi_ratio = w.pi_ratio;
     a.st = w.st;
@@ -269,7 +272,7 @@ void Engine::sync_state_to_device() {
 int Engine::refresh_xb_y(const Problem &P, const double *cost) {
     Work &w = *w_;
     launch_matvec_rows(w.binv[cur_], P.ld, P.m, P.db, w.xb, stream_);
-    launch_y_from_binv(w.binv[cur_], P.ld, P.m, cost, w.basic, w.yscratch, w.y, stream_);
+    launch_y_from_binv(w.binv[cur_], P.ld, P.m, cost, w.basic, w.yscratch, w.yb[ycur_], stream_);
     launches_ += 3;
     return GOMILP_OK;
 }
@@ -322,18 +325,39 @@ int Engine::host_bland(const Problem &P, LPArgs &a, gomilp_lp_stats *st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pivot loop (simplex.go:233-293): chunks of (price, ftran, update) launches; the kernels stop
-// themselves through DevState::done, the host looks at the state after each chunk.
+// Pivot loop (simplex.go:233-293): chunks of kernel launches; the kernels stop themselves through
+// DevState::done, the host looks at the state after each chunk.
 // returns GOMILP_OK when the loop ended at an optimum, else the reference's error class.
 // ------------------------------------------------------------------------------------------------
+void Engine::account_samples(gomilp_lp_stats *st, const std::vector<int64_t> &sample_t, int64_t executed, int nk) {
+    // nk kernels per pivot, each bracketed by its own (start, stop) event pair attached to the dispatch
+    if (!st) return;
+    Work &w = *w_;
+    for (size_t s = 0; s < sample_t.size(); s++) {
+        if (sample_t[s] >= executed) break;  // kernels already stopped by DevState::done are not samples
+        float ms[3] = {0, 0, 0};
+        bool ok = true;
+        for (int k = 0; k < nk; k++)
+            ok = ok && hipEventElapsedTime(&ms[k], w.sample_ev[(s * 3 + k) * 2], w.sample_ev[(s * 3 + k) * 2 + 1]) == hipSuccess;
+        if (!ok) continue;
+        if (nk == 3) {
+            st->pivot_kernel_seconds[0] += ms[0] * 1e-3; st->pivot_kernel_seconds[1] += ms[1] * 1e-3;
+            st->pivot_kernel_seconds[2] += ms[2] * 1e-3;
+        } else {
+            st->pivot_kernel_seconds[0] += ms[0] * 1e-3; st->pivot_kernel_seconds[2] += ms[1] * 1e-3;
+        }
+        st->pivot_kernel_seconds[3] += 1.0;  // number of sampled pivots
+    }
+}
+
 int Engine::run_loop(const Problem &P, int phase, double tol, int nn, const double *cost, gomilp_lp_stats *st) {
+    if (fused_ && fused_supported(P.ld)) return run_loop_fused(P, phase, tol, nn, cost, st);
     Work &w = *w_;
     DevState &hs = *w.st_host;
     hs.done = 0; hs.status = ST_RUNNING; hs.pivots = 0; hs.q = hs.p = -1; hs.rq = hs.dp = hs.mv = 0;
     hs.max_pivots = max_pivots_;
     hs.lu_singular = 0;
-    // trace_len is cumulative over the solve
-    sync_state_to_device();
+    sync_state_to_device();  // trace_len is cumulative over the solve
     int64_t since_refresh = 0;
     HIP_TRY(hipEventRecord(w.ev[0], stream_));
     int ret = GOMILP_OK;
@@ -346,17 +370,16 @@ int Engine::run_loop(const Problem &P, int phase, double tol, int nn, const doub
             a.binv_cur = w.binv[(cur_ + t) & 1];
             a.binv_next = w.binv[(cur_ + t + 1) & 1];
             const bool sample = sampling && ((before + t) % sample_events_ == 0);
-            const size_t e0 = sample_t.size() * 4;
+            hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             if (sample) {
-                while (w.sample_ev.size() < e0 + 4) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); w.sample_ev.push_back(e); }
-                HIP_TRY(hipEventRecord(w.sample_ev[e0 + 0], stream_));
+                const size_t e0 = sample_t.size() * 6;
+                while (w.sample_ev.size() < e0 + 6) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); w.sample_ev.push_back(ev); }
+                for (int k = 0; k < 6; k++) e[k] = w.sample_ev[e0 + k];
+                sample_t.push_back(t);
             }
-            const int gp = launch_price(a, stream_);
-            if (sample) HIP_TRY(hipEventRecord(w.sample_ev[e0 + 1], stream_));
-            const int gr = launch_ftran(a, gp, -1, -1, stream_);
-            if (sample) HIP_TRY(hipEventRecord(w.sample_ev[e0 + 2], stream_));
-            launch_update(a, gr, -1, 0, 0, stream_);
-            if (sample) { HIP_TRY(hipEventRecord(w.sample_ev[e0 + 3], stream_)); sample_t.push_back(t); }
+            const int gp = launch_price(a, stream_, e[0], e[1]);
+            const int gr = launch_ftran(a, gp, -1, -1, stream_, e[2], e[3]);
+            launch_update(a, gr, -1, 0, 0, stream_, e[4], e[5]);
             launches_ += 3;
         }
         HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
@@ -365,21 +388,7 @@ int Engine::run_loop(const Problem &P, int phase, double tol, int nn, const doub
         const int64_t executed = hs.pivots - before;
         cur_ = (int)((cur_ + executed) & 1);
         since_refresh += executed;
-        if (st) {
-            // only pivots that really executed (kernels not yet stopped by DevState::done) are meaningful samples
-            for (size_t s = 0; s < sample_t.size(); s++) {
-                if (sample_t[s] >= executed) break;
-                float ms[3];
-                bool ok = true;
-                for (int k = 0; k < 3; k++)
-                    ok = ok && hipEventElapsedTime(&ms[k], w.sample_ev[s * 4 + k], w.sample_ev[s * 4 + k + 1]) == hipSuccess;
-                if (!ok) continue;
-                st->pivot_kernel_seconds[0] += ms[0] * 1e-3;
-                st->pivot_kernel_seconds[1] += ms[1] * 1e-3;
-                st->pivot_kernel_seconds[2] += ms[2] * 1e-3;
-                st->pivot_kernel_seconds[3] += 1.0;  // number of sampled pivots
-            }
-        }
+        account_samples(st, sample_t, executed, 3);
         if (!hs.done) {
             if (refresh_ > 0 && since_refresh >= refresh_) {
                 refresh_xb_y(P, cost);
@@ -400,6 +409,99 @@ int Engine::run_loop(const Problem &P, int phase, double tol, int nn, const doub
             HIP_TRY(hipStreamSynchronize(stream_));
             hs.done = 0; hs.status = ST_RUNNING;
             sync_state_to_device();
+            continue;
+        }
+        ret = GOMILP_ERR_DEVICE;
+        break;
+    }
+    HIP_TRY(hipEventRecord(w.ev[1], stream_));
+    HIP_TRY(hipEventSynchronize(w.ev[1]));
+    float ms = 0;
+    hipEventElapsedTime(&ms, w.ev[0], w.ev[1]);
+    if (st) {
+        st->seconds_pivot_loop += ms * 1e-3;
+        if (phase == 1) st->pivots_phase1 += hs.pivots; else st->pivots_phase2 += hs.pivots;
+    }
+    return ret;
+}
+
+// Fused two-kernel pipeline (fused_kernels.hip).  Within a segment (since the last restart) launch index t:
+//   K_A(t) reads  y = Y[(y0+t-1)&1], row p from B[(c0+t-1)&1]; writes Y[(y0+t)&1]      (t >= 1; t = 0: reads Y[y0])
+//   K_B(t) reads  B[(c0+t-1)&1], writes B[(c0+t)&1]                                     (t >= 1; t = 0: reads B[c0])
+// After T committed pivots the current buffers are B[(c0+T)&1], Y[(y0+T)&1] whatever stopped the loop.
+int Engine::run_loop_fused(const Problem &P, int phase, double tol, int nn, const double *cost, gomilp_lp_stats *st) {
+    Work &w = *w_;
+    DevState &hs = *w.st_host;
+    hs.done = 0; hs.status = ST_RUNNING; hs.pivots = 0; hs.q = hs.p = -1; hs.rq = hs.dp = hs.mv = 0;
+    hs.max_pivots = 0;
+    hs.lu_singular = 0;
+    hs.theta = 0; hs.ent_cur = hs.ent_prev = hs.lea = -1;
+    sync_state_to_device();
+    int64_t since_refresh = 0;
+    HIP_TRY(hipEventRecord(w.ev[0], stream_));
+    int ret = GOMILP_OK;
+    const bool sampling = sample_events_ > 0;
+    int c0 = cur_, y0 = ycur_;
+    int64_t seg_start = 0, tseg = 0;  // pivots committed at segment start, launch index inside the segment
+    for (;;) {
+        const int64_t before = hs.pivots;
+        std::vector<int64_t> sample_t;
+        int64_t nlaunch = chunk_;
+        if (max_pivots_ > 0) nlaunch = std::min<int64_t>(nlaunch, std::max<int64_t>(1, max_pivots_ - hs.pivots + 1));
+        for (int64_t t = 0; t < nlaunch; t++, tseg++) {
+            const int pending = tseg > 0;
+            LPArgs a = make_args(P, phase, tol, nn, cost);
+            const int prev = (int)((tseg + 1) & 1);  // (x + tseg - 1) & 1 == (x + tseg + 1) & 1
+            a.binv_cur = w.binv[pending ? ((c0 + prev) & 1) : c0];
+            a.binv_next = w.binv[(c0 + tseg) & 1];
+            const double *y_in = w.yb[pending ? ((y0 + prev) & 1) : y0];
+            double *y_out = w.yb[(y0 + tseg) & 1];
+            const bool sample = sampling && ((before + t) % sample_events_ == 0) && pending;
+            hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+            if (sample) {
+                const size_t e0 = sample_t.size() * 6;
+                while (w.sample_ev.size() < e0 + 6) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); w.sample_ev.push_back(ev); }
+                for (int k = 0; k < 4; k++) e[k] = w.sample_ev[e0 + k];
+                sample_t.push_back(t);
+            }
+            const int gr = grid_ratio_;
+            const int gp = launch_price_fused(a, y_in, y_out, pending, gr, stream_, e[0], e[1]);
+            grid_ratio_ = launch_update_ftran_fused(a, pending, gp, stream_, e[2], e[3]);
+            launches_ += 2;
+        }
+        HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(hipGetLastError());
+        const int64_t executed = hs.pivots - before;
+        since_refresh += executed;
+        // a sampled launch index t measured K_A(t) (which commits pivot t-1) and K_B(t): valid while t <= executed
+        account_samples(st, sample_t, executed + 1, 2);
+        const int64_t T = hs.pivots - seg_start;
+        if (!hs.done) {
+            if (max_pivots_ > 0 && hs.pivots >= max_pivots_) { cur_ = (c0 + T) & 1; ycur_ = (y0 + T) & 1; ret = GOMILP_ERR_UNSUPPORTED; break; }
+            if (refresh_ > 0 && since_refresh >= refresh_) {
+                cur_ = (int)((c0 + T) & 1); ycur_ = (int)((y0 + T) & 1);
+                refresh_xb_y(P, cost);
+                since_refresh = 0;
+                if (st) st->refreshes++;
+            }
+            continue;
+        }
+        cur_ = (int)((c0 + T) & 1);
+        ycur_ = (int)((y0 + T) & 1);
+        if (hs.status == ST_OPTIMAL) break;
+        if (hs.status == ST_UNBOUNDED) { ret = GOMILP_ERR_UNBOUNDED; break; }
+        if (hs.status == ST_NEED_BLAND) {
+            // the degenerate pivot has not been committed: B^-1, x_B, y and the index lists are those of the
+            // current basis; the Bland step runs on the unfused kernels, then a new fused segment starts
+            LPArgs a = make_args(P, phase, tol, nn, cost);
+            int rc = host_bland(P, a, st);
+            if (rc != GOMILP_OK) { ret = rc; break; }
+            HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipStreamSynchronize(stream_));
+            hs.done = 0; hs.status = ST_RUNNING;
+            sync_state_to_device();
+            c0 = cur_; y0 = ycur_; seg_start = hs.pivots; tseg = 0;
             continue;
         }
         ret = GOMILP_ERR_DEVICE;
@@ -544,7 +646,9 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     HIP_TRY(hipMemcpyAsync(w.rho, rho.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
     launch_set_binv_perm(w.binv[0], P.ld, m, w.rho, stream_);
     HIP_TRY(hipMemsetAsync(w.xb, 0, (size_t)P.ld * sizeof(double), stream_));
-    HIP_TRY(hipMemsetAsync(w.y, 0, (size_t)P.ld * sizeof(double), stream_));
+    ycur_ = 0;
+    HIP_TRY(hipMemsetAsync(w.yb[0], 0, (size_t)P.ld * sizeof(double), stream_));
+    HIP_TRY(hipMemsetAsync(w.yb[1], 0, (size_t)P.ld * sizeof(double), stream_));
     HIP_TRY(hipMemcpyAsync(w.xb, xb.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
 
@@ -643,7 +747,7 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     if (st->phase1_used) {
         refresh_xb_y(P, P.dc);
     } else {
-        launch_y_from_binv(w.binv[cur_], P.ld, m, P.dc, w.basic, w.yscratch, w.y, stream_);
+        launch_y_from_binv(w.binv[cur_], P.ld, m, P.dc, w.basic, w.yscratch, w.yb[ycur_], stream_);
         launches_ += 2;
     }
     int loop_rc = run_loop(P, 2, tol, (int)nonbasic.size(), P.dc, st);

@@ -46,6 +46,8 @@ class Engine {
     int ensure_work(int m, int ncols);
     LPArgs make_args(const Problem &P, int phase, double tol, int nn, const double *cost);
     int run_loop(const Problem &P, int phase, double tol, int nn, const double *cost, gomilp_lp_stats *st);
+    int run_loop_fused(const Problem &P, int phase, double tol, int nn, const double *cost, gomilp_lp_stats *st);
+    void account_samples(gomilp_lp_stats *st, const std::vector<int64_t> &sample_t, int64_t executed, int nk);
     int host_bland(const Problem &P, LPArgs &a, gomilp_lp_stats *st);
     int refresh_xb_y(const Problem &P, const double *cost);
     int final_solve(const Problem &P, int ncols_rows, std::vector<double> &xb_exact, bool *singular);
@@ -58,9 +60,11 @@ class Engine {
     std::vector<std::unique_ptr<Problem>> problems_;
     std::unique_ptr<Work> w_;
     // knobs
-    int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0;
+    int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1;
     // per-solve state
-    int cur_ = 0;  // which Binv buffer is current
+    int cur_ = 0;   // which Binv buffer is current
+    int ycur_ = 0;  // which y buffer is current
+    int grid_ratio_ = 1;  // workgroups of the last ratio-test kernel (partials to reduce)
     int64_t launches_ = 0;
     std::vector<gomilp_pivot> last_trace_;
     int64_t last_trace_total_ = 0;
@@ -70,9 +74,16 @@ int device_count();
 const char *compiled_arch();
 
 // launch wrappers implemented in simplex_kernels.hip
-int launch_price(const LPArgs &a, hipStream_t s);
-int launch_ftran(const LPArgs &a, int nparts_price, int forced_pos, int forced_var, hipStream_t s);
-void launch_update(const LPArgs &a, int nparts_ratio, int forced_p, int no_swap, int bland, hipStream_t s);
+int launch_price(const LPArgs &a, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+int launch_ftran(const LPArgs &a, int nparts_price, int forced_pos, int forced_var, hipStream_t s, hipEvent_t e0 = nullptr,
+                 hipEvent_t e1 = nullptr);
+void launch_update(const LPArgs &a, int nparts_ratio, int forced_p, int no_swap, int bland, hipStream_t s,
+                   hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// fused_kernels.hip
+bool fused_supported(int ld);
+int launch_price_fused(const LPArgs &a, const double *y_in, double *y_out, int pending, int nparts_ratio, hipStream_t s,
+                       hipEvent_t e0, hipEvent_t e1);
+int launch_update_ftran_fused(const LPArgs &a, int pending, int nparts_price, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 void launch_transpose_in(const double *A, int64_t lda, int m, int n, double *At, int ld, hipStream_t s);
 void launch_col_stats(const double *At, int ld, int m, int n, int32_t *nnz, int32_t *lastrow, int32_t *allone,
                       int32_t *rowflag, hipStream_t s);

@@ -1,0 +1,260 @@
+// Fused two-kernel pivot pipeline for gfx950 (the fast path when the padded row length is 64*NV double2).
+//
+// Per pivot the reference does pricing + 3 LU solves (simplex.go:233-293).  The explicit-inverse form needs
+// pricing (read A_N), FTRAN (read B^-1) and the rank-1 update (read+write B^-1).  Here the update of pivot
+// t-1 and the FTRAN of pivot t share ONE pass over B^-1:
+//
+//   K_A(t)  k_price_fused : reduce the ratio-test partials of pivot t-1 -> leaving row p; commit pivot t-1
+//                           (index swap, trace, counters); y_t = y_{t-1} + (r_q/d_p) * row_p(B^-1_{t-1}) built
+//                           directly in LDS; price all nonbasic columns with y_t; partial argmin.
+//   K_B(t)  k_update_ftran_fused : reduce the pricing partials -> entering q (or OPTIMAL); one streaming pass
+//                           over B^-1: row_i <- row_i - (d_i/d_p) row_p (update t-1, written to the other
+//                           buffer), d'_i = row_i_new . a_q (FTRAN t), x_B update, ratio test, partial argmin.
+//
+// HBM traffic per pivot: 8*[m(n-m) + 2 m^2] bytes instead of 8*[m(n-m) + 3 m^2].
+// Every wave owns whole rows; all NV 16-byte loads of a row are issued before the first use (NV KiB in flight
+// per wave).  Cross-workgroup data only crosses kernel boundaries; buffers that one kernel both reads globally
+// and rewrites (B^-1, y) are ping-ponged by the host.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+
+#include "device_types.h"
+#include "kernels_common.h"
+
+namespace gomilp {
+
+template <int NV>
+__global__ __launch_bounds__(kBlock) void k_price_fused(LPArgs a, const double *__restrict__ y_in,
+                                                        double *__restrict__ y_out, int pending, int nparts_ratio) {
+    extern __shared__ __attribute__((aligned(16))) double2 svec[];
+    __shared__ unsigned long long sk[kWavesPerBlock];
+    __shared__ unsigned int si[kWavesPerBlock];
+    DevState *st = a.st;
+    if (st->done) return;
+    constexpr int ld2 = NV * 64;
+    int q_prev = -1, lea = -1;
+    if (pending) {
+        const int p = (int)reduce_partials(a.pk_ratio, a.pi_ratio, nparts_ratio, sk, si, nullptr);
+        const double mv = a.move[p];
+        if (mv == __builtin_inf()) {  // simplex.go:328-330
+            if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->status = ST_UNBOUNDED; st->p = p; st->mv = mv; }
+            return;
+        }
+        if (mv <= 0) {  // simplex.go:269 -> Bland
+            if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->status = ST_NEED_BLAND; st->p = p; st->mv = mv; }
+            return;
+        }
+        const double dpv = a.dvec[p];
+        const double alpha = st->rq / dpv;
+        q_prev = st->q;
+        lea = a.basic[p];
+        const double2 *rp = reinterpret_cast<const double2 *>(a.binv_cur + (size_t)p * a.ld);
+        const double2 *yi = reinterpret_cast<const double2 *>(y_in);
+        double2 *yo = reinterpret_cast<double2 *>(y_out);
+        for (int c = threadIdx.x; c < ld2; c += kBlock) {
+            double2 v = yi[c];
+            const double2 r = rp[c];
+            v.x = v.x + alpha * r.x;
+            v.y = v.y + alpha * r.y;
+            svec[c] = v;
+            if (blockIdx.x == 0) yo[c] = v;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            // commit pivot t-1 (simplex.go:280); basic[p] itself is rewritten by K_B(t) because this kernel's
+            // other workgroups still read it as the leaving variable
+            const int ent = st->ent_cur;
+            st->p = p; st->dp = dpv; st->mv = mv; st->theta = a.xb[p] / dpv;
+            st->ent_prev = ent; st->lea = lea;
+            a.nonbasic[q_prev] = lea;
+            if (a.trace && st->trace_len < a.trace_cap) {
+                DevPivot &t = a.trace[st->trace_len];
+                t.phase = a.phase; t.bland = 0; t.min_idx = q_prev; t.replace = p; t.entering = ent; t.leaving = lea;
+            }
+            st->trace_len += 1;
+            st->pivots += 1;
+        }
+        __syncthreads();
+    } else {
+        stage_vec(svec, y_in, ld2);
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    unsigned long long bk = ~0ull;
+    unsigned int bi = 0xFFFFFFFFu;
+    for (int pos = wave; pos < a.nn; pos += nwaves) {
+        const int j = (pos == q_prev) ? lea : a.nonbasic[pos];
+        const double2 *r2 = reinterpret_cast<const double2 *>(a.At + (size_t)j * a.ld);
+        double2 v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = r2[lane + 64 * k];
+        double acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const double2 s0 = svec[lane + 64 * k];
+            acc[k & 3] += v[k].x * s0.x + v[k].y * s0.y;
+        }
+        const double dot = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+        const double r = a.cost[j] - dot;
+        if (lane == 0) a.rvec[pos] = r;
+        amin_take(bk, bi, ordkey(r), (unsigned int)pos);
+    }
+    block_argmin(bk, bi, sk, si);
+    if (threadIdx.x == 0) { a.pk_price[blockIdx.x] = bk; a.pi_price[blockIdx.x] = bi; }
+}
+
+template <int NV>
+__global__ __launch_bounds__(kBlock) void k_update_ftran_fused(LPArgs a, int pending, int nparts_price) {
+    extern __shared__ __attribute__((aligned(16))) double2 svec[];
+    __shared__ unsigned long long sk[kWavesPerBlock];
+    __shared__ unsigned int si[kWavesPerBlock];
+    DevState *st = a.st;
+    if (st->done) return;
+    constexpr int ld2 = NV * 64;
+    double2 *svecA = svec;        // entering column a_q
+    double2 *svecP = svec + ld2;  // old row p of B^-1
+    const int q = (int)reduce_partials(a.pk_price, a.pi_price, nparts_price, sk, si, nullptr);
+    const double rq = a.rvec[q];
+    const bool optimal = (rq >= -a.tol);  // simplex.go:248
+    int p = -1, var = -1;
+    double dpv = 1, theta = 0;
+    if (pending) {
+        p = st->p; dpv = st->dp; theta = st->theta;
+        const double2 *rp = reinterpret_cast<const double2 *>(a.binv_cur + (size_t)p * a.ld);
+        for (int c = threadIdx.x; c < ld2; c += kBlock) svecP[c] = rp[c];
+    }
+    if (!optimal) {
+        var = a.nonbasic[q];
+        const double2 *aq = reinterpret_cast<const double2 *>(a.At + (size_t)var * a.ld);
+        for (int c = threadIdx.x; c < ld2; c += kBlock) svecA[c] = aq[c];
+    }
+    __syncthreads();
+    if (!pending && optimal) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->status = ST_OPTIMAL; st->q = q; st->rq = rq; }
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    unsigned long long bk = ~0ull;
+    unsigned int bi = 0xFFFFFFFFu;
+    for (int i = wave; i < a.m; i += nwaves) {
+        const double2 *src = reinterpret_cast<const double2 *>(a.binv_cur + (size_t)i * a.ld);
+        double2 v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = src[lane + 64 * k];
+        const double di_old = pending ? a.dvec[i] : 0.0;
+        double xbi = a.xb[i];
+        if (pending) {
+            double2 *dst = reinterpret_cast<double2 *>(a.binv_next + (size_t)i * a.ld);
+            if (i == p) {
+#pragma unroll
+                for (int k = 0; k < NV; k++) { v[k].x = v[k].x / dpv; v[k].y = v[k].y / dpv; dst[lane + 64 * k] = v[k]; }
+                xbi = theta;
+            } else {
+                const double f = di_old / dpv;
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    const double2 rp = svecP[lane + 64 * k];
+                    v[k].x = v[k].x - f * rp.x;
+                    v[k].y = v[k].y - f * rp.y;
+                    dst[lane + 64 * k] = v[k];
+                }
+                xbi = xbi - theta * di_old;
+            }
+            if (lane == 0) a.xb[i] = xbi;
+        }
+        if (!optimal) {
+            double acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                const double2 s0 = svecA[lane + 64 * k];
+                acc[k & 3] += v[k].x * s0.x + v[k].y * s0.y;
+            }
+            const double dnew = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+            double d = -dnew;                  // simplex.go:319
+            if (fabs(d) < 1e-13) d = 0;        // :321-325
+            const double mv = (d >= 0) ? __builtin_inf() : xbi / fabs(d);  // :334-340
+            if (lane == 0) { a.dvec[i] = dnew; a.move[i] = mv; }
+            amin_take(bk, bi, ordkey(mv), (unsigned int)i);
+        }
+    }
+    if (!optimal) {
+        block_argmin(bk, bi, sk, si);
+        if (threadIdx.x == 0) { a.pk_ratio[blockIdx.x] = bk; a.pi_ratio[blockIdx.x] = bi; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (pending) a.basic[p] = st->ent_prev;
+        st->q = q; st->rq = rq;
+        if (optimal) { st->done = 1; st->status = ST_OPTIMAL; }
+        else st->ent_cur = var;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers.  ev_start/ev_stop (nullable) are attached to the dispatch itself
+// (hipExtLaunchKernelGGL), so their elapsed time is the kernel's own duration, not launch gaps.
+// ------------------------------------------------------------------------------------------------
+
+bool fused_supported(int ld) {
+    if (ld % 128 != 0) return false;
+    const int nv = ld / 128;
+    return nv == 1 || nv == 2 || nv == 4 || nv == 8 || nv == 16 || nv == 32;
+}
+
+static inline int grid_rows(int rows) {
+    int g = (rows + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (g > kMaxPartials) g = kMaxPartials;
+    return g < 1 ? 1 : g;
+}
+
+template <int NV>
+static int launch_price_fused_t(const LPArgs &a, const double *y_in, double *y_out, int pending, int nparts_ratio,
+                                hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const int g = grid_rows(a.nn);
+    hipExtLaunchKernelGGL((k_price_fused<NV>), dim3(g), dim3(kBlock), (size_t)a.ld * sizeof(double), s, e0, e1, 0, a, y_in,
+                          y_out, pending, nparts_ratio);
+    return g;
+}
+template <int NV>
+static int launch_uf_fused_t(const LPArgs &a, int pending, int nparts_price, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const int g = grid_rows(a.m);
+    if (NV == 32) {  // 2 x 32 KiB of staged vectors + the reduction scratch exceed the default 64 KiB dynamic-LDS cap
+        static bool once = false;
+        if (!once) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_update_ftran_fused<NV>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4096 * (int)sizeof(double));
+            once = true;
+        }
+    }
+    hipExtLaunchKernelGGL((k_update_ftran_fused<NV>), dim3(g), dim3(kBlock), (size_t)a.ld * 2 * sizeof(double), s, e0, e1, 0,
+                          a, pending, nparts_price);
+    return g;
+}
+
+int launch_price_fused(const LPArgs &a, const double *y_in, double *y_out, int pending, int nparts_ratio, hipStream_t s,
+                       hipEvent_t e0, hipEvent_t e1) {
+    switch (a.ld / 128) {
+        case 1: return launch_price_fused_t<1>(a, y_in, y_out, pending, nparts_ratio, s, e0, e1);
+        case 2: return launch_price_fused_t<2>(a, y_in, y_out, pending, nparts_ratio, s, e0, e1);
+        case 4: return launch_price_fused_t<4>(a, y_in, y_out, pending, nparts_ratio, s, e0, e1);
+        case 8: return launch_price_fused_t<8>(a, y_in, y_out, pending, nparts_ratio, s, e0, e1);
+        case 16: return launch_price_fused_t<16>(a, y_in, y_out, pending, nparts_ratio, s, e0, e1);
+        case 32: return launch_price_fused_t<32>(a, y_in, y_out, pending, nparts_ratio, s, e0, e1);
+    }
+    return -1;
+}
+int launch_update_ftran_fused(const LPArgs &a, int pending, int nparts_price, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    switch (a.ld / 128) {
+        case 1: return launch_uf_fused_t<1>(a, pending, nparts_price, s, e0, e1);
+        case 2: return launch_uf_fused_t<2>(a, pending, nparts_price, s, e0, e1);
+        case 4: return launch_uf_fused_t<4>(a, pending, nparts_price, s, e0, e1);
+        case 8: return launch_uf_fused_t<8>(a, pending, nparts_price, s, e0, e1);
+        case 16: return launch_uf_fused_t<16>(a, pending, nparts_price, s, e0, e1);
+        case 32: return launch_uf_fused_t<32>(a, pending, nparts_price, s, e0, e1);
+    }
+    return -1;
+}
+
+}  // namespace gomilp

@@ -9,98 +9,13 @@
 // arg-reductions (entering column, leaving row) fused into the epilogue as first-index argmins.
 // Kernels communicate only across kernel boundaries; nothing depends on dispatch order.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "device_types.h"
+#include "kernels_common.h"
 
 namespace gomilp {
-
-// ------------------------------------------------------------------------------------------------
-// helpers
-// ------------------------------------------------------------------------------------------------
-
-// Order-preserving map double -> u64 for floats.MinIdx semantics (floats/floats.go:458-474):
-// NaN never wins (largest key), -0 == +0, ties resolved by the smaller index.
-__device__ __forceinline__ unsigned long long ordkey(double v) {
-    if (v != v) return ~0ull;
-    v = v + 0.0;  // -0 -> +0
-    unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-
-__device__ __forceinline__ void amin_take(unsigned long long &k, unsigned int &i, unsigned long long k2,
-                                          unsigned int i2) {
-    if (k2 < k || (k2 == k && i2 < i)) { k = k2; i = i2; }
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-__device__ __forceinline__ void wave_argmin(unsigned long long &k, unsigned int &i) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned long long k2 = __shfl_xor(k, o, 64);
-        unsigned int i2 = __shfl_xor(i, o, 64);
-        amin_take(k, i, k2, i2);
-    }
-}
-
-// argmin over the 4 waves of a 256-thread workgroup; result valid in every thread
-__device__ __forceinline__ void block_argmin(unsigned long long &k, unsigned int &i, unsigned long long *sk,
-                                             unsigned int *si) {
-    wave_argmin(k, i);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { sk[w] = k; si[w] = i; }
-    __syncthreads();
-    k = sk[0]; i = si[0];
-#pragma unroll
-    for (int t = 1; t < kWavesPerBlock; t++) amin_take(k, i, sk[t], si[t]);
-    __syncthreads();
-}
-
-// reduce the per-workgroup partials of the previous kernel (every workgroup does it redundantly:
-// <= 1024 entries out of L2, cheaper than another kernel boundary)
-__device__ __forceinline__ unsigned int reduce_partials(const unsigned long long *pk, const unsigned int *pi,
-                                                        int nparts, unsigned long long *sk, unsigned int *si,
-                                                        unsigned long long *key_out) {
-    unsigned long long k = ~0ull;
-    unsigned int i = 0xFFFFFFFFu;
-    for (int t = threadIdx.x; t < nparts; t += kBlock) amin_take(k, i, pk[t], pi[t]);
-    block_argmin(k, i, sk, si);
-    if (key_out) *key_out = k;
-    return i;
-}
-
-// dot of one padded row (ld doubles, 16-byte aligned) with the LDS-staged vector; result in all lanes
-__device__ __forceinline__ double wave_dot_row(const double *__restrict__ row, const double2 *__restrict__ svec,
-                                               int ld2, int lane) {
-    const double2 *r2 = reinterpret_cast<const double2 *>(row);
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    int c = lane;
-    for (; c + 192 < ld2; c += 256) {
-        double2 v0 = r2[c], v1 = r2[c + 64], v2 = r2[c + 128], v3 = r2[c + 192];
-        double2 s0 = svec[c], s1 = svec[c + 64], s2 = svec[c + 128], s3 = svec[c + 192];
-        a0 += v0.x * s0.x + v0.y * s0.y;
-        a1 += v1.x * s1.x + v1.y * s1.y;
-        a2 += v2.x * s2.x + v2.y * s2.y;
-        a3 += v3.x * s3.x + v3.y * s3.y;
-    }
-    for (; c < ld2; c += 64) {
-        double2 v0 = r2[c];
-        double2 s0 = svec[c];
-        a0 += v0.x * s0.x + v0.y * s0.y;
-    }
-    return wave_sum((a0 + a1) + (a2 + a3));
-}
-
-__device__ __forceinline__ void stage_vec(double2 *__restrict__ svec, const double *__restrict__ src, int ld2) {
-    const double2 *s2 = reinterpret_cast<const double2 *>(src);
-    for (int c = threadIdx.x; c < ld2; c += kBlock) svec[c] = s2[c];
-    __syncthreads();
-}
 
 // ------------------------------------------------------------------------------------------------
 // K1  pricing:  r[pos] = cost[j] - At[j,:].y   (simplex.go:242-243), fused first-index argmin (:247)
@@ -466,21 +381,23 @@ static inline int grid_for_rows(int rows) {
     return g;
 }
 
-int launch_price(const LPArgs &a, hipStream_t s) {
+int launch_price(const LPArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const int g = grid_for_rows(a.nn);
-    hipLaunchKernelGGL(k_price, dim3(g), dim3(kBlock), (size_t)a.ld * sizeof(double), s, a);
+    hipExtLaunchKernelGGL(k_price, dim3(g), dim3(kBlock), (size_t)a.ld * sizeof(double), s, e0, e1, 0, a);
     return g;
 }
-int launch_ftran(const LPArgs &a, int nparts_price, int forced_pos, int forced_var, hipStream_t s) {
+int launch_ftran(const LPArgs &a, int nparts_price, int forced_pos, int forced_var, hipStream_t s, hipEvent_t e0,
+                 hipEvent_t e1) {
     const int g = grid_for_rows(a.m);
-    hipLaunchKernelGGL(k_ftran, dim3(g), dim3(kBlock), (size_t)a.ld * sizeof(double), s, a, nparts_price, forced_pos,
-                       forced_var);
+    hipExtLaunchKernelGGL(k_ftran, dim3(g), dim3(kBlock), (size_t)a.ld * sizeof(double), s, e0, e1, 0, a, nparts_price,
+                          forced_pos, forced_var);
     return g;
 }
-void launch_update(const LPArgs &a, int nparts_ratio, int forced_p, int no_swap, int bland, hipStream_t s) {
+void launch_update(const LPArgs &a, int nparts_ratio, int forced_p, int no_swap, int bland, hipStream_t s, hipEvent_t e0,
+                   hipEvent_t e1) {
     const int g = grid_for_rows(a.m);
-    hipLaunchKernelGGL(k_update, dim3(g), dim3(kBlock), (size_t)a.ld * sizeof(double), s, a, nparts_ratio, forced_p,
-                       no_swap, bland);
+    hipExtLaunchKernelGGL(k_update, dim3(g), dim3(kBlock), (size_t)a.ld * sizeof(double), s, e0, e1, 0, a, nparts_ratio,
+                          forced_p, no_swap, bland);
 }
 void launch_transpose_in(const double *A, int64_t lda, int m, int n, double *At, int ld, hipStream_t s) {
     dim3 grid((n + 31) / 32, (m + 31) / 32), block(32, 8);

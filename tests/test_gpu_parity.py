@@ -73,6 +73,19 @@ def test_dense_lp_matches_oracle_bitwise(ctx, m, seed):
     assert g.stats["pivots_phase2"] > 0
 
 
+@pytest.mark.parametrize("m,seed,fused", [(128, 9, 1), (128, 9, 0), (256, 11, 1), (512, 3, 1), (512, 3, 0)])
+def test_fused_and_unfused_pipelines_match_oracle(m, seed, fused):
+    """ld = 128*NV sizes take the fused two-kernel pipeline (fused_kernels.hip); knob fused=0 forces the
+    three-kernel path on the same input.  Both must reproduce the oracle's pivot sequence and bits."""
+    c, A, b = synth.dense_lp_standard_form(m, seed)
+    cx = lp.Context(fused=fused, chunk=16)
+    try:
+        g, o = _check_against_oracle(cx, c, A, b)
+        assert g.stats["kernel_launches"] > 0
+    finally:
+        cx.close()
+
+
 def test_rectangular_more_columns(ctx):
     c, A, b = synth.dense_lp_standard_form(40, 21, nv=90)
     _check_against_oracle(ctx, c, A, b)
