@@ -93,7 +93,7 @@ def main() -> int:
     t0 = time.perf_counter()
     pivots = 0
     ksec = [0.0, 0.0, 0.0, 0.0]
-    loop_s = final_s = 0.0
+    loop_s = final_s = final_dev = final_host = 0.0
     last = None
     for _ in range(args.steps):
         last = step()
@@ -102,6 +102,8 @@ def main() -> int:
             ksec[i] += last.stats["pivot_kernel_seconds"][i]
         loop_s += last.stats["seconds_pivot_loop"]
         final_s += last.stats["seconds_final_solve"]
+        final_dev += last.stats["seconds_final_device"]
+        final_host += last.stats["seconds_final_host"]
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt, float(pivots)], dtype=torch.float64, device="cuda")
@@ -145,7 +147,7 @@ def main() -> int:
                                     "k_update": 1e6 * ksec[2] / nsamp, "sampled_pivots": int(ksec[3])},
                          "per_pivot": {"bytes": bytes_pivot, "achieved_GBs": value / world * bytes_pivot / 1e9,
                                        "frac": value / world * bytes_pivot / 1e9 / HBM_PEAK_GBS}},
-            "breakdown": {"pivot_loop_s": loop_s, "final_solve_s": final_s, "wall_s": dt, "drift_xb": last.stats["drift_xb"],
+            "breakdown": {"pivot_loop_s": loop_s, "final_solve_s": final_s, "final_device_s": final_dev, "final_host_s": final_host, "wall_s": dt, "drift_xb": last.stats["drift_xb"],
                           "z": last.z},
         }
         if not args.no_cpu_baseline:

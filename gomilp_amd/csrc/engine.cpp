@@ -128,6 +128,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "max_pivots") max_pivots_ = v < 0 ? 0 : v;
     else if (key == "sample_events") sample_events_ = v < 0 ? 0 : v;
     else if (key == "fused") fused_ = v ? 1 : 0;
+    else if (key == "lu_blocked") lu_blocked_ = v ? 1 : 0;
     else return GOMILP_ERR_BAD_SHAPE;
     return GOMILP_OK;
 }
@@ -525,6 +526,7 @@ int Engine::run_loop_fused(const Problem &P, int phase, double tol, int nn, cons
 // ------------------------------------------------------------------------------------------------
 int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *singular) {
     Work &w = *w_;
+    const double tf0 = now_s();
     const int m = P.m, ldw = P.ld;
     launch_gather_w(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
     LUArgs a;
@@ -533,13 +535,15 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     a.st = w.st;
     w.st_host->lu_singular = 0;
     sync_state_to_device();
-    launch_lu(a, stream_);
-    launches_ += m + 2;
+    if (lu_blocked_ && lu_blocked_supported(m)) launches_ += launch_lu_blocked(a, w.rho, stream_) + 1;
+    else { launch_lu(a, stream_); launches_ += m + 2; }
     HIP_TRY(hipMemcpyAsync(w.h_W, w.W, (size_t)m * ldw * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(w.h_idx, w.lpos, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     HIP_TRY(hipGetLastError());
+    const double tf1 = now_s();
+    fs_device_ += tf1 - tf0;
     std::vector<int32_t> phys(m);
     for (int R = 0; R < m; R++) phys[w.h_idx[R]] = R;
     // LU.Det() == 0 (mat/lu.go:301, :118-135): exp(sum log|u_ii|) == 0
@@ -571,6 +575,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
         const double t = 1 / row[i];
         x[i] = bi * t;
     }
+    fs_host_ += now_s() - tf1;
     return GOMILP_OK;
 }
 
@@ -592,8 +597,13 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     if (id < 0 || (size_t)id >= problems_.size() || !problems_[id] || !opt_f || !opt_x || !has_x) return GOMILP_ERR_BAD_SHAPE;
     const Problem &P = *problems_[id];
     st->seconds_upload = P.seconds_upload;
-    auto finish = [&](int code) { st->seconds_total = now_s() - t0; st->kernel_launches = launches_; return code; };
+    auto finish = [&](int code) {
+        st->seconds_total = now_s() - t0; st->kernel_launches = launches_;
+        st->seconds_final_device = fs_device_; st->seconds_final_host = fs_host_;
+        return code;
+    };
     launches_ = 0;
+    fs_device_ = fs_host_ = 0;
     last_trace_.clear();
     last_trace_total_ = 0;
     if (P.verify_status != GOMILP_OK) {  // simplex.go:94-100

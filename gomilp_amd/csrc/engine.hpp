@@ -60,12 +60,13 @@ class Engine {
     std::vector<std::unique_ptr<Problem>> problems_;
     std::unique_ptr<Work> w_;
     // knobs
-    int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1;
+    int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 1;
     // per-solve state
     int cur_ = 0;   // which Binv buffer is current
     int ycur_ = 0;  // which y buffer is current
     int grid_ratio_ = 1;  // workgroups of the last ratio-test kernel (partials to reduce)
     int64_t launches_ = 0;
+    double fs_device_ = 0, fs_host_ = 0;
     std::vector<gomilp_pivot> last_trace_;
     int64_t last_trace_total_ = 0;
 };
@@ -95,5 +96,8 @@ void launch_y_from_binv(const double *binv, int ld, int m, const double *cost, c
 void launch_gather_w(const double *At, int ld, int m, const int32_t *basic, double *W, int ldw, hipStream_t s);
 int lu_grid(int m);
 void launch_lu(const LUArgs &a, hipStream_t s);
+// lu_kernels.hip
+bool lu_blocked_supported(int m);
+int launch_lu_blocked(const LUArgs &a, int32_t *pivrow, hipStream_t s);
 
 }  // namespace gomilp

@@ -33,7 +33,22 @@ __global__ __launch_bounds__(kBlock) void k_price_fused(LPArgs a, const double *
     DevState *st = a.st;
     if (st->done) return;
     constexpr int ld2 = NV * 64;
-    int q_prev = -1, lea = -1;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    int q_prev = pending ? st->q : -1;
+    int lea = -1;
+    // issue the loads of this wave's first row now: they fly while the prologue's dependent chain
+    // (partials -> p -> row p / y) runs.  The one wave that owns position q_prev must wait for `lea`.
+    double2 v[NV];
+    int j0 = -1;
+    const bool pre = (wave < a.nn) && (wave != q_prev);
+    if (pre) {
+        j0 = a.nonbasic[wave];
+        const double2 *r2 = reinterpret_cast<const double2 *>(a.At + (size_t)j0 * a.ld);
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = r2[lane + 64 * k];
+    }
     if (pending) {
         const int p = (int)reduce_partials(a.pk_ratio, a.pi_ratio, nparts_ratio, sk, si, nullptr);
         const double mv = a.move[p];
@@ -47,18 +62,17 @@ __global__ __launch_bounds__(kBlock) void k_price_fused(LPArgs a, const double *
         }
         const double dpv = a.dvec[p];
         const double alpha = st->rq / dpv;
-        q_prev = st->q;
         lea = a.basic[p];
         const double2 *rp = reinterpret_cast<const double2 *>(a.binv_cur + (size_t)p * a.ld);
         const double2 *yi = reinterpret_cast<const double2 *>(y_in);
         double2 *yo = reinterpret_cast<double2 *>(y_out);
         for (int c = threadIdx.x; c < ld2; c += kBlock) {
-            double2 v = yi[c];
+            double2 w = yi[c];
             const double2 r = rp[c];
-            v.x = v.x + alpha * r.x;
-            v.y = v.y + alpha * r.y;
-            svec[c] = v;
-            if (blockIdx.x == 0) yo[c] = v;
+            w.x = w.x + alpha * r.x;
+            w.y = w.y + alpha * r.y;
+            svec[c] = w;
+            if (blockIdx.x == 0) yo[c] = w;
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             // commit pivot t-1 (simplex.go:280); basic[p] itself is rewritten by K_B(t) because this kernel's
@@ -78,17 +92,16 @@ __global__ __launch_bounds__(kBlock) void k_price_fused(LPArgs a, const double *
     } else {
         stage_vec(svec, y_in, ld2);
     }
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * kWavesPerBlock;
     unsigned long long bk = ~0ull;
     unsigned int bi = 0xFFFFFFFFu;
     for (int pos = wave; pos < a.nn; pos += nwaves) {
-        const int j = (pos == q_prev) ? lea : a.nonbasic[pos];
-        const double2 *r2 = reinterpret_cast<const double2 *>(a.At + (size_t)j * a.ld);
-        double2 v[NV];
+        int j = j0;
+        if (!(pre && pos == wave)) {
+            j = (pos == q_prev) ? lea : a.nonbasic[pos];
+            const double2 *r2 = reinterpret_cast<const double2 *>(a.At + (size_t)j * a.ld);
 #pragma unroll
-        for (int k = 0; k < NV; k++) v[k] = r2[lane + 64 * k];
+            for (int k = 0; k < NV; k++) v[k] = r2[lane + 64 * k];
+        }
         double acc[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < NV; k++) {
@@ -114,6 +127,16 @@ __global__ __launch_bounds__(kBlock) void k_update_ftran_fused(LPArgs a, int pen
     constexpr int ld2 = NV * 64;
     double2 *svecA = svec;        // entering column a_q
     double2 *svecP = svec + ld2;  // old row p of B^-1
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    // this wave's first row of B^-1 goes in flight before the prologue (reduce -> q -> stage a_q, row p)
+    double2 v[NV];
+    if (wave < a.m) {
+        const double2 *src = reinterpret_cast<const double2 *>(a.binv_cur + (size_t)wave * a.ld);
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = src[lane + 64 * k];
+    }
     const int q = (int)reduce_partials(a.pk_price, a.pi_price, nparts_price, sk, si, nullptr);
     const double rq = a.rvec[q];
     const bool optimal = (rq >= -a.tol);  // simplex.go:248
@@ -134,16 +157,14 @@ __global__ __launch_bounds__(kBlock) void k_update_ftran_fused(LPArgs a, int pen
         if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->status = ST_OPTIMAL; st->q = q; st->rq = rq; }
         return;
     }
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * kWavesPerBlock;
     unsigned long long bk = ~0ull;
     unsigned int bi = 0xFFFFFFFFu;
     for (int i = wave; i < a.m; i += nwaves) {
-        const double2 *src = reinterpret_cast<const double2 *>(a.binv_cur + (size_t)i * a.ld);
-        double2 v[NV];
+        if (i != wave) {
+            const double2 *src = reinterpret_cast<const double2 *>(a.binv_cur + (size_t)i * a.ld);
 #pragma unroll
-        for (int k = 0; k < NV; k++) v[k] = src[lane + 64 * k];
+            for (int k = 0; k < NV; k++) v[k] = src[lane + 64 * k];
+        }
         const double di_old = pending ? a.dvec[i] : 0.0;
         double xbi = a.xb[i];
         if (pending) {

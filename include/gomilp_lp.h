@@ -56,7 +56,10 @@ typedef struct gomilp_lp_stats {
     double seconds_pivot_loop;  /* HIP-event time of all pivot-loop kernels (Phase I + II) */
     double seconds_final_solve; /* gonum-order LU on device + host triangular solves */
     double drift_xb;            /* max |x_B(updated) - x_B(fresh LU)| at termination: accuracy of the B^-1 updates */
-    double pivot_kernel_seconds[4]; /* HIP-event time per kernel class: price, ftran, update, other */
+    double pivot_kernel_seconds[4]; /* HIP-event time of sampled pivots: [0] pricing kernel, [1] ftran kernel (0 when fused),
+                                       [2] update(+ftran) kernel, [3] number of sampled pivots */
+    double seconds_final_device; /* part of seconds_final_solve: gather + LU kernels + device->host copy */
+    double seconds_final_host;   /* part of seconds_final_solve: the two triangular solves on the host */
 } gomilp_lp_stats;
 
 /* One record per pivot, execution order (Phase I first).  Same fields as the oracle's trace. */

@@ -149,6 +149,25 @@ def test_exactly_constrained_m_equals_n(ctx):
     _check_against_oracle(ctx, c, A, b)
 
 
+@pytest.mark.parametrize("m,seed", [(200, 2), (700, 3), (1024, 1), (2048, 2)])
+def test_blocked_lu_equals_per_column_lu_bitwise(m, seed):
+    """The blocked final solve (lu_kernels.hip: register panel + trailing rank-nb update) must give the same bits
+    as the one-launch-per-column schedule (simplex_kernels.hip k_lu_step), which the small cases pin to the oracle."""
+    c, A, b = synth.dense_lp_standard_form(m, seed)
+    res = []
+    for blocked in (1, 0):
+        cx = lp.Context(lu_blocked=blocked)
+        try:
+            rl = cx.upload(c, A, b)
+            res.append(rl.solve(0.0))
+            rl.free()
+        finally:
+            cx.close()
+    assert res[0].status == lp.OK == res[1].status
+    assert np.array_equal(res[0].basis, res[1].basis)
+    assert np.array_equal(res[0].x, res[1].x) and res[0].z == res[1].z
+
+
 def test_full_size_properties_C2(ctx):
     """1024x2048 (BASELINE config C2): size-independent checks — primal/dual feasibility, complementary
     slackness through an independent LAPACK solve, objective against HiGHS."""
