@@ -45,12 +45,10 @@ __global__ __launch_bounds__(T) void k_lu_panel(LUArgs a, int k0, int nb, int32_
     __shared__ unsigned long long sk[NW];
     __shared__ unsigned int sl[NW], sr[NW];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    PanelRow<NB> r0, r1, r2, r3;
-#define GOMILP_FOR_ROWS(F)                                  \
-    do {                                                    \
-        F(r0, 0);                                           \
-        if constexpr (RPT > 1) F(r1, 1);                    \
-        if constexpr (RPT > 2) { F(r2, 2); F(r3, 3); }      \
+    PanelRow<NB> rows[RPT];
+#define GOMILP_FOR_ROWS(F)                              \
+    do {                                                \
+        _Pragma("unroll") for (int rr_ = 0; rr_ < RPT; rr_++) F(rows[rr_], rr_); \
     } while (0)
     auto load_row = [&](PanelRow<NB> &row, int r) {
         row.R = tid + r * T;
@@ -233,6 +231,8 @@ bool lu_blocked_supported(int m) { return m <= 4096; }
 // returns the number of kernel launches enqueued
 int launch_lu_blocked(const LUArgs &a, int32_t *pivrow, hipStream_t s) {
     const int m = a.m;
+    // measured at m = 2048 (gfx950): <1024,2,16> 80 us per 16-column panel, <256,8,16> 190 us: the per-step
+    // reduce/publish/shift overhead is issue-bound, more resident waves hide it better than fewer, fatter ones
     if (m <= 512) { lu_blocked_t<512, 1, 32>(a, pivrow, s); return 1 + 3 * ((m + 31) / 32); }
     if (m <= 1024) { lu_blocked_t<1024, 1, 32>(a, pivrow, s); return 1 + 3 * ((m + 31) / 32); }
     if (m <= 2048) { lu_blocked_t<1024, 2, 16>(a, pivrow, s); return 1 + 3 * ((m + 15) / 16); }
