@@ -2,10 +2,14 @@
 // interface it replaces; see INTEGRATION.md for the cgo binding.
 #include <math.h>
 
+#include <atomic>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "engine.hpp"
 
@@ -13,6 +17,14 @@ using gomilp::Engine;
 
 struct gomilp_ctx {
     std::unique_ptr<Engine> eng;
+};
+
+// One worker = one Engine (stream + work buffers) with its own resident copy of the root.
+struct gomilp_pool {
+    int device = 0;
+    std::vector<std::unique_ptr<Engine>> eng;
+    std::vector<int64_t> root;  // root problem id inside each engine
+    int64_t m0 = 0, n0 = 0;
 };
 
 extern "C" {
@@ -51,6 +63,91 @@ int gomilp_lp_solve_resident(gomilp_ctx *ctx, int64_t problem, double tol, const
     if (!ctx) return GOMILP_ERR_BAD_SHAPE;
     return ctx->eng->solve(problem, tol, initial_basic, opt_f, opt_x, has_x, basis_out, stats);
 }
+int64_t gomilp_lp_upload_child(gomilp_ctx *ctx, int64_t root_problem, int32_t K, const int32_t *var, const double *sign,
+                               const double *rhs) {
+    if (!ctx) return -GOMILP_ERR_BAD_SHAPE;
+    return ctx->eng->upload_child(root_problem, K, var, sign, rhs);
+}
+
+gomilp_pool *gomilp_pool_create(int device, int workers, int *status) {
+    int n = gomilp::device_count();
+    if (n <= 0) { if (status) *status = GOMILP_ERR_DEVICE; return nullptr; }
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= n || workers < 1 || workers > 64) { if (status) *status = device >= n ? GOMILP_ERR_DEVICE : GOMILP_ERR_BAD_SHAPE; return nullptr; }
+    gomilp_pool *p = new gomilp_pool;
+    p->device = device;
+    for (int w = 0; w < workers; w++) { p->eng.emplace_back(new Engine(device)); p->root.push_back(-1); }
+    if (status) *status = GOMILP_OK;
+    return p;
+}
+void gomilp_pool_destroy(gomilp_pool *pool) { delete pool; }
+
+int gomilp_pool_set_root(gomilp_pool *pool, const double *c0, const double *A0, int64_t lda, const double *b0, int64_t m0,
+                         int64_t n0) {
+    if (!pool) return GOMILP_ERR_BAD_SHAPE;
+    for (size_t w = 0; w < pool->eng.size(); w++) {
+        if (pool->root[w] >= 0) pool->eng[w]->free_problem(pool->root[w]);
+        int64_t id = pool->eng[w]->upload(c0, A0, lda, b0, m0, n0);
+        if (id < 0) { pool->root[w] = -1; return (int)-id; }
+        pool->root[w] = id;
+    }
+    pool->m0 = m0; pool->n0 = n0;
+    return GOMILP_OK;
+}
+
+int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff, const int32_t *var, const double *sign,
+                          const double *rhs, double tol, double *z_out, double *x_out, int32_t *status_out,
+                          int32_t *has_x_out, gomilp_frontier_stats *stats) {
+    if (!pool || count < 0 || !koff || !z_out || !x_out || !status_out || !has_x_out) return GOMILP_ERR_BAD_SHAPE;
+    for (auto r : pool->root) if (r < 0) return GOMILP_ERR_BAD_SHAPE;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int64_t n0 = pool->n0;
+    std::atomic<int64_t> next(0);
+    const int W = (int)pool->eng.size();
+    std::vector<gomilp_frontier_stats> ws(W);
+    auto work = [&](int w) {
+        Engine &E = *pool->eng[w];
+        gomilp_frontier_stats &S = ws[w];
+        S = gomilp_frontier_stats();
+        std::vector<double> x;
+        for (;;) {
+            const int64_t i = next.fetch_add(1);
+            if (i >= count) break;
+            const auto s0 = std::chrono::steady_clock::now();
+            const int64_t k0 = koff[i], K = koff[i + 1] - koff[i];
+            z_out[i] = NAN; has_x_out[i] = 0;
+            int64_t id = E.upload_child(pool->root[w], (int)K, var + k0, sign + k0, rhs + k0);
+            if (id < 0) { status_out[i] = (int32_t)-id; continue; }
+            x.assign((size_t)(n0 + K), 0.0);
+            gomilp_lp_stats st;
+            int32_t hx = 0;
+            double z = NAN;
+            const int rc = E.solve(id, tol, nullptr, &z, x.data(), &hx, nullptr, &st);
+            E.free_problem(id);
+            status_out[i] = rc; z_out[i] = z; has_x_out[i] = hx;
+            if (hx) for (int64_t j = 0; j < n0; j++) x_out[i * n0 + j] = x[j];  // subproblem.go:157-159
+            S.relaxations++; S.pivots_phase1 += st.pivots_phase1; S.pivots_phase2 += st.pivots_phase2;
+            S.bland_steps += st.bland_steps; S.phase1_runs += st.phase1_used; S.kernel_launches += st.kernel_launches;
+            S.seconds_busy_sum += std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count();
+        }
+    };
+    std::vector<std::thread> th;
+    for (int w = 1; w < W; w++) th.emplace_back(work, w);
+    work(0);
+    for (auto &t : th) t.join();
+    if (stats) {
+        *stats = gomilp_frontier_stats();
+        for (auto &S : ws) {
+            stats->relaxations += S.relaxations; stats->pivots_phase1 += S.pivots_phase1; stats->pivots_phase2 += S.pivots_phase2;
+            stats->bland_steps += S.bland_steps; stats->phase1_runs += S.phase1_runs; stats->kernel_launches += S.kernel_launches;
+            stats->seconds_busy_sum += S.seconds_busy_sum;
+        }
+        stats->workers = W; stats->device_id = pool->device;
+        stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return GOMILP_OK;
+}
+
 int64_t gomilp_lp_last_trace(gomilp_ctx *ctx, gomilp_pivot *out, int64_t cap) {
     if (!ctx) return -1;
     return ctx->eng->last_trace(out, cap);

@@ -240,6 +240,72 @@ int64_t Engine::upload(const double *c, const double *A, int64_t lda, const doub
     return (int64_t)problems_.size() - 1;
 }
 
+int64_t Engine::upload_child(int64_t root, int K, const int32_t *var, const double *sign, const double *rhs) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (root < 0 || (size_t)root >= problems_.size() || !problems_[root] || K < 0 || (K > 0 && (!var || !sign || !rhs)))
+        return -GOMILP_ERR_BAD_SHAPE;
+    const Problem &R = *problems_[root];
+    const int m0 = R.m, n0 = R.n, m = m0 + K, n = n0 + K;
+    const int ld = (m + 1) & ~1;
+    for (int k = 0; k < K; k++) if (var[k] < 0 || var[k] >= n0) return -GOMILP_ERR_BAD_SHAPE;
+    if ((size_t)ld * sizeof(double) > 64 * 1024) return -GOMILP_ERR_UNSUPPORTED;
+    if (hipSetDevice(device_) != hipSuccess) return -GOMILP_ERR_DEVICE;
+    const double t0 = now_s();
+    std::unique_ptr<Problem> P(new Problem);
+    P->m = m; P->n = n; P->ld = ld;
+    int32_t *dvar = nullptr;
+    double *dsign = nullptr;
+    auto fail = [&](int code) -> int64_t {
+        if (dvar) hipFree(dvar);
+        if (dsign) hipFree(dsign);
+        if (P->dAt) hipFree(P->dAt);
+        if (P->dc) hipFree(P->dc);
+        if (P->dc1) hipFree(P->dc1);
+        if (P->db) hipFree(P->db);
+        return -code;
+    };
+#define UP_TRY(expr) do { if ((expr) != hipSuccess) return fail(GOMILP_ERR_DEVICE); } while (0)
+    UP_TRY(dmalloc(&P->dAt, (size_t)(n + 1) * ld));
+    UP_TRY(dmalloc(&P->dc, (size_t)n + 1));
+    UP_TRY(dmalloc(&P->dc1, (size_t)n + 1));
+    UP_TRY(dmalloc(&P->db, (size_t)ld));
+    UP_TRY(dmalloc(&dvar, (size_t)K));
+    UP_TRY(dmalloc(&dsign, (size_t)K));
+    P->hc = R.hc; P->hc.resize(n, 0.0);        // c' = [c, 0]   (subproblem.go:110-114)
+    P->hb = R.hb; P->hb.insert(P->hb.end(), rhs, rhs + K);  // b' = [b; h]  (:117-119)
+    std::vector<double> hb_pad(ld, 0.0), hc_pad((size_t)n + 1, 0.0), hc1((size_t)n + 1, 0.0);
+    std::copy(P->hb.begin(), P->hb.end(), hb_pad.begin());
+    std::copy(P->hc.begin(), P->hc.end(), hc_pad.begin());
+    hc1[n] = 1.0;
+    if (K) {
+        UP_TRY(hipMemcpyAsync(dvar, var, (size_t)K * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        UP_TRY(hipMemcpyAsync(dsign, sign, (size_t)K * sizeof(double), hipMemcpyHostToDevice, stream_));
+    }
+    UP_TRY(hipMemcpyAsync(P->db, hb_pad.data(), (size_t)ld * sizeof(double), hipMemcpyHostToDevice, stream_));
+    UP_TRY(hipMemcpyAsync(P->dc, hc_pad.data(), ((size_t)n + 1) * sizeof(double), hipMemcpyHostToDevice, stream_));
+    UP_TRY(hipMemcpyAsync(P->dc1, hc1.data(), ((size_t)n + 1) * sizeof(double), hipMemcpyHostToDevice, stream_));
+    launch_child_assemble(R.dAt, R.ld, m0, n0, P->dAt, ld, K, dvar, dsign, stream_);
+    UP_TRY(hipStreamSynchronize(stream_));
+    UP_TRY(hipGetLastError());
+#undef UP_TRY
+    hipFree(dvar); dvar = nullptr;
+    hipFree(dsign); dsign = nullptr;
+    // column statistics follow from the root's: a branched column gains one entry per constraint on it
+    P->nnz = R.nnz; P->lastrow = R.lastrow; P->allone = R.allone;
+    P->nnz.resize(n); P->lastrow.resize(n); P->allone.resize(n);
+    for (int k = 0; k < K; k++) {
+        P->nnz[var[k]] += 1; P->lastrow[var[k]] = m0 + k;
+        if (sign[k] != 1.0) P->allone[var[k]] = 0;
+        P->nnz[n0 + k] = 1; P->lastrow[n0 + k] = m0 + k; P->allone[n0 + k] = 1;
+    }
+    P->verify_status = R.verify_status;  // bnb rows and their slack columns are never empty
+    P->seconds_upload = now_s() - t0;
+    for (size_t i = 0; i < problems_.size(); i++)
+        if (!problems_[i]) { problems_[i] = std::move(P); return (int64_t)i; }
+    problems_.push_back(std::move(P));
+    return (int64_t)problems_.size() - 1;
+}
+
 int Engine::free_problem(int64_t id) {
     std::lock_guard<std::mutex> g(mu_);
     if (id < 0 || (size_t)id >= problems_.size() || !problems_[id]) return GOMILP_ERR_BAD_SHAPE;

@@ -37,6 +37,8 @@ class Engine {
 
     int64_t upload(const double *c, const double *A, int64_t lda, const double *b, int64_t m, int64_t n);
     int free_problem(int64_t id);
+    // child of a resident root: K branch-and-bound rows (var, sign, rhs) appended on the device (subproblem.go:141-159)
+    int64_t upload_child(int64_t root, int K, const int32_t *var, const double *sign, const double *rhs);
     int solve(int64_t id, double tol, const int64_t *initial_basic, double *opt_f, double *opt_x, int32_t *has_x,
               int64_t *basis_out, gomilp_lp_stats *stats);
     int64_t last_trace(gomilp_pivot *out, int64_t cap);
@@ -89,6 +91,8 @@ void launch_transpose_in(const double *A, int64_t lda, int m, int n, double *At,
 void launch_col_stats(const double *At, int ld, int m, int n, int32_t *nnz, int32_t *lastrow, int32_t *allone,
                       int32_t *rowflag, hipStream_t s);
 void launch_set_binv_perm(double *binv, int ld, int m, const int32_t *rho, hipStream_t s);
+void launch_child_assemble(const double *At0, int ld0, int m0, int n0, double *At1, int ld1, int K, const int32_t *var,
+                           const double *sign, hipStream_t s);
 void launch_matvec_rows(const double *M, int ld, int m, const double *vec, double *out, hipStream_t s);
 int y_chunks(int m);
 void launch_y_from_binv(const double *binv, int ld, int m, const double *cost, const int32_t *basic, double *scratch,

@@ -213,6 +213,28 @@ __global__ __launch_bounds__(kBlock) void k_col_stats(const double *__restrict__
     }
 }
 
+// Child relaxation of a B&B node assembled in HBM from the resident root (subproblem.go:81-139, :245-255):
+//   child A = [[A0, 0], [G#, I_K]],  G# row k = sign_k * e_{var_k}.  In the transposed layout every root column keeps
+//   its m0 entries and gains K entries; K unit columns are appended; the last row is the (zeroed) artificial slot.
+__global__ __launch_bounds__(kBlock) void k_child_assemble(const double *__restrict__ At0, int ld0, int m0, int n0,
+                                                           double *__restrict__ At1, int ld1, int K,
+                                                           const int32_t *__restrict__ var, const double *__restrict__ sign) {
+    const int j = blockIdx.x;  // child column
+    double *dst = At1 + (size_t)j * ld1;
+    if (j < n0) {
+        const double *src = At0 + (size_t)j * ld0;
+        for (int i = threadIdx.x; i < ld1; i += kBlock) {
+            double v = 0.0;
+            if (i < m0) v = src[i];
+            else if (i < m0 + K && var[i - m0] == j) v = sign[i - m0];
+            dst[i] = v;
+        }
+    } else {
+        const int unit = (j < n0 + K) ? m0 + (j - n0) : -1;
+        for (int i = threadIdx.x; i < ld1; i += kBlock) dst[i] = (i == unit) ? 1.0 : 0.0;
+    }
+}
+
 // Binv = permutation: Binv[pos, rho[pos]] = 1 (buffer pre-zeroed)
 __global__ void k_set_binv_perm(double *binv, int ld, int m, const int32_t *rho) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
@@ -406,6 +428,10 @@ void launch_transpose_in(const double *A, int64_t lda, int m, int n, double *At,
 void launch_col_stats(const double *At, int ld, int m, int n, int32_t *nnz, int32_t *lastrow, int32_t *allone,
                       int32_t *rowflag, hipStream_t s) {
     hipLaunchKernelGGL(k_col_stats, dim3(grid_for_rows(n)), dim3(kBlock), 0, s, At, ld, m, n, nnz, lastrow, allone, rowflag);
+}
+void launch_child_assemble(const double *At0, int ld0, int m0, int n0, double *At1, int ld1, int K, const int32_t *var,
+                           const double *sign, hipStream_t s) {
+    hipLaunchKernelGGL(k_child_assemble, dim3(n0 + K + 1), dim3(kBlock), 0, s, At0, ld0, m0, n0, At1, ld1, K, var, sign);
 }
 void launch_set_binv_perm(double *binv, int ld, int m, const int32_t *rho, hipStream_t s) {
     hipLaunchKernelGGL(k_set_binv_perm, dim3((m + 255) / 256), dim3(256), 0, s, binv, ld, m, rho);

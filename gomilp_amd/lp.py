@@ -46,7 +46,15 @@ class Pivot(C.Structure):
                 ("entering", C.c_int64), ("leaving", C.c_int64)]
 
 
+class FrontierStats(C.Structure):
+    _fields_ = [("relaxations", C.c_int64), ("pivots_phase1", C.c_int64), ("pivots_phase2", C.c_int64),
+                ("bland_steps", C.c_int64), ("phase1_runs", C.c_int64), ("kernel_launches", C.c_int64),
+                ("workers", C.c_int32), ("device_id", C.c_int32), ("seconds_total", C.c_double),
+                ("seconds_busy_sum", C.c_double)]
+
+
 EXPORTS = [
+    "gomilp_lp_upload_child", "gomilp_pool_create", "gomilp_pool_destroy", "gomilp_pool_set_root", "gomilp_frontier_solve",
     "gomilp_lp_simplex", "gomilp_ctx_create", "gomilp_ctx_destroy", "gomilp_ctx_device", "gomilp_ctx_set",
     "gomilp_lp_upload", "gomilp_lp_free", "gomilp_lp_solve_resident", "gomilp_lp_last_trace", "gomilp_version",
     "gomilp_device_count", "gomilp_compiled_arch",
@@ -80,6 +88,15 @@ def lib():
     L.gomilp_lp_last_trace.argtypes = [C.c_void_p, C.POINTER(Pivot), C.c_int64]
     L.gomilp_lp_simplex.argtypes = [dp, dp, C.c_int64, dp, C.c_int64, C.c_int64, C.c_double, ip, dp, dp,
                                     C.POINTER(C.c_int32), ip, C.POINTER(Stats)]
+    i32p = C.POINTER(C.c_int32)
+    L.gomilp_lp_upload_child.restype = C.c_int64
+    L.gomilp_lp_upload_child.argtypes = [C.c_void_p, C.c_int64, C.c_int32, i32p, dp, dp]
+    L.gomilp_pool_create.restype = C.c_void_p
+    L.gomilp_pool_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.gomilp_pool_destroy.argtypes = [C.c_void_p]
+    L.gomilp_pool_set_root.argtypes = [C.c_void_p, dp, dp, C.c_int64, dp, C.c_int64, C.c_int64]
+    L.gomilp_frontier_solve.argtypes = [C.c_void_p, C.c_int64, ip, i32p, dp, dp, C.c_double, dp, dp, i32p, i32p,
+                                        C.POINTER(FrontierStats)]
     _lib = L
     return L
 
@@ -180,6 +197,18 @@ class ResidentLP:
     def __init__(self, ctx: Context, pid: int, m: int, n: int):
         self.ctx, self.pid, self.m, self.n = ctx, pid, m, n
 
+    def child(self, constraints) -> "ResidentLP":
+        """B&B child assembled on the device: constraints = [(var, sign, rhs), ...] (subproblem.go:36-44)."""
+        K = len(constraints)
+        var = np.array([c[0] for c in constraints], dtype=np.int32)
+        sign = np.array([c[1] for c in constraints], dtype=np.float64)
+        rhs = np.array([c[2] for c in constraints], dtype=np.float64)
+        pid = lib().gomilp_lp_upload_child(self.ctx._h, self.pid, K, var.ctypes.data_as(C.POINTER(C.c_int32)), _dp(sign),
+                                           _dp(rhs))
+        if pid < 0:
+            raise RuntimeError("gomilp_lp_upload_child failed: %s" % STATUS_NAMES.get(-pid, -pid))
+        return ResidentLP(self.ctx, pid, self.m + K, self.n + K)
+
     def solve(self, tol: float = 0.0, trace: bool = False) -> LPResult:
         L = lib()
         x = np.zeros(self.n)
@@ -204,3 +233,73 @@ class ResidentLP:
         if self.pid >= 0:
             lib().gomilp_lp_free(self.ctx._h, self.pid)
             self.pid = -1
+
+
+@dataclass
+class FrontierResult:
+    status: np.ndarray   # int32[count]
+    z: np.ndarray        # float64[count]
+    x: np.ndarray        # float64[count, n0] (rows valid where has_x)
+    has_x: np.ndarray    # int32[count]
+    stats: dict
+
+
+class FrontierPool:
+    """`workers` engine contexts on one GPU solving independent child relaxations of one root concurrently
+    (the solveWorker pool of /root/reference/tree.go:98-100,196-205 for one FIFO level)."""
+
+    def __init__(self, device: int = -1, workers: int = 4):
+        st = C.c_int(0)
+        self._h = lib().gomilp_pool_create(int(device), int(workers), C.byref(st))
+        if not self._h:
+            raise RuntimeError("gomilp_pool_create failed: %s" % STATUS_NAMES.get(st.value, st.value))
+        self.n0 = self.m0 = 0
+
+    def set_root(self, c0, A0, b0) -> None:
+        A0 = np.ascontiguousarray(A0, dtype=np.float64)
+        c0 = np.ascontiguousarray(c0, dtype=np.float64)
+        b0 = np.ascontiguousarray(b0, dtype=np.float64)
+        m0, n0 = A0.shape
+        rc = lib().gomilp_pool_set_root(self._h, _dp(c0), _dp(A0), n0, _dp(b0), m0, n0)
+        if rc != OK:
+            raise RuntimeError("gomilp_pool_set_root failed: %s" % STATUS_NAMES.get(rc, rc))
+        self.m0, self.n0 = m0, n0
+
+    def solve(self, children, tol: float = 0.0) -> FrontierResult:
+        """children: list of constraint lists [(var, sign, rhs), ...]."""
+        count = len(children)
+        koff = np.zeros(count + 1, dtype=np.int64)
+        for i, ch in enumerate(children):
+            koff[i + 1] = koff[i] + len(ch)
+        tot = int(koff[-1])
+        var = np.zeros(max(tot, 1), dtype=np.int32)
+        sign = np.zeros(max(tot, 1), dtype=np.float64)
+        rhs = np.zeros(max(tot, 1), dtype=np.float64)
+        k = 0
+        for ch in children:
+            for (v, s, r) in ch:
+                var[k], sign[k], rhs[k] = v, s, r
+                k += 1
+        z = np.full(count, math.nan)
+        x = np.zeros((count, self.n0))
+        status = np.zeros(count, dtype=np.int32)
+        has_x = np.zeros(count, dtype=np.int32)
+        st = FrontierStats()
+        i32p = C.POINTER(C.c_int32)
+        rc = lib().gomilp_frontier_solve(self._h, count, _ip(koff), var.ctypes.data_as(i32p), _dp(sign), _dp(rhs),
+                                         float(tol), _dp(z), _dp(x), status.ctypes.data_as(i32p),
+                                         has_x.ctypes.data_as(i32p), C.byref(st))
+        if rc != OK:
+            raise RuntimeError("gomilp_frontier_solve failed: %s" % STATUS_NAMES.get(rc, rc))
+        return FrontierResult(status, z, x, has_x, {k: getattr(st, k) for k, _ in FrontierStats._fields_})
+
+    def close(self) -> None:
+        if self._h:
+            lib().gomilp_pool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -54,3 +54,23 @@ def integrality_mask(nv: int, m: int) -> np.ndarray:
 
 # BASELINE.json configs: name -> (m, seed)
 CONFIGS = {"C2": (1024, 1), "M": (2048, 2), "C4": (4096, 4), "C3": (512, 3), "C5": (512, 3)}
+
+
+def frontier_children(root_x, integrality, nvars: int = 8):
+    """C5 (SURVEY.md §8d): the `nvars` highest-index integer-constrained variables with a fractional root value;
+    every sign pattern of {x_j <= floor(x_j*), -x_j <= -(floor(x_j*)+1)} is one independent child, described as
+    [(var, sign, rhs), ...] exactly like the bnbConstraints of /root/reference/subproblem.go:193-259."""
+    import math
+    picks = [j for j in range(len(integrality) - 1, -1, -1)
+             if integrality[j] and root_x[j] != math.floor(root_x[j])][:nvars]
+    children = []
+    for pattern in range(1 << len(picks)):
+        cons = []
+        for k, j in enumerate(picks):
+            fl = float(math.floor(root_x[j]))
+            if (pattern >> k) & 1:
+                cons.append((j, -1, -(fl + 1.0)))
+            else:
+                cons.append((j, 1, fl))
+        children.append(cons)
+    return children

@@ -114,6 +114,42 @@ int gomilp_lp_solve_resident(gomilp_ctx *ctx, int64_t problem, double tol, const
  * total number of pivots performed. */
 int64_t gomilp_lp_last_trace(gomilp_ctx *ctx, gomilp_pivot *out, int64_t cap);
 
+/* Child of a resident root problem, assembled on the device: the K branch-and-bound rows
+ * G#_k = sign_k * e_{var_k}, h#_k = rhs_k of /root/reference/subproblem.go:36-44,245-255 are appended exactly like
+ * convertToEqualities (subproblem.go:81-139) does: A' = [[A0, 0], [G#, I_K]], c' = [c0, 0], b' = [b0; h#].
+ * Returns a problem id (solve it with gomilp_lp_solve_resident; x has n0 + K entries, the caller keeps the
+ * first n0 like subproblem.go:157-159) or -(gomilp_status). */
+int64_t gomilp_lp_upload_child(gomilp_ctx *ctx, int64_t root_problem, int32_t K, const int32_t *var, const double *sign,
+                               const double *rhs);
+
+/* ------------------------------------------------------------------------------------------
+ * Frontier API: one FIFO level of the enumeration tree (independent relaxations sharing the root data,
+ * tree.go:98-100,196-205) solved by a pool of `workers` contexts on ONE GPU, each on its own HIP stream.
+ * Multi-GPU runs use one pool per process/GPU and shard the children by index (bench.py).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gomilp_pool gomilp_pool;
+
+typedef struct gomilp_frontier_stats {
+    int64_t relaxations;
+    int64_t pivots_phase1, pivots_phase2, bland_steps, phase1_runs;
+    int64_t kernel_launches;
+    int32_t workers, device_id;
+    double seconds_total;       /* host wall clock of the call */
+    double seconds_busy_sum;    /* sum over workers of time spent inside solves */
+} gomilp_frontier_stats;
+
+gomilp_pool *gomilp_pool_create(int device, int workers, int *status);
+void gomilp_pool_destroy(gomilp_pool *pool);
+/* Upload the root standard form (row-major A0, stride lda) to every worker context of the pool. */
+int gomilp_pool_set_root(gomilp_pool *pool, const double *c0, const double *A0, int64_t lda, const double *b0, int64_t m0,
+                         int64_t n0);
+/* Solve `count` children.  Child i owns the triples [koff[i], koff[i+1]) of (var, sign, rhs) (koff has count+1 entries).
+ * Outputs, all caller-owned: z_out[count]; x_out[count*n0] (root width, subproblem.go:157-159); status_out[count]
+ * (gomilp_status); has_x_out[count].  Returns GOMILP_OK unless the call itself could not run. */
+int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff, const int32_t *var, const double *sign,
+                          const double *rhs, double tol, double *z_out, double *x_out, int32_t *status_out,
+                          int32_t *has_x_out, gomilp_frontier_stats *stats);
+
 /* Library / device probes (no compute): used by the loader checks and by __graft_entry__. */
 const char *gomilp_version(void);
 int gomilp_device_count(void);

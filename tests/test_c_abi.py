@@ -1,0 +1,68 @@
+"""CPU-side checks of the drop-in boundary: libgomilp_hip.so builds/loads and exports every symbol that
+include/gomilp_lp.h declares; without a GPU the product fails loudly (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gomilp_amd import lp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gomilp_lp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gomilp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    L = lp.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(L, name), name
+    assert set(lp.EXPORTS) <= set(declared)
+
+
+def test_status_codes_match_between_header_binding_and_oracle():
+    text = open(os.path.join(ROOT, "include", "gomilp_lp.h")).read()
+    codes = dict((k, int(v)) for k, v in re.findall(r"(GOMILP_(?:OK|ERR_[A-Z0-9_]+))\s*=\s*(\d+)", text))
+    assert codes["GOMILP_OK"] == lp.OK == 0
+    for name in ("BLAND", "INFEASIBLE", "LINSOLVE", "UNBOUNDED", "SINGULAR", "ZERO_COLUMN", "ZERO_ROW", "CONDITION",
+                 "PHASE1_WRAPPED", "BAD_SHAPE", "PANIC", "DEVICE", "UNSUPPORTED"):
+        assert codes["GOMILP_ERR_" + name] == getattr(lp, "ERR_" + name)
+    from oracle import oracle as O
+    for name in ("BLAND", "INFEASIBLE", "LINSOLVE", "UNBOUNDED", "SINGULAR", "ZERO_COLUMN", "ZERO_ROW", "CONDITION",
+                 "PHASE1_WRAPPED", "BAD_SHAPE", "PANIC"):
+        assert getattr(O, "ERR_" + name) == getattr(lp, "ERR_" + name)
+
+
+def test_library_is_built_for_gfx950():
+    L = lp.lib()
+    assert L.gomilp_compiled_arch() == b"gfx950"
+    assert b"gfx950" in L.gomilp_version()
+
+
+def test_no_cpu_fallback_without_a_device():
+    L = lp.lib()
+    if L.gomilp_device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = lp.simplex([-1.0, -2.0, 0.0, 0.0], [[-1.0, 2.0, 1.0, 0.0], [3.0, 1.0, 0.0, 1.0]], [4.0, 9.0])
+    assert r.status == lp.ERR_DEVICE and r.x is None
+    with pytest.raises(RuntimeError):
+        lp.Context()
+
+
+def test_product_does_not_import_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gomilp_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("the oracle's trace", "").replace("Same fields as the oracle", ""), (dirpath, f)
+
+
+def test_bad_shapes_are_rejected_before_touching_the_device():
+    r = lp.simplex([1.0], [[1.0, 1.0]], [1.0])
+    assert r.status == lp.ERR_BAD_SHAPE

@@ -190,3 +190,51 @@ def test_full_size_properties_C2(ctx):
     ref = linprog(cc, A_ub=G, b_ub=h, method="highs")
     assert abs(ref.fun - g.z) <= 1e-9 * max(1.0, abs(g.z))
     assert g.stats["drift_xb"] < 1e-8
+
+
+def _frontier_case(m, seed, nvars):
+    c0, A0, b0 = synth.dense_lp_standard_form(m, seed)
+    root = O.simplex(c0, A0, b0, 0.0, None, fast_initial_basis=True)
+    mask = synth.integrality_mask(m, m)
+    children = synth.frontier_children(root.x, mask, nvars)
+    return c0, A0, b0, children
+
+
+def test_device_child_assembly_equals_host_assembly(ctx):
+    c0, A0, b0, children = _frontier_case(24, 3, 3)
+    root = ctx.upload(c0, A0, b0)
+    for cons in children:
+        ch = root.child(cons)
+        g = ch.solve(0.0, trace=True)
+        ch.free()
+        cc, AA, bb = O.child_standard_form(c0, A0, b0, cons)
+        o = O.simplex(cc, AA, bb, 0.0, None, fast_initial_basis=True, trace=True)
+        assert g.status == o.status
+        if o.x is not None:
+            assert _same_trace(g.pivots, o.pivots)
+            assert np.array_equal(g.x, o.x) and g.z == o.z
+    root.free()
+
+
+@pytest.mark.parametrize("workers", [1, 4])
+def test_frontier_pool_matches_oracle(workers):
+    c0, A0, b0, children = _frontier_case(128, 3, 4)
+    assert len(children) == 16
+    pool = lp.FrontierPool(workers=workers)
+    try:
+        pool.set_root(c0, A0, b0)
+        res = pool.solve(children)
+    finally:
+        pool.close()
+    n0 = A0.shape[1]
+    statuses = set()
+    for i, cons in enumerate(children):
+        cc, AA, bb = O.child_standard_form(c0, A0, b0, cons)
+        o = O.simplex(cc, AA, bb, 0.0, None, fast_initial_basis=True)
+        statuses.add(o.status)
+        assert res.status[i] == o.status, (i, res.status[i], o.status)
+        if o.status == O.OK:
+            assert res.has_x[i] == 1
+            assert np.array_equal(res.x[i], o.x[:n0]) and res.z[i] == o.z
+    assert res.stats["relaxations"] == len(children) and res.stats["workers"] == workers
+    assert O.OK in statuses
