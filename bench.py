@@ -39,6 +39,9 @@ def main() -> int:
     ap.add_argument("--sample-events", type=int, default=8, help="time the kernels of every k-th pivot with HIP events")
     ap.add_argument("--chunk", type=int, default=64)
     ap.add_argument("--refresh", type=int, default=0)
+    ap.add_argument("--frontier-vars", type=int, default=8, help="C5: 2^k children from the k highest fractional integer vars (0 = skip)")
+    ap.add_argument("--workers", type=int, default=8, help="engine contexts (HIP streams) per GPU for the frontier")
+    ap.add_argument("--frontier-cpu-children", type=int, default=8, help="children timed on the CPU oracle")
     args = ap.parse_args()
 
     import numpy as np
@@ -115,6 +118,51 @@ def main() -> int:
     else:
         dt_max, piv_all = dt, float(pivots)
 
+    # ---- C5: one 256-wide B&B wave of 512x1024 relaxations, sharded over the ranks ----
+    frontier_out = None
+    if args.frontier_vars > 0:
+        from gomilp_amd import frontier as fr
+        m5, seed5 = synth.CONFIGS["C5"]
+        c5, A5, b5 = synth.dense_lp_standard_form(m5, seed5)
+        mask5 = synth.integrality_mask(m5, m5)
+        ctx5 = lp.Context(device=local_rank)
+        root5 = ctx5.upload(c5, A5, b5).solve(0.0)          # every rank solves the root (tree.go:72), outside the timing
+        ctx5.close()
+        children = synth.frontier_children(root5.x, mask5, args.frontier_vars)
+        pool = lp.FrontierPool(device=local_rank, workers=args.workers)
+        pool.set_root(c5, A5, b5)                            # root resident on every GPU before the timed region
+        holder = {}
+
+        def solve_shard(chs):
+            r = pool.solve(chs)
+            holder["stats"] = r.stats
+            return r.status, r.z, r.x, r.has_x
+
+        dev = torch.device("cuda", local_rank)
+        fr.solve_wave(solve_shard, children[: 2 * world * args.workers], mask5, rank, world, dist, dev)  # warm-up wave
+        barrier()
+        tf0 = time.perf_counter()
+        wave = fr.solve_wave(solve_shard, children, mask5, rank, world, dist, dev)
+        barrier()
+        tf = time.perf_counter() - tf0
+        tft = torch.tensor([tf], dtype=torch.float64, device="cuda")
+        st5 = holder["stats"]
+        agg = torch.tensor([float(st5["pivots_phase1"] + st5["pivots_phase2"]), float(st5["phase1_runs"]),
+                            float(st5["bland_steps"]), float(sum(1 for s in wave["status"] if s == lp.OK))],
+                           dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(tft, op=dist.ReduceOp.MAX)
+            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        frontier_out = {
+            "workload": "C5: %d children of the %dx%d root (seed %d), %d bnb rows each, sharded child i -> rank i %% %d"
+                        % (len(children), m5, 2 * m5, seed5, args.frontier_vars, world),
+            "relaxations_per_s": len(children) / float(tft[0]), "wave_seconds": float(tft[0]), "n_gpus": world,
+            "workers_per_gpu": args.workers, "pivots": int(agg[0]), "phase1_runs": int(agg[1]), "bland_steps": int(agg[2]),
+            "feasible_children": int(agg[3]), "incumbent_z": wave["incumbent_z"], "incumbent_child": wave["incumbent_index"],
+            "collective": "2 x all_reduce(min) of one scalar per wave (RCCL)" if dist is not None else "none (1 rank)",
+        }
+        pool.close()
+
     if rank == 0:
         value = piv_all / dt_max
         nn = n - m
@@ -163,6 +211,25 @@ def main() -> int:
                 "sample": "first %d Phase-II pivots of the same %dx%d LP from the slack basis (reference algorithm: "
                           "3 fresh LU + cond estimate per pivot, gonum order); unit-column initial-basis fast path; "
                           "%.1f s wall" % (ro.pivots_phase2, m, n, tcb)}
+        if frontier_out is not None:
+            if not args.no_cpu_baseline and args.frontier_cpu_children > 0:
+                from concurrent.futures import ThreadPoolExecutor
+                from oracle import oracle as O
+                O.set_threads(1)
+                sample = children[: args.frontier_cpu_children]
+
+                def cpu_child(cons):
+                    cc, AA, bb = O.child_standard_form(c5, A5, b5, cons)
+                    return O.simplex(cc, AA, bb, 0.0, None, fast_initial_basis=True).status
+
+                tcb = time.perf_counter()
+                with ThreadPoolExecutor(max_workers=len(sample)) as ex:
+                    list(ex.map(cpu_child, sample))
+                tcb = time.perf_counter() - tcb
+                frontier_out["cpu_baseline"] = {"value": len(sample) / tcb, "unit": "relaxations/s", "cores": len(sample),
+                                                "kind": "port", "sample": "first %d children of the same wave, one oracle "
+                                                "solve per host thread (mirrors Problem.SetWorkers), %.1f s wall" % (len(sample), tcb)}
+            out["frontier"] = frontier_out
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1,0 +1,78 @@
+"""Multi-GPU sharding of one branch-and-bound wave.
+
+The frontier of an enumeration tree is a set of independent LP relaxations that share the root data
+(/root/reference/subproblem.go:20-29); the reference spreads them over goroutine workers
+(/root/reference/tree.go:98-100,196-205).  Here: one process per GPU, child i of the wave goes to rank i % world
+(round-robin keeps the per-GPU batches equal and the result order independent of the GPU count), every rank
+solves its shard on its own GPU through gomilp_frontier_solve, and the only exchange is the incumbent bound:
+one all-reduce(min) per wave (RCCL over xGMI on the GPU box, gloo in the CPU tests).  The bound is used exactly
+like /root/reference/tree.go:228-230 uses it — after the solves, for pruning — never inside a solve.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+BIG_INDEX = 2 ** 62
+
+
+def shard_indices(count: int, rank: int, world: int) -> List[int]:
+    """Children owned by `rank`: i % world == rank."""
+    return list(range(rank, count, world))
+
+
+def is_all_integer(v: float) -> bool:
+    """tree.go:290-297: k == math.Trunc(k) (true for +-Inf, false for NaN)."""
+    if math.isnan(v):
+        return False
+    if math.isinf(v):
+        return True
+    return v == math.trunc(v)
+
+
+def feasible_for_ip(integrality: Sequence[bool], x: Sequence[float]) -> bool:
+    """tree.go:276-288."""
+    return all(is_all_integer(float(x[j])) for j in range(len(integrality)) if integrality[j])
+
+
+def local_incumbent(indices: Sequence[int], status, z, x, has_x, integrality) -> Tuple[float, int]:
+    """Best integer-feasible relaxation of this rank's shard: (z, global child index), (+inf, BIG_INDEX) if none.
+    Ties on z go to the smaller child index = the one the reference's FIFO order would have met first."""
+    best_z, best_i = math.inf, BIG_INDEX
+    for local, gi in enumerate(indices):
+        if status[local] != 0 or not has_x[local]:
+            continue
+        if not feasible_for_ip(integrality, x[local]):
+            continue
+        if z[local] < best_z or (z[local] == best_z and gi < best_i):
+            best_z, best_i = float(z[local]), gi
+    return best_z, best_i
+
+
+def allreduce_incumbent(z_local: float, idx_local: int, dist=None, device=None) -> Tuple[float, int]:
+    """Global (min z, then min index).  Two scalar all-reduce(min): 8 bytes each, latency-bound."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return z_local, idx_local
+    import torch
+    tz = torch.tensor([z_local], dtype=torch.float64, device=device)
+    dist.all_reduce(tz, op=dist.ReduceOp.MIN)
+    zg = float(tz[0])
+    ti = torch.tensor([idx_local if z_local == zg else BIG_INDEX], dtype=torch.int64, device=device)
+    dist.all_reduce(ti, op=dist.ReduceOp.MIN)
+    return zg, int(ti[0])
+
+
+def solve_wave(solve_shard: Callable[[List[list]], tuple], children: List[list], integrality: Sequence[bool],
+               rank: int = 0, world: int = 1, dist=None, device=None) -> dict:
+    """One wave: shard -> solve the shard -> incumbent all-reduce.
+
+    `solve_shard(list_of_children)` returns (status, z, x, has_x) arrays for that list (FrontierPool.solve on
+    the GPU box; a stub in the gloo tests)."""
+    mine = shard_indices(len(children), rank, world)
+    status, z, x, has_x = solve_shard([children[i] for i in mine])
+    zl, il = local_incumbent(mine, status, z, x, has_x, integrality)
+    zg, ig = allreduce_incumbent(zl, il, dist, device)
+    return {"indices": mine, "status": status, "z": z, "x": x, "has_x": has_x, "incumbent_z": zg, "incumbent_index": ig,
+            "local_incumbent_z": zl}

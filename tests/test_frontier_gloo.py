@@ -1,0 +1,109 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the wave sharding + incumbent all-reduce (no GPU needed: the
+per-shard solver is the CPU oracle here, standing in for FrontierPool.solve)."""
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gomilp_amd import frontier, synth
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _case():
+    m, seed = 24, 3
+    c0, A0, b0 = synth.dense_lp_standard_form(m, seed)
+    root = O.simplex(c0, A0, b0, 0.0, None, fast_initial_basis=True)
+    mask = synth.integrality_mask(m, m)
+    children = synth.frontier_children(root.x, mask, 3)
+    return c0, A0, b0, mask, children
+
+
+def _oracle_shard_solver(c0, A0, b0):
+    n0 = A0.shape[1]
+
+    def solve(chs):
+        status = np.zeros(len(chs), dtype=np.int32)
+        z = np.full(len(chs), math.nan)
+        x = np.zeros((len(chs), n0))
+        has_x = np.zeros(len(chs), dtype=np.int32)
+        for i, cons in enumerate(chs):
+            cc, AA, bb = O.child_standard_form(c0, A0, b0, cons)
+            r = O.simplex(cc, AA, bb, 0.0, None, fast_initial_basis=True)
+            status[i], z[i] = r.status, r.z
+            if r.x is not None:
+                x[i], has_x[i] = r.x[:n0], 1
+        return status, z, x, has_x
+    return solve
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c0, A0, b0, mask, children = _case()
+    res = frontier.solve_wave(_oracle_shard_solver(c0, A0, b0), children, mask, rank, world, dist, torch.device("cpu"))
+    out.put((rank, res["indices"], res["incumbent_z"], res["incumbent_index"], res["local_incumbent_z"],
+             [int(s) for s in res["status"]], [float(v) for v in res["z"]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_indices_partition():
+    for count in (0, 1, 7, 256):
+        for world in (1, 2, 3, 8):
+            seen = sorted(i for r in range(world) for i in frontier.shard_indices(count, r, world))
+            assert seen == list(range(count))
+    assert frontier.shard_indices(256, 3, 8)[:3] == [3, 11, 19] and len(frontier.shard_indices(256, 3, 8)) == 32
+
+
+def test_integrality_semantics_follow_tree_go():
+    assert frontier.is_all_integer(2.0) and frontier.is_all_integer(-0.0) and frontier.is_all_integer(math.inf)
+    assert not frontier.is_all_integer(math.nan) and not frontier.is_all_integer(0.6666666666666666)
+    assert frontier.feasible_for_ip([False, True], [0.5, 3.0]) and not frontier.feasible_for_ip([True, True], [0.5, 3.0])
+
+
+def test_two_rank_gloo_wave_matches_single_rank():
+    c0, A0, b0, mask, children = _case()
+    single = frontier.solve_wave(_oracle_shard_solver(c0, A0, b0), children, mask)
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort()
+    # both ranks agree on the global incumbent, and it is the single-process answer
+    assert got[0][2] == got[1][2] == single["incumbent_z"]
+    assert got[0][3] == got[1][3] == single["incumbent_index"]
+    assert min(got[0][4], got[1][4]) == single["incumbent_z"]
+    # the shards tile the wave and reproduce the single-rank per-child results bit for bit
+    merged_status, merged_z = {}, {}
+    for rank, idx, _, _, _, st, zz in got:
+        assert idx == frontier.shard_indices(len(children), rank, 2)
+        for i, s, v in zip(idx, st, zz):
+            merged_status[i], merged_z[i] = s, v
+    assert sorted(merged_status) == list(range(len(children)))
+    for i in range(len(children)):
+        assert merged_status[i] == single["status"][i]
+        assert (math.isnan(merged_z[i]) and math.isnan(single["z"][i])) or merged_z[i] == single["z"][i]
