@@ -38,6 +38,12 @@ struct DevState {
     int32_t ent_prev;  // variable entering in the pivot being committed
     int32_t lea;       // variable leaving in the pivot being committed
     int32_t pad2;
+    // single-kernel tableau pipeline: kernel t reads slot (t & 1) and writes slot ((t + 1) & 1), so a workgroup
+    // that starts late never sees values produced by its own launch
+    int32_t nq[2];     // entering position chosen for the next pivot
+    int32_t nent[2];   // its variable id
+    double nrq[2];     // its reduced cost
+    int64_t stop_at;   // launches with index >= stop_at are no-ops (set by launch t to t + 1)
 };
 
 struct DevPivot {  // mirrors gomilp_pivot
@@ -68,6 +74,29 @@ struct LPArgs {
     unsigned int *pi_price;
     unsigned long long *pk_ratio;
     unsigned int *pi_ratio;
+    unsigned int *pv_price;        // fused pipeline payloads: variable id of the best column of each workgroup
+    double *pd_ratio;              //   d'_i of the best row of each workgroup
+    unsigned int *pb_ratio;        //   basic[i] of the best row of each workgroup
+    DevState *st;
+    DevPivot *trace;
+    int64_t trace_cap;
+};
+
+// Arguments of the single-kernel tableau pivot (tableau_kernels.hip).
+struct TabArgs {
+    int32_t m, nn;     // rows, nonbasic positions (tableau columns)
+    int32_t ldt;       // padded row length of T in doubles (multiple of 128), zero padded
+    int32_t phase;
+    double tol;
+    const double *T_cur;   // m x ldt : B^-1 A_N, column j = nonbasic position j
+    double *T_next;
+    const double *r_in;    // ldt : reduced costs by position (padding = 0, ignored)
+    double *r_out;
+    double *xb, *dvec, *move;
+    int32_t *basic, *nonbasic;
+    unsigned long long *pk_ratio;
+    unsigned int *pi_ratio, *pb_ratio;
+    double *pd_ratio, *px_ratio;
     DevState *st;
     DevPivot *trace;
     int64_t trace_cap;

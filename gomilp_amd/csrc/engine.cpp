@@ -2,103 +2,9 @@
 // (vendor/gonum.org/v1/gonum/optimize/convex/lp/simplex.go:93-302); all O(m^2)/O(m*n) work is
 // enqueued as gfx950 kernels (simplex_kernels.hip).  No CPU fallback exists: any HIP failure
 // surfaces as GOMILP_ERR_DEVICE.
-#include "engine.hpp"
-
-#include <math.h>
-#include <string.h>
-
-#include <algorithm>
-#include <chrono>
-#include <limits>
+#include "engine_work.hpp"
 
 namespace gomilp {
-
-namespace {
-
-double now_s() {
-    using namespace std::chrono;
-    return duration<double>(steady_clock::now().time_since_epoch()).count();
-}
-
-#define HIP_TRY(expr)                                   \
-    do {                                                \
-        hipError_t _e = (expr);                         \
-        if (_e != hipSuccess) return GOMILP_ERR_DEVICE; \
-    } while (0)
-
-// floats.MinIdx (floats/floats.go:458-474)
-int64_t min_idx(const double *s, int64_t n) {
-    double mn = std::numeric_limits<double>::quiet_NaN();
-    int64_t ind = 0;
-    for (int64_t i = 0; i < n; i++) {
-        const double v = s[i];
-        if (v != v) continue;
-        if (v < mn || mn != mn) { mn = v; ind = i; }
-    }
-    return ind;
-}
-
-// f64.DotUnitary (internal/asm/f64/dot_amd64.s:43-92): 4 interleaved partial sums, tail into lane 0.
-// Used for z = cb.xb (simplex.go:296) so the objective is bit-identical given identical xb.
-double dot_unitary(const double *x, const double *y, int64_t n) {
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int64_t i = 0;
-    for (; i + 4 <= n; i += 4) {
-        s0 += x[i] * y[i];
-        s1 += x[i + 1] * y[i + 1];
-        s2 += x[i + 2] * y[i + 2];
-        s3 += x[i + 3] * y[i + 3];
-    }
-    for (; i < n; i++) s0 += x[i] * y[i];
-    return (s0 + s2) + (s1 + s3);
-}
-
-template <typename T>
-hipError_t dmalloc(T **p, size_t count) {
-    return hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T));
-}
-
-}  // namespace
-
-struct Engine::Work {
-    int cap_m = 0, cap_ld = 0, cap_cols = 0;
-    double *binv[2] = {nullptr, nullptr};
-    double *yb[2] = {nullptr, nullptr};
-    double *xb = nullptr, *dvec = nullptr, *move = nullptr, *rvec = nullptr, *yscratch = nullptr, *W = nullptr;
-    int32_t *basic = nullptr, *nonbasic = nullptr, *lpos = nullptr, *rowstep = nullptr, *rho = nullptr;
-    unsigned long long *pk_price = nullptr, *pk_ratio = nullptr, *lpk[2] = {nullptr, nullptr};
-    unsigned int *pi_price = nullptr, *pi_ratio = nullptr, *lpl[2] = {nullptr, nullptr}, *lpr[2] = {nullptr, nullptr};
-    DevState *st = nullptr;
-    DevState *st_host = nullptr;  // pinned
-    DevPivot *trace = nullptr;
-    int64_t trace_cap = 0;
-    double *h_W = nullptr;  // pinned, cap_m * cap_ld
-    double *h_vec = nullptr;  // pinned, max(cap_ld, cap_cols)
-    int32_t *h_idx = nullptr; // pinned, max(cap_m, cap_cols)
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    std::vector<hipEvent_t> sample_ev;  // pairs around sampled kernels
-
-    void release() {
-        for (auto &p : binv) { if (p) hipFree(p); p = nullptr; }
-        for (double **p : {&xb, &yb[0], &yb[1], &dvec, &move, &rvec, &yscratch, &W}) { if (*p) hipFree(*p); *p = nullptr; }
-        for (int32_t **p : {&basic, &nonbasic, &lpos, &rowstep, &rho}) { if (*p) hipFree(*p); *p = nullptr; }
-        if (h_W) hipHostFree(h_W); h_W = nullptr;
-        if (h_vec) hipHostFree(h_vec); h_vec = nullptr;
-        if (h_idx) hipHostFree(h_idx); h_idx = nullptr;
-        cap_m = cap_ld = cap_cols = 0;
-    }
-    void release_all() {
-        release();
-        for (auto **p : {&pk_price, &pk_ratio, &lpk[0], &lpk[1]}) { if (*p) hipFree(*p); *p = nullptr; }
-        for (auto **p : {&pi_price, &pi_ratio, &lpl[0], &lpl[1], &lpr[0], &lpr[1]}) { if (*p) hipFree(*p); *p = nullptr; }
-        if (st) hipFree(st); st = nullptr;
-        if (st_host) hipHostFree(st_host); st_host = nullptr;
-        if (trace) hipFree(trace); trace = nullptr;
-        for (auto &e : ev) { if (e) hipEventDestroy(e); e = nullptr; }
-        for (auto &e : sample_ev) hipEventDestroy(e);
-        sample_ev.clear();
-    }
-};
 
 int device_count() {
     int n = 0;
@@ -129,6 +35,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "sample_events") sample_events_ = v < 0 ? 0 : v;
     else if (key == "fused") fused_ = v ? 1 : 0;
     else if (key == "lu_blocked") lu_blocked_ = v ? 1 : 0;
+    else if (key == "tableau") tableau_ = v ? 1 : 0;
     else return GOMILP_ERR_BAD_SHAPE;
     return GOMILP_OK;
 }
@@ -140,6 +47,7 @@ int Engine::ensure_work(int m, int ncols) {
     if (!w.st) {
         HIP_TRY(dmalloc(&w.pk_price, kMaxPartials)); HIP_TRY(dmalloc(&w.pk_ratio, kMaxPartials));
         HIP_TRY(dmalloc(&w.pi_price, kMaxPartials)); HIP_TRY(dmalloc(&w.pi_ratio, kMaxPartials));
+        HIP_TRY(dmalloc(&w.pv_price, kMaxPartials)); HIP_TRY(dmalloc(&w.pb_ratio, kMaxPartials)); HIP_TRY(dmalloc(&w.pd_ratio, kMaxPartials)); HIP_TRY(dmalloc(&w.px_ratio, kMaxPartials));
         for (int t = 0; t < 2; t++) {
             HIP_TRY(dmalloc(&w.lpk[t], kMaxPartials)); HIP_TRY(dmalloc(&w.lpl[t], kMaxPartials)); HIP_TRY(dmalloc(&w.lpr[t], kMaxPartials));
         }
@@ -326,6 +234,7 @@ LPArgs Engine::make_args(const Problem &P, int phase, double tol, int nn, const 
     a.xb = w.xb; a.y = w.yb[ycur_]; a.dvec = w.dvec; a.move = w.move; a.rvec = w.rvec;
     a.basic = w.basic; a.nonbasic = w.nonbasic;
     a.pk_price = w.pk_price; a.pi_price = w.pi_price; a.pk_ratio = w.pk_ratio; a.pi_ratio = w.pi_ratio;
+    a.pv_price = w.pv_price; a.pd_ratio = w.pd_ratio; a.pb_ratio = w.pb_ratio;
     a.st = w.st;
     a.trace = trace_on_ ? w.trace : nullptr;
     a.trace_cap = w.trace_cap;
@@ -728,6 +637,29 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     HIP_TRY(hipMemcpyAsync(w.xb, xb.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
 
+    // pipeline choice: the explicit tableau moves 16*m*(n-m) bytes per pivot in one launch, the revised form
+    // 8*[m(n-m) + 2m^2] in two: the tableau wins while n - m < 2m
+    const int nn_max = n + 1 - m;
+    const bool use_tab = tableau_ && (n - m) < 2 * m && (size_t)tab_ld(nn_max) * sizeof(double) <= 64 * 1024;
+    st->reserved = use_tab ? 2 : ((fused_ && fused_supported(P.ld)) ? 1 : 0);
+    int loop_rc = GOMILP_OK;
+    if (use_tab) {
+        const int ldt = tab_ld(nn_max);
+        if (w.cap_T < (size_t)m * ldt || w.cap_ldt < ldt) {
+            for (double **pp : {&w.T[0], &w.T[1], &w.R[0], &w.R[1], &w.tscratch}) { if (*pp) hipFree(*pp); *pp = nullptr; }
+            if (w.srcpos) hipFree(w.srcpos); w.srcpos = nullptr;
+            const size_t cap = std::max(w.cap_T, (size_t)m * ldt);
+            const int cl = std::max(w.cap_ldt, ldt);
+            HIP_TRY(dmalloc(&w.T[0], cap)); HIP_TRY(dmalloc(&w.T[1], cap));
+            HIP_TRY(dmalloc(&w.R[0], (size_t)cl)); HIP_TRY(dmalloc(&w.R[1], (size_t)cl));
+            HIP_TRY(dmalloc(&w.tscratch, (size_t)64 * cl)); HIP_TRY(dmalloc(&w.srcpos, (size_t)cl));
+            w.cap_T = cap; w.cap_ldt = cl;
+        }
+        HIP_TRY(hipMemsetAsync(w.R[0], 0, (size_t)w.cap_ldt * sizeof(double), stream_));
+        HIP_TRY(hipMemsetAsync(w.R[1], 0, (size_t)w.cap_ldt * sizeof(double), stream_));
+        rc = solve_tableau(P, tol, basic, rho, xb, feasible, st, &loop_rc);
+        if (rc != GOMILP_OK) return finish(rc);
+    } else {
     std::vector<int32_t> nonbasic;
     auto build_nonbasic = [&](int ncols) {  // simplex.go:174-184: ascending ids not in the basis
         std::vector<char> inb(ncols, 0);
@@ -826,7 +758,8 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
         launch_y_from_binv(w.binv[cur_], P.ld, m, P.dc, w.basic, w.yscratch, w.yb[ycur_], stream_);
         launches_ += 2;
     }
-    int loop_rc = run_loop(P, 2, tol, (int)nonbasic.size(), P.dc, st);
+    loop_rc = run_loop(P, 2, tol, (int)nonbasic.size(), P.dc, st);
+    }  // revised-simplex pipelines
     if (loop_rc == GOMILP_ERR_DEVICE) return finish(loop_rc);
     if (loop_rc == GOMILP_ERR_UNBOUNDED) { *opt_f = -inf; return finish(loop_rc); }  // :261-263, :272-274
 

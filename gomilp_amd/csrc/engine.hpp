@@ -49,6 +49,13 @@ class Engine {
     LPArgs make_args(const Problem &P, int phase, double tol, int nn, const double *cost);
     int run_loop(const Problem &P, int phase, double tol, int nn, const double *cost, gomilp_lp_stats *st);
     int run_loop_fused(const Problem &P, int phase, double tol, int nn, const double *cost, gomilp_lp_stats *st);
+    int run_loop_tab(const Problem &P, int phase, double tol, int nn, gomilp_lp_stats *st);
+    int host_bland_tab(const Problem &P, int phase, double tol, int nn, gomilp_lp_stats *st, int *par_out);
+    TabArgs make_tab_args(const Problem &P, int phase, double tol, int nn);
+    int tab_forced_pivot(const Problem &P, int phase, double tol, int nn, int q, int ent, double rq, int p, double dp, double xp,
+                         int lea, int flags, long long t);
+    int solve_tableau(const Problem &P, double tol, std::vector<int32_t> &basic, const std::vector<int32_t> &rho,
+                      std::vector<double> &xb, bool feasible, gomilp_lp_stats *st, int *loop_rc);
     void account_samples(gomilp_lp_stats *st, const std::vector<int64_t> &sample_t, int64_t executed, int nk);
     int host_bland(const Problem &P, LPArgs &a, gomilp_lp_stats *st);
     int refresh_xb_y(const Problem &P, const double *cost);
@@ -62,11 +69,12 @@ class Engine {
     std::vector<std::unique_ptr<Problem>> problems_;
     std::unique_ptr<Work> w_;
     // knobs
-    int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 1;
+    int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 1, tableau_ = 1;
     // per-solve state
     int cur_ = 0;   // which Binv buffer is current
     int ycur_ = 0;  // which y buffer is current
-    int grid_ratio_ = 1;  // workgroups of the last ratio-test kernel (partials to reduce)
+    int grid_ratio_ = 1;
+    int tcur_ = 0, rcur_ = 0, ldt_ = 0;  // tableau pipeline: current T / r buffer, row length of T  // workgroups of the last ratio-test kernel (partials to reduce)
     int64_t launches_ = 0;
     double fs_device_ = 0, fs_host_ = 0;
     std::vector<gomilp_pivot> last_trace_;
@@ -87,6 +95,17 @@ bool fused_supported(int ld);
 int launch_price_fused(const LPArgs &a, const double *y_in, double *y_out, int pending, int nparts_ratio, hipStream_t s,
                        hipEvent_t e0, hipEvent_t e1);
 int launch_update_ftran_fused(const LPArgs &a, int pending, int nparts_price, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+// tableau_kernels.hip
+int tab_ld(int nn);
+int launch_tableau_pivot(const TabArgs &a, int flags, int nparts, long long t, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+void launch_tab_gather(const double *At, int ld, int m, int nn, const int32_t *nonbasic, const int32_t *rho, double *T, int ldt,
+                       hipStream_t s);
+void launch_tab_permute_cols(const double *Tin, int ld_in, double *Tout, int ld_out, int m, int nn_out, const int32_t *srcpos,
+                             hipStream_t s);
+int tab_r_chunks(int m);
+void launch_tab_r(const double *T, int ldt, int m, int nn, const double *cost, const int32_t *basic, const int32_t *nonbasic,
+                  double *scratch, double *r, hipStream_t s);
+void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb, double *dvec, double *move, hipStream_t s);
 void launch_transpose_in(const double *A, int64_t lda, int m, int n, double *At, int ld, hipStream_t s);
 void launch_col_stats(const double *At, int ld, int m, int n, int32_t *nnz, int32_t *lastrow, int32_t *allone,
                       int32_t *rowflag, hipStream_t s);

@@ -1,0 +1,319 @@
+// Host control of the single-kernel tableau pipeline (tableau_kernels.hip).  Same reference control flow as
+// engine.cpp (simplex.go:93-302); only the per-pivot device work differs: T = B^-1 A_N is kept explicitly and
+// one launch applies a whole pivot.
+#include "engine_work.hpp"
+
+namespace gomilp {
+
+TabArgs Engine::make_tab_args(const Problem &P, int phase, double tol, int nn) {
+    Work &w = *w_;
+    TabArgs a;
+    memset(&a, 0, sizeof(a));
+    a.m = P.m; a.nn = nn; a.ldt = ldt_; a.phase = phase; a.tol = tol;
+    a.T_cur = w.T[tcur_]; a.T_next = w.T[tcur_ ^ 1];
+    a.r_in = w.R[rcur_]; a.r_out = w.R[rcur_ ^ 1];
+    a.xb = w.xb; a.dvec = w.dvec; a.move = w.move;
+    a.basic = w.basic; a.nonbasic = w.nonbasic;
+    a.pk_ratio = w.pk_ratio; a.pi_ratio = w.pi_ratio; a.pb_ratio = w.pb_ratio; a.pd_ratio = w.pd_ratio; a.px_ratio = w.px_ratio;
+    a.st = w.st;
+    a.trace = trace_on_ ? w.trace : nullptr;
+    a.trace_cap = w.trace_cap;
+    return a;
+}
+
+// One pivot chosen by the host (Phase-I set-up, artificial exchange, Bland step): entering position q (variable ent,
+// reduced cost rq), leaving position p with pivot element dp, x_B[p] = xp, leaving variable lea.  dvec must already hold
+// column q of the current T (launch_tab_column).  The launch is kernel `t` of a fresh segment.
+int Engine::tab_forced_pivot(const Problem &P, int phase, double tol, int nn, int q, int ent, double rq, int p, double dp,
+                             double xp, int lea, int flags, long long t) {
+    Work &w = *w_;
+    DevState &hs = *w.st_host;
+    const int par = (int)(t & 1);
+    hs.done = 0; hs.status = ST_RUNNING; hs.stop_at = std::numeric_limits<int64_t>::max();
+    hs.nq[par] = q; hs.nent[par] = ent; hs.nrq[par] = rq;
+    sync_state_to_device();
+    // fabricate the single ratio partial the kernel will reduce
+    struct { unsigned long long k; unsigned int i, b; double d, x; } part;
+    part.k = 0xBFF0000000000000ull;  // ordkey(1.0): any finite positive ratio
+    part.i = (unsigned int)p; part.b = (unsigned int)lea; part.d = dp; part.x = xp;
+    HIP_TRY(hipMemcpyAsync(w.pk_ratio, &part.k, sizeof(part.k), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(w.pi_ratio, &part.i, sizeof(part.i), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(w.pb_ratio, &part.b, sizeof(part.b), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(w.pd_ratio, &part.d, sizeof(part.d), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(w.px_ratio, &part.x, sizeof(part.x), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));  // `part` lives on this stack frame
+    TabArgs a = make_tab_args(P, phase, tol, nn);
+    grid_ratio_ = launch_tableau_pivot(a, flags | 1 | 2, 1, t, stream_, nullptr, nullptr);
+    launches_++;
+    tcur_ ^= 1;
+    rcur_ ^= 1;
+    return GOMILP_OK;
+}
+
+// replaceBland (simplex.go:347-383) on the tableau: a candidate's FTRAN is just its column of T.
+// On success the Bland pivot has been enqueued as kernel 0 of a new segment.
+int Engine::host_bland_tab(const Problem &P, int phase, double tol, int nn, gomilp_lp_stats *st, int *) {
+    Work &w = *w_;
+    const int m = P.m;
+    std::vector<double> r(nn), move(m), xb(m), dv(m);
+    std::vector<int32_t> bas(m);
+    HIP_TRY(hipMemcpyAsync(w.h_vec, w.R[rcur_], (size_t)nn * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    std::vector<double> rraw(w.h_vec, w.h_vec + nn);
+    for (int j = 0; j < nn; j++) { r[j] = rraw[j]; if (fabs(r[j]) < 1e-13) r[j] = 0; }  // rRoundTol, :252-256
+    HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    for (int i = 0; i < m; i++) { xb[i] = w.h_vec[i]; bas[i] = w.h_idx[i]; }
+    for (int i = 0; i < nn; i++) {
+        if (r[i] > -1e-14) continue;  // blandNegTol, :352
+        launch_tab_column(w.T[tcur_], ldt_, m, i, w.xb, w.dvec, w.move, stream_);
+        launches_++;
+        HIP_TRY(hipMemcpyAsync(w.h_vec, w.move, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        for (int k = 0; k < m; k++) move[k] = w.h_vec[k];
+        HIP_TRY(hipMemcpyAsync(w.h_vec, w.dvec, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        for (int k = 0; k < m; k++) dv[k] = w.h_vec[k];
+        int64_t replace = min_idx(move.data(), m);
+        if (move[replace] == std::numeric_limits<double>::infinity()) return GOMILP_ERR_UNBOUNDED;  // computeMove :328
+        if (!(fabs(move[replace]) > 1e-12)) {  // blandZeroTol, :362
+            replace = -1;
+            for (int rp = 0; rp < m; rp++)
+                if (!(move[rp] > 1e-12)) { replace = rp; break; }  // :368-379 (cond guard: DESIGN.md §3)
+            if (replace < 0) continue;
+        }
+        int32_t ent = 0;
+        HIP_TRY(hipMemcpy(&ent, w.nonbasic + i, sizeof(int32_t), hipMemcpyDeviceToHost));
+        int rc = tab_forced_pivot(P, phase, tol, nn, i, ent, rraw[i], (int)replace, dv[replace], xb[replace], bas[replace], 8, 0);
+        if (rc != GOMILP_OK) return rc;
+        if (st) st->bland_steps++;
+        return GOMILP_OK;
+    }
+    return GOMILP_ERR_BLAND;
+}
+
+// Pivot loop, one launch per pivot.  Kernel index t inside a segment: slot parity t & 1; a launch that applies a
+// pivot reads T[(c0+a)&1], r[(r0+a)&1] and writes the other copies, a = pivots applied so far in the segment.
+int Engine::run_loop_tab(const Problem &P, int phase, double tol, int nn, gomilp_lp_stats *st) {
+    Work &w = *w_;
+    DevState &hs = *w.st_host;
+    hs.done = 0; hs.status = ST_RUNNING; hs.pivots = 0; hs.q = hs.p = -1; hs.rq = hs.dp = hs.mv = 0;
+    hs.max_pivots = 0; hs.lu_singular = 0;
+    hs.stop_at = std::numeric_limits<int64_t>::max();
+    sync_state_to_device();
+    HIP_TRY(hipEventRecord(w.ev[0], stream_));
+    int ret = GOMILP_OK;
+    const bool sampling = sample_events_ > 0;
+    int c0 = tcur_, r0 = rcur_;
+    long long tseg = 0;          // next kernel index in the segment
+    int64_t applied = 0;         // pending launches enqueued in the segment
+    int64_t seg_start = 0;       // pivots committed when the segment started
+    bool first_pending = false;  // the segment started with a forced (already enqueued) pivot
+    for (;;) {
+        const int64_t before = hs.pivots;
+        std::vector<int64_t> sample_t;
+        int64_t nlaunch = chunk_;
+        if (max_pivots_ > 0) nlaunch = std::min<int64_t>(nlaunch, std::max<int64_t>(1, max_pivots_ - hs.pivots + 1));
+        const int64_t applied_before = applied;
+        for (int64_t t = 0; t < nlaunch; t++, tseg++) {
+            const int pending = (tseg > 0 || first_pending) ? 1 : 0;
+            TabArgs a = make_tab_args(P, phase, tol, nn);
+            a.T_cur = w.T[(c0 + applied) & 1]; a.T_next = w.T[(c0 + applied + 1) & 1];
+            a.r_in = w.R[(r0 + applied) & 1]; a.r_out = w.R[(r0 + applied + 1) & 1];
+            const bool sample = sampling && pending && ((before + t) % sample_events_ == 0);
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (sample) {
+                const size_t b0 = sample_t.size() * 6;
+                while (w.sample_ev.size() < b0 + 6) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); w.sample_ev.push_back(ev); }
+                e0 = w.sample_ev[b0]; e1 = w.sample_ev[b0 + 1];
+                sample_t.push_back(applied - applied_before);
+            }
+            grid_ratio_ = launch_tableau_pivot(a, pending, grid_ratio_, tseg, stream_, e0, e1);
+            launches_++;
+            if (pending) applied++;
+        }
+        HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(hipGetLastError());
+        const int64_t executed = hs.pivots - before;
+        if (st) {
+            for (size_t s = 0; s < sample_t.size(); s++) {
+                if (sample_t[s] >= executed) break;
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, w.sample_ev[s * 6], w.sample_ev[s * 6 + 1]) != hipSuccess) continue;
+                st->pivot_kernel_seconds[2] += ms * 1e-3;
+                st->pivot_kernel_seconds[3] += 1.0;
+            }
+        }
+        const int64_t T = hs.pivots - seg_start;  // pivots applied and committed in this segment
+        if (!hs.done) {
+            if (max_pivots_ > 0 && hs.pivots >= max_pivots_) { tcur_ = (c0 + T) & 1; rcur_ = (r0 + T) & 1; ret = GOMILP_ERR_UNSUPPORTED; break; }
+            continue;
+        }
+        tcur_ = (int)((c0 + T) & 1);
+        rcur_ = (int)((r0 + T) & 1);
+        if (hs.status == ST_OPTIMAL) break;
+        if (hs.status == ST_UNBOUNDED) { ret = GOMILP_ERR_UNBOUNDED; break; }
+        if (hs.status == ST_NEED_BLAND) {
+            int rc = host_bland_tab(P, phase, tol, nn, st, nullptr);  // enqueues the Bland pivot as kernel 0 of a new segment
+            if (rc != GOMILP_OK) { ret = rc; break; }
+            // tab_forced_pivot flipped tcur_/rcur_ for the pivot it enqueued; the new segment starts BEFORE that pivot
+            c0 = tcur_ ^ 1; r0 = rcur_ ^ 1;
+            seg_start = hs.pivots; tseg = 1; applied = 1; first_pending = true;
+            continue;
+        }
+        ret = GOMILP_ERR_DEVICE;
+        break;
+    }
+    HIP_TRY(hipEventRecord(w.ev[1], stream_));
+    HIP_TRY(hipEventSynchronize(w.ev[1]));
+    float ms = 0;
+    hipEventElapsedTime(&ms, w.ev[0], w.ev[1]);
+    if (st) {
+        st->seconds_pivot_loop += ms * 1e-3;
+        if (phase == 1) st->pivots_phase1 += hs.pivots; else st->pivots_phase2 += hs.pivots;
+    }
+    return ret;
+}
+
+// Phase I / Phase II on the tableau pipeline.  Called by Engine::solve after the initial (slack) basis is known.
+// On return `basic` / `xb` hold the final basis positions and updated x_B; *loop_rc is the Phase-II loop result.
+int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &basic, const std::vector<int32_t> &rho,
+                          std::vector<double> &xb, bool feasible, gomilp_lp_stats *st, int *loop_rc) {
+    Work &w = *w_;
+    const int m = P.m, n = P.n;
+    int rc;
+    std::vector<int32_t> nonbasic;
+    auto build_nonbasic = [&](int ncols) {
+        std::vector<char> inb(ncols, 0);
+        for (int i = 0; i < m; i++) inb[basic[i]] = 1;
+        nonbasic.clear();
+        for (int j = 0; j < ncols; j++) if (!inb[j]) nonbasic.push_back(j);
+    };
+    tcur_ = 0; rcur_ = 0;
+    HIP_TRY(hipMemcpyAsync(w.rho, rho.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemsetAsync(w.xb, 0, (size_t)P.ld * sizeof(double), stream_));
+    HIP_TRY(hipMemcpyAsync(w.xb, xb.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    auto set_up_T = [&](int nn) -> int {  // T = B^-1 A_N for the slack basis (B^-1 = permutation rho)
+        ldt_ = tab_ld(nn);
+        HIP_TRY(hipMemsetAsync(w.T[0], 0, (size_t)m * ldt_ * sizeof(double), stream_));
+        launch_tab_gather(P.dAt, P.ld, m, nn, w.nonbasic, w.rho, w.T[0], ldt_, stream_);
+        launches_++;
+        return GOMILP_OK;
+    };
+    int nn;
+    if (!feasible) {
+        // ---- Phase I (simplex.go:529-606) ----
+        st->phase1_used = 1;
+        const int64_t minidx = min_idx(xb.data(), m);
+        std::vector<double> art(P.ld, 0.0);
+        for (int k = 0; k < m; k++) art[k] = P.hb[k];
+        for (int i = 0; i < m; i++) { if (i == minidx) continue; art[rho[i]] = -1 * 1.0 + art[rho[i]]; }  // floats.Sub, :536-542
+        bool art_zero = true;
+        for (int k = 0; k < m; k++) if (art[k] != 0) { art_zero = false; break; }
+        if (art_zero) { st->wrapped_status = GOMILP_ERR_ZERO_COLUMN; return GOMILP_ERR_PHASE1_WRAPPED; }
+        HIP_TRY(hipMemcpyAsync(P.dAt + (size_t)n * P.ld, art.data(), (size_t)P.ld * sizeof(double), hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        // tableau over the n+1-m columns that are nonbasic w.r.t. the slack basis (the artificial is the last one),
+        // then one forced pivot brings the artificial into position minidx (the basis of simplex.go:551)
+        build_nonbasic(n + 1);
+        nn = (int)nonbasic.size();
+        if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return rc;
+        if ((rc = set_up_T(nn)) != GOMILP_OK) return rc;
+        const int qa = nn - 1;  // position of the artificial
+        launch_tab_column(w.T[0], ldt_, m, qa, w.xb, w.dvec, w.move, stream_);
+        launches_++;
+        const double dp = art[rho[minidx]];
+        const int slack = basic[minidx];
+        if ((rc = tab_forced_pivot(P, 1, 1e-10, nn, qa, n, 0.0, (int)minidx, dp, xb[minidx], slack, 4, 0)) != GOMILP_OK) return rc;
+        basic[minidx] = n;
+        nonbasic[qa] = slack;  // ascending order is preserved: every structural id < slack id < n
+        if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return rc;
+        launch_tab_r(w.T[tcur_], ldt_, m, nn, P.dc1, w.basic, w.nonbasic, w.tscratch, w.R[rcur_], stream_);
+        launches_ += 2;
+        HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        for (int i = 0; i < m; i++) if (w.h_vec[i] < -1e-13) return GOMILP_ERR_PANIC;  // simplex.go:155-158
+        rc = run_loop_tab(P, 1, 1e-10, nn, st);
+        if (rc == GOMILP_ERR_DEVICE) return rc;
+        if (rc != GOMILP_OK) { st->wrapped_status = rc; return GOMILP_ERR_PHASE1_WRAPPED; }  // :557-559
+        HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        int added = -1;
+        for (int i = 0; i < m; i++) { basic[i] = w.h_idx[i]; xb[i] = w.h_vec[i]; if (basic[i] == n) added = i; }
+        HIP_TRY(hipMemcpy(nonbasic.data(), w.nonbasic, (size_t)nn * sizeof(int32_t), hipMemcpyDeviceToHost));
+        double xart = added >= 0 ? xb[added] : 0.0;
+        if (added >= 0 && fabs(xart) > 1e-13 && fabs(xart) < 1e-11) {
+            std::vector<double> xe;
+            bool sing = false;
+            if ((rc = final_solve(P, n + 1, xe, &sing)) != GOMILP_OK) return rc;
+            if (!sing) xart = xe[added];
+        }
+        if (fabs(xart) > 1e-12) return GOMILP_ERR_INFEASIBLE;  // phaseIZeroTol, :563-565
+        if (added >= 0) {
+            // :581-606 exchange the zero-level artificial for the first nonbasic variable (ascending id) that works
+            std::vector<std::pair<int32_t, int>> cand;  // (variable id, position)
+            for (int jp = 0; jp < nn; jp++) if (nonbasic[jp] < n) cand.emplace_back(nonbasic[jp], jp);
+            std::sort(cand.begin(), cand.end());
+            bool exchanged = false;
+            for (auto &cv : cand) {
+                const int jp = cv.second;
+                launch_tab_column(w.T[tcur_], ldt_, m, jp, w.xb, w.dvec, w.move, stream_);
+                launches_++;
+                HIP_TRY(hipMemcpyAsync(w.h_vec, w.dvec, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+                HIP_TRY(hipStreamSynchronize(stream_));
+                double dmax = 0;
+                for (int i = 0; i < m; i++) dmax = std::max(dmax, fabs(w.h_vec[i]));
+                const double dpv = w.h_vec[added];
+                if (!(fabs(dpv) > 1e-9 * std::max(1.0, dmax))) continue;
+                const double theta = xb[added] / dpv;
+                bool feas = true;
+                for (int i = 0; i < m && feas; i++) {
+                    const double v = (i == added) ? theta : xb[i] - theta * w.h_vec[i];
+                    if (v < -1e-13) feas = false;
+                }
+                if (!feas) continue;
+                if ((rc = tab_forced_pivot(P, 1, 1e-10, nn, jp, cv.first, 0.0, added, dpv, xb[added], n, 4, 0)) != GOMILP_OK) return rc;
+                basic[added] = cv.first;
+                nonbasic[jp] = n;
+                exchanged = true;
+                break;
+            }
+            if (!exchanged) return GOMILP_ERR_INFEASIBLE;  // :606
+            HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipStreamSynchronize(stream_));
+            for (int i = 0; i < m; i++) xb[i] = w.h_vec[i];
+        }
+        // ---- Phase I -> Phase II: nonbasic list rebuilt in ascending order (simplex.go:174-184), T columns follow
+        std::vector<int32_t> old_nb = nonbasic;
+        build_nonbasic(n);
+        const int nn2 = (int)nonbasic.size();
+        std::vector<int32_t> pos_of(n + 1, -1), srcpos(nn2);
+        for (int jp = 0; jp < nn; jp++) pos_of[old_nb[jp]] = jp;
+        for (int jp = 0; jp < nn2; jp++) srcpos[jp] = pos_of[nonbasic[jp]];
+        HIP_TRY(hipMemcpyAsync(w.srcpos, srcpos.data(), (size_t)nn2 * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        const int ldt2 = tab_ld(nn2);
+        launch_tab_permute_cols(w.T[tcur_], ldt_, w.T[tcur_ ^ 1], ldt2, m, nn2, w.srcpos, stream_);
+        launches_++;
+        tcur_ ^= 1;
+        ldt_ = ldt2;
+        nn = nn2;
+        if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return rc;
+    } else {
+        build_nonbasic(n);
+        nn = (int)nonbasic.size();
+        if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return rc;
+        if ((rc = set_up_T(nn)) != GOMILP_OK) return rc;
+    }
+    // ---- Phase II ----
+    launch_tab_r(w.T[tcur_], ldt_, m, nn, P.dc, w.basic, w.nonbasic, w.tscratch, w.R[rcur_], stream_);
+    launches_ += 2;
+    *loop_rc = run_loop_tab(P, 2, tol, nn, st);
+    return GOMILP_OK;
+}
+
+}  // namespace gomilp

@@ -24,34 +24,55 @@
 
 namespace gomilp {
 
+// Both kernels keep their dependent global-load chain to three round trips (at m = 2048 the fixed part of
+// a pivot kernel, not the streaming, is what limits the rate):
+//   round 1  state block + this thread's partials + (K_A) nonbasic[pos] / (K_B) first B^-1 row and old row p
+//   round 2  reduction in registers/LDS; the winner carries its payload (d_p, basic[p] / variable id, and the
+//            value itself is decoded from the sort key), so no load depends on the winning index
+//   round 3  (K_A) row p of B^-1 and y  /  (K_B) entering column a_q
+
 template <int NV>
 __global__ __launch_bounds__(kBlock) void k_price_fused(LPArgs a, const double *__restrict__ y_in,
                                                         double *__restrict__ y_out, int pending, int nparts_ratio) {
     extern __shared__ __attribute__((aligned(16))) double2 svec[];
+    __shared__ ArgMinP sm[kWavesPerBlock];
     __shared__ unsigned long long sk[kWavesPerBlock];
     __shared__ unsigned int si[kWavesPerBlock];
     DevState *st = a.st;
-    if (st->done) return;
     constexpr int ld2 = NV * 64;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * kWavesPerBlock;
-    int q_prev = pending ? st->q : -1;
-    int lea = -1;
-    // issue the loads of this wave's first row now: they fly while the prologue's dependent chain
-    // (partials -> p -> row p / y) runs.  The one wave that owns position q_prev must wait for `lea`.
-    double2 v[NV];
+    // ---- round 1: everything that depends on nothing
+    const int done = st->done;
+    const int q_prev = pending ? st->q : -1;
+    const double rq_prev = st->rq;
+    ArgMinP best;
+    best.k = ~0ull; best.i = 0xFFFFFFFFu; best.u = 0; best.d = 0;
+    if (pending) {
+        for (int t = threadIdx.x; t < nparts_ratio; t += kBlock) {
+            ArgMinP c;
+            c.k = a.pk_ratio[t]; c.i = a.pi_ratio[t]; c.u = a.pb_ratio[t]; c.d = a.pd_ratio[t];
+            aminp_take(best, c);
+        }
+    }
     int j0 = -1;
     const bool pre = (wave < a.nn) && (wave != q_prev);
+    if (pre) j0 = a.nonbasic[wave];
+    if (done) return;
+    // this wave's first column goes in flight now; the one wave that owns position q_prev must wait for `lea`
+    double2 v[NV];
     if (pre) {
-        j0 = a.nonbasic[wave];
         const double2 *r2 = reinterpret_cast<const double2 *>(a.At + (size_t)j0 * a.ld);
 #pragma unroll
         for (int k = 0; k < NV; k++) v[k] = r2[lane + 64 * k];
     }
+    int lea = -1;
     if (pending) {
-        const int p = (int)reduce_partials(a.pk_ratio, a.pi_ratio, nparts_ratio, sk, si, nullptr);
-        const double mv = a.move[p];
+        // ---- round 2: leaving row of pivot t-1
+        block_argminp(best, sm);
+        const int p = (int)best.i;
+        const double mv = orddecode(best.k);
         if (mv == __builtin_inf()) {  // simplex.go:328-330
             if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->status = ST_UNBOUNDED; st->p = p; st->mv = mv; }
             return;
@@ -60,9 +81,10 @@ __global__ __launch_bounds__(kBlock) void k_price_fused(LPArgs a, const double *
             if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->status = ST_NEED_BLAND; st->p = p; st->mv = mv; }
             return;
         }
-        const double dpv = a.dvec[p];
-        const double alpha = st->rq / dpv;
-        lea = a.basic[p];
+        const double dpv = best.d;
+        const double alpha = rq_prev / dpv;
+        lea = (int)best.u;
+        // ---- round 3: y_t = y_{t-1} + (r_q/d_p) * row_p(B^-1_{t-1}), built directly in LDS
         const double2 *rp = reinterpret_cast<const double2 *>(a.binv_cur + (size_t)p * a.ld);
         const double2 *yi = reinterpret_cast<const double2 *>(y_in);
         double2 *yo = reinterpret_cast<double2 *>(y_out);
@@ -75,8 +97,7 @@ __global__ __launch_bounds__(kBlock) void k_price_fused(LPArgs a, const double *
             if (blockIdx.x == 0) yo[c] = w;
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
-            // commit pivot t-1 (simplex.go:280); basic[p] itself is rewritten by K_B(t) because this kernel's
-            // other workgroups still read it as the leaving variable
+            // commit pivot t-1 (simplex.go:280); basic[p] itself is rewritten by K_B(t)
             const int ent = st->ent_cur;
             st->p = p; st->dp = dpv; st->mv = mv; st->theta = a.xb[p] / dpv;
             st->ent_prev = ent; st->lea = lea;
@@ -93,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void k_price_fused(LPArgs a, const double *
         stage_vec(svec, y_in, ld2);
     }
     unsigned long long bk = ~0ull;
-    unsigned int bi = 0xFFFFFFFFu;
+    unsigned int bi = 0xFFFFFFFFu, bv = 0;
     for (int pos = wave; pos < a.nn; pos += nwaves) {
         int j = j0;
         if (!(pre && pos == wave)) {
@@ -111,44 +132,59 @@ __global__ __launch_bounds__(kBlock) void k_price_fused(LPArgs a, const double *
         const double dot = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
         const double r = a.cost[j] - dot;
         if (lane == 0) a.rvec[pos] = r;
-        amin_take(bk, bi, ordkey(r), (unsigned int)pos);
+        const unsigned long long key = ordkey(r);
+        if (key < bk || (key == bk && (unsigned int)pos < bi)) { bk = key; bi = (unsigned int)pos; bv = (unsigned int)j; }
     }
-    block_argmin(bk, bi, sk, si);
-    if (threadIdx.x == 0) { a.pk_price[blockIdx.x] = bk; a.pi_price[blockIdx.x] = bi; }
+    // workgroup winner with its variable id
+    ArgMinP mine;
+    mine.k = bk; mine.i = bi; mine.u = bv; mine.d = 0;
+    block_argminp(mine, sm);
+    if (threadIdx.x == 0) { a.pk_price[blockIdx.x] = mine.k; a.pi_price[blockIdx.x] = mine.i; a.pv_price[blockIdx.x] = mine.u; }
+    (void)sk; (void)si;
 }
 
 template <int NV>
 __global__ __launch_bounds__(kBlock) void k_update_ftran_fused(LPArgs a, int pending, int nparts_price) {
     extern __shared__ __attribute__((aligned(16))) double2 svec[];
-    __shared__ unsigned long long sk[kWavesPerBlock];
-    __shared__ unsigned int si[kWavesPerBlock];
+    __shared__ ArgMinP sm[kWavesPerBlock];
     DevState *st = a.st;
-    if (st->done) return;
     constexpr int ld2 = NV * 64;
     double2 *svecA = svec;        // entering column a_q
     double2 *svecP = svec + ld2;  // old row p of B^-1
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * kWavesPerBlock;
-    // this wave's first row of B^-1 goes in flight before the prologue (reduce -> q -> stage a_q, row p)
+    // ---- round 1: state, partials, first row, old row p
+    const int done = st->done;
+    const int p = pending ? st->p : -1;
+    const double dpv = pending ? st->dp : 1.0;
+    const double theta = pending ? st->theta : 0.0;
+    ArgMinP best;
+    best.k = ~0ull; best.i = 0xFFFFFFFFu; best.u = 0; best.d = 0;
+    for (int t = threadIdx.x; t < nparts_price; t += kBlock) {
+        ArgMinP c;
+        c.k = a.pk_price[t]; c.i = a.pi_price[t]; c.u = a.pv_price[t]; c.d = 0;
+        aminp_take(best, c);
+    }
+    if (done) return;
     double2 v[NV];
     if (wave < a.m) {
         const double2 *src = reinterpret_cast<const double2 *>(a.binv_cur + (size_t)wave * a.ld);
 #pragma unroll
         for (int k = 0; k < NV; k++) v[k] = src[lane + 64 * k];
     }
-    const int q = (int)reduce_partials(a.pk_price, a.pi_price, nparts_price, sk, si, nullptr);
-    const double rq = a.rvec[q];
-    const bool optimal = (rq >= -a.tol);  // simplex.go:248
-    int p = -1, var = -1;
-    double dpv = 1, theta = 0;
     if (pending) {
-        p = st->p; dpv = st->dp; theta = st->theta;
         const double2 *rp = reinterpret_cast<const double2 *>(a.binv_cur + (size_t)p * a.ld);
         for (int c = threadIdx.x; c < ld2; c += kBlock) svecP[c] = rp[c];
     }
+    // ---- round 2: entering column of pivot t
+    block_argminp(best, sm);
+    const int q = (int)best.i;
+    const int var = (int)best.u;
+    const double rq = orddecode(best.k);
+    const bool optimal = (rq >= -a.tol);  // simplex.go:248
+    // ---- round 3: a_q
     if (!optimal) {
-        var = a.nonbasic[q];
         const double2 *aq = reinterpret_cast<const double2 *>(a.At + (size_t)var * a.ld);
         for (int c = threadIdx.x; c < ld2; c += kBlock) svecA[c] = aq[c];
     }
@@ -159,6 +195,7 @@ __global__ __launch_bounds__(kBlock) void k_update_ftran_fused(LPArgs a, int pen
     }
     unsigned long long bk = ~0ull;
     unsigned int bi = 0xFFFFFFFFu;
+    double bd = 0;
     for (int i = wave; i < a.m; i += nwaves) {
         if (i != wave) {
             const double2 *src = reinterpret_cast<const double2 *>(a.binv_cur + (size_t)i * a.ld);
@@ -198,12 +235,21 @@ __global__ __launch_bounds__(kBlock) void k_update_ftran_fused(LPArgs a, int pen
             if (fabs(d) < 1e-13) d = 0;        // :321-325
             const double mv = (d >= 0) ? __builtin_inf() : xbi / fabs(d);  // :334-340
             if (lane == 0) { a.dvec[i] = dnew; a.move[i] = mv; }
-            amin_take(bk, bi, ordkey(mv), (unsigned int)i);
+            const unsigned long long key = ordkey(mv);
+            if (key < bk || (key == bk && (unsigned int)i < bi)) { bk = key; bi = (unsigned int)i; bd = dnew; }
         }
     }
     if (!optimal) {
-        block_argmin(bk, bi, sk, si);
-        if (threadIdx.x == 0) { a.pk_ratio[blockIdx.x] = bk; a.pi_ratio[blockIdx.x] = bi; }
+        ArgMinP mine;
+        mine.k = bk; mine.i = bi; mine.d = bd;
+        // basic[] is stable in this kernel except position p, rewritten below by (0,0) to ent_prev: read it through
+        // the same substitution so that the payload is the post-commit value
+        mine.u = (bi == 0xFFFFFFFFu) ? 0u : (unsigned int)(((int)bi == p) ? st->ent_prev : a.basic[bi]);
+        block_argminp(mine, sm);
+        if (threadIdx.x == 0) {
+            a.pk_ratio[blockIdx.x] = mine.k; a.pi_ratio[blockIdx.x] = mine.i; a.pd_ratio[blockIdx.x] = mine.d;
+            a.pb_ratio[blockIdx.x] = mine.u;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (pending) a.basic[p] = st->ent_prev;

@@ -20,6 +20,13 @@ __device__ __forceinline__ unsigned long long ordkey(double v) {
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
+// inverse of ordkey (exact; -0 comes back as +0, NaN as NaN)
+__device__ __forceinline__ double orddecode(unsigned long long k) {
+    if (k == ~0ull) return __builtin_nan("");
+    const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
 __device__ __forceinline__ void amin_take(unsigned long long &k, unsigned int &i, unsigned long long k2,
                                           unsigned int i2) {
     if (k2 < k || (k2 == k && i2 < i)) { k = k2; i = i2; }
@@ -64,6 +71,36 @@ __device__ __forceinline__ unsigned int reduce_partials(const unsigned long long
     block_argmin(k, i, sk, si);
     if (key_out) *key_out = k;
     return i;
+}
+
+// argmin with two payload words travelling with the winner (fused pipeline: saves the dependent
+// global loads that would otherwise follow the reduction)
+struct ArgMinP {
+    unsigned long long k;
+    unsigned int i;
+    unsigned int u;  // payload: variable id
+    double d;        // payload: d'_i
+};
+__device__ __forceinline__ void aminp_take(ArgMinP &a, const ArgMinP &b) {
+    if (b.k < a.k || (b.k == a.k && b.i < a.i)) a = b;
+}
+__device__ __forceinline__ void wave_argminp(ArgMinP &a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMinP b;
+        b.k = __shfl_xor(a.k, o, 64); b.i = __shfl_xor(a.i, o, 64); b.u = __shfl_xor(a.u, o, 64); b.d = __shfl_xor(a.d, o, 64);
+        aminp_take(a, b);
+    }
+}
+__device__ __forceinline__ void block_argminp(ArgMinP &a, ArgMinP *sm) {
+    wave_argminp(a);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sm[w] = a;
+    __syncthreads();
+    a = sm[0];
+#pragma unroll
+    for (int t = 1; t < kWavesPerBlock; t++) aminp_take(a, sm[t]);
+    __syncthreads();
 }
 
 // dot of one padded row (ld doubles, 16-byte aligned) with the LDS-staged vector; result in all lanes

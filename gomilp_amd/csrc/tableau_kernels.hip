@@ -1,0 +1,326 @@
+// Single-kernel pivot on the explicit tableau T = B^-1 A_N (gfx950) — the fast path when n - m < 2m.
+//
+// The reference prices with fresh duals every pivot (simplex.go:236-247).  Keeping T = B^-1 A_N (m x (n-m), one
+// column per nonbasic POSITION, same positional order as nonBasicIdx) turns a whole pivot into ONE streaming pass:
+//
+//   prologue  reduce the ratio-test partials of the current pivot -> leaving row p (simplex.go:268);
+//             stage row p of T in LDS; update the reduced costs r <- r - (r_q/d_p) * T[p,:] (r_q slot: -r_q/d_p);
+//             first-index argmin of the new r -> next entering position (simplex.go:247) or OPTIMAL (:248)
+//   pass      T[i,:] <- T[i,:] - (d_i/d_p) T[p,:]  (row p: / d_p; column q becomes the leaving variable's column),
+//             written to the other copy of T; the lane that owns the next entering column hands d'_i = T'[i, q']
+//             to the ratio test (simplex.go:306-342) — FTRAN and pricing cost no extra pass
+//   epilogue  per-workgroup first-index argmin of the ratios, winner carries (d'_i, basic[i], x_B[i])
+//
+// HBM traffic per pivot: 16*m*(n-m) bytes (read + write T) — at n = 2m that is half of what the
+// pricing + FTRAN + update formulation (8*[m(n-m) + 3m^2]) moves, in one launch instead of two or three.
+// Launch t reads the "next pivot" slot (t & 1) of DevState and writes slot ((t+1) & 1); a launch only turns
+// later launches into no-ops (stop_at), so nothing depends on when a workgroup of the same launch starts.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+
+#include "device_types.h"
+#include "kernels_common.h"
+
+namespace gomilp {
+
+struct ArgMinT {
+    unsigned long long k;
+    unsigned int i, u;
+    double d, x;
+};
+__device__ __forceinline__ void amint_take(ArgMinT &a, const ArgMinT &b) {
+    if (b.k < a.k || (b.k == a.k && b.i < a.i)) a = b;
+}
+__device__ __forceinline__ void block_argmint(ArgMinT &a, ArgMinT *sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMinT b;
+        b.k = __shfl_xor(a.k, o, 64); b.i = __shfl_xor(a.i, o, 64); b.u = __shfl_xor(a.u, o, 64);
+        b.d = __shfl_xor(a.d, o, 64); b.x = __shfl_xor(a.x, o, 64);
+        amint_take(a, b);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sm[w] = a;
+    __syncthreads();
+    a = sm[0];
+#pragma unroll
+    for (int t = 1; t < kWavesPerBlock; t++) amint_take(a, sm[t]);
+    __syncthreads();
+}
+
+// U = number of 1-KiB row chunks (64 lanes x 16 bytes) loaded back to back before the first use.
+// flags: bit0 pending (a pivot is waiting to be applied), bit1 forced (skip the unbounded / degenerate tests:
+// Bland step or set-up pivot chosen by the host), bit2 no_commit (set-up pivot: indices managed by the host),
+// bit3 bland (trace only)
+template <int U>
+__global__ __launch_bounds__(kBlock) void k_tableau_pivot(TabArgs a, int flags, int nparts, long long t) {
+    extern __shared__ __attribute__((aligned(16))) double2 srow[];  // old row p
+    __shared__ ArgMinT sm[kWavesPerBlock];
+    __shared__ unsigned long long sk[kWavesPerBlock];
+    __shared__ unsigned int si[kWavesPerBlock];
+    DevState *st = a.st;
+    const bool pending = flags & 1, forced = flags & 2, no_commit = flags & 4;
+    const int par = (int)(t & 1);
+    const int ld2 = a.ldt >> 1;
+    const int nch = ld2 >> 6;  // 1-KiB chunks per row
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    // ---- round 1: state + partials
+    const long long stop_at = st->stop_at;
+    const int q_cur = st->nq[par];
+    const double rq_cur = st->nrq[par];
+    const int ent_cur = st->nent[par];
+    ArgMinT best;
+    best.k = ~0ull; best.i = 0xFFFFFFFFu; best.u = 0; best.d = 0; best.x = 0;
+    if (pending) {
+        for (int c = threadIdx.x; c < nparts; c += kBlock) {
+            ArgMinT b;
+            b.k = a.pk_ratio[c]; b.i = a.pi_ratio[c]; b.u = a.pb_ratio[c]; b.d = a.pd_ratio[c]; b.x = a.px_ratio[c];
+            amint_take(best, b);
+        }
+    }
+    if (t >= stop_at) return;
+    int p = -1, lea = -1;
+    double dpv = 1, theta = 0, mult = 0;
+    if (pending) {
+        // ---- round 2: leaving row of the current pivot
+        block_argmint(best, sm);
+        p = (int)best.i;
+        const double mv = orddecode(best.k);
+        if (!forced) {
+            if (mv == __builtin_inf()) {  // simplex.go:328-330
+                if (blockIdx.x == 0 && threadIdx.x == 0) { st->stop_at = t + 1; st->done = 1; st->status = ST_UNBOUNDED; st->p = p; st->mv = mv; }
+                return;
+            }
+            if (mv <= 0) {  // simplex.go:269 -> Bland
+                if (blockIdx.x == 0 && threadIdx.x == 0) { st->stop_at = t + 1; st->done = 1; st->status = ST_NEED_BLAND; st->p = p; st->mv = mv; }
+                return;
+            }
+        }
+        dpv = best.d; lea = (int)best.u; theta = best.x / dpv; mult = rq_cur / dpv;
+    }
+    // ---- round 3: row p -> LDS, new reduced costs, next entering position
+    unsigned long long bk = ~0ull;
+    unsigned int bi = 0xFFFFFFFFu;
+    {
+        const double2 *rp2 = reinterpret_cast<const double2 *>(a.T_cur + (size_t)(pending ? p : 0) * a.ldt);
+        const double2 *ri2 = reinterpret_cast<const double2 *>(a.r_in);
+        double2 *ro2 = reinterpret_cast<double2 *>(a.r_out);
+        for (int c = threadIdx.x; c < ld2; c += kBlock) {
+            double2 rr = ri2[c];
+            if (pending) {
+                const double2 w = rp2[c];
+                srow[c] = w;
+                rr.x = rr.x - mult * w.x;
+                rr.y = rr.y - mult * w.y;
+                if (2 * c == q_cur) rr.x = -mult;      // the leaving variable takes position q: r = -r_q/d_p
+                if (2 * c + 1 == q_cur) rr.y = -mult;
+                if (blockIdx.x == 0) ro2[c] = rr;
+            }
+            if (2 * c < a.nn) amin_take(bk, bi, ordkey(rr.x), (unsigned int)(2 * c));
+            if (2 * c + 1 < a.nn) amin_take(bk, bi, ordkey(rr.y), (unsigned int)(2 * c + 1));
+        }
+    }
+    block_argmin(bk, bi, sk, si);  // contains the barrier that publishes srow
+    const int q_next = (int)bi;
+    const double rq_next = orddecode(bk);
+    const bool optimal = (rq_next >= -a.tol);  // simplex.go:248
+    if (!pending && optimal) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { st->stop_at = t + 1; st->done = 1; st->status = ST_OPTIMAL; st->q = q_next; st->rq = rq_next; }
+        return;
+    }
+    // ---- streaming pass
+    const int qn_chunk = (q_next >> 1) >> 6, qn_lane = (q_next >> 1) & 63, qn_half = q_next & 1;
+    const int qc_chunk = (q_cur >> 1) >> 6, qc_lane = (q_cur >> 1) & 63, qc_half = q_cur & 1;
+    ArgMinT mine;
+    mine.k = ~0ull; mine.i = 0xFFFFFFFFu; mine.u = 0; mine.d = 0; mine.x = 0;
+    for (int i = wave; i < a.m; i += nwaves) {
+        const double2 *src = reinterpret_cast<const double2 *>(a.T_cur + (size_t)i * a.ldt);
+        double2 *dst = reinterpret_cast<double2 *>(a.T_next + (size_t)i * a.ldt);
+        const double di = pending ? a.dvec[i] : 0.0;
+        const double f = di / dpv;
+        const bool is_p = (i == p);
+        double dn = 0;
+        for (int c0 = 0; c0 < nch; c0 += U) {
+            // scalars, not double2: a select between .x and .y of a vector becomes a dynamic extractelement,
+            // which demotes the whole array to scratch
+            double vx[U], vy[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) {  // nch is a multiple of U (launch wrapper)
+                const double2 ld = src[lane + 64 * (c0 + k)];
+                vx[k] = ld.x; vy[k] = ld.y;
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const int ch = c0 + k;
+                if (pending) {
+                    const double2 rp = srow[lane + 64 * ch];
+                    if (is_p) { vx[k] = vx[k] / dpv; vy[k] = vy[k] / dpv; }
+                    else { vx[k] = vx[k] - f * rp.x; vy[k] = vy[k] - f * rp.y; }
+                    if (ch == qc_chunk && lane == qc_lane) {  // column q now belongs to the leaving variable (eta column)
+                        const double e = is_p ? 1.0 / dpv : -f;
+                        vx[k] = qc_half ? vx[k] : e;
+                        vy[k] = qc_half ? e : vy[k];
+                    }
+                    double2 outv;
+                    outv.x = vx[k]; outv.y = vy[k];
+                    dst[lane + 64 * ch] = outv;
+                }
+                if (ch == qn_chunk && lane == qn_lane) dn = qn_half ? vy[k] : vx[k];
+            }
+        }
+        dn = __shfl(dn, qn_lane, 64);
+        double xbi = a.xb[i];
+        if (pending) {
+            xbi = is_p ? theta : xbi - theta * di;
+            if (lane == 0) a.xb[i] = xbi;
+        }
+        if (!optimal) {
+            double d = -dn;                  // simplex.go:319
+            if (fabs(d) < 1e-13) d = 0;      // :321-325
+            const double mv = (d >= 0) ? __builtin_inf() : xbi / fabs(d);  // :334-340
+            if (lane == 0) { a.dvec[i] = dn; a.move[i] = mv; }
+            ArgMinT c;
+            c.k = ordkey(mv); c.i = (unsigned int)i; c.d = dn; c.x = xbi;
+            c.u = (unsigned int)((pending && is_p && !no_commit) ? ent_cur : a.basic[i]);
+            amint_take(mine, c);
+        }
+    }
+    if (!optimal) {
+        block_argmint(mine, sm);
+        if (threadIdx.x == 0) {
+            a.pk_ratio[blockIdx.x] = mine.k; a.pi_ratio[blockIdx.x] = mine.i; a.pb_ratio[blockIdx.x] = mine.u;
+            a.pd_ratio[blockIdx.x] = mine.d; a.px_ratio[blockIdx.x] = mine.x;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (pending && !no_commit) {  // simplex.go:280
+            a.basic[p] = ent_cur;
+            a.nonbasic[q_cur] = lea;
+            if (a.trace && st->trace_len < a.trace_cap) {
+                DevPivot &tr = a.trace[st->trace_len];
+                tr.phase = a.phase; tr.bland = (flags & 8) ? 1 : 0; tr.min_idx = q_cur; tr.replace = p; tr.entering = ent_cur; tr.leaving = lea;
+            }
+            st->trace_len += 1;
+            st->pivots += 1;
+            st->p = p; st->dp = dpv; st->theta = theta;
+        }
+        st->nq[par ^ 1] = q_next;
+        st->nrq[par ^ 1] = rq_next;
+        // variable id at the next entering position AFTER this launch's swap
+        st->nent[par ^ 1] = (pending && !no_commit && q_next == q_cur) ? lea : a.nonbasic[q_next];
+        st->q = q_next; st->rq = rq_next;
+        if (optimal) { st->stop_at = t + 1; st->done = 1; st->status = ST_OPTIMAL; }
+    }
+}
+
+// ---- set-up kernels ---------------------------------------------------------------------------
+
+// T[pos, jp] = At[var(jp)][rho[pos]]  (B^-1 = permutation of the slack basis: row pos of T is row rho[pos] of A_N)
+__global__ void k_tab_gather(const double *__restrict__ At, int ld, int m, int nn, const int32_t *__restrict__ nonbasic,
+                             const int32_t *__restrict__ rho, double *__restrict__ T, int ldt) {
+    __shared__ double tile[32][33];
+    const int j0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    // the source rows are permuted by rho, so read one At row segment per (jp) and scatter through LDS
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int jp = j0 + r, pos = p0 + threadIdx.x;
+        if (jp < nn && pos < m) tile[r][threadIdx.x] = At[(size_t)nonbasic[jp] * ld + rho[pos]];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int pos = p0 + r, jp = j0 + threadIdx.x;
+        if (jp < nn && pos < m) T[(size_t)pos * ldt + jp] = tile[threadIdx.x][r];
+    }
+}
+
+// T_out[:, jp] = T_in[:, src[jp]]  (Phase I -> Phase II: nonbasic list rebuilt in ascending variable order)
+__global__ void k_tab_permute_cols(const double *__restrict__ Tin, int ld_in, double *__restrict__ Tout, int ld_out, int m,
+                                   int nn_out, const int32_t *__restrict__ srcpos) {
+    const int i = blockIdx.y;
+    const int jp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (jp < ld_out) Tout[(size_t)i * ld_out + jp] = (jp < nn_out) ? Tin[(size_t)i * ld_in + srcpos[jp]] : 0.0;
+}
+
+// r[jp] = cost[nonbasic[jp]] - sum_i cost[basic[i]] * T[i, jp]   (row-chunked, fixed-order reduction)
+__global__ __launch_bounds__(kBlock) void k_tab_r_partial(const double *__restrict__ T, int ldt, int m, int nn,
+                                                          const double *__restrict__ cost, const int32_t *__restrict__ basic,
+                                                          double *__restrict__ scratch, int rows_per_chunk) {
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    const int chunk = blockIdx.y;
+    const int i0 = chunk * rows_per_chunk, i1 = min(m, i0 + rows_per_chunk);
+    if (j >= ldt) return;
+    double acc = 0;
+    for (int i = i0; i < i1; i++) {
+        const double cb = cost[basic[i]];
+        if (cb != 0) acc += cb * T[(size_t)i * ldt + j];
+    }
+    scratch[(size_t)chunk * ldt + j] = acc;
+}
+__global__ void k_tab_r_reduce(const double *__restrict__ scratch, int ldt, int nn, int nchunks, const double *__restrict__ cost,
+                               const int32_t *__restrict__ nonbasic, double *__restrict__ r) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ldt) return;
+    double acc = 0;
+    for (int c = 0; c < nchunks; c++) acc += scratch[(size_t)c * ldt + j];
+    r[j] = (j < nn) ? cost[nonbasic[j]] - acc : 0.0;
+}
+
+// column jp of T -> dvec, ratio vector (computeMove for a Bland candidate, simplex.go:306-342)
+__global__ void k_tab_column(const double *__restrict__ T, int ldt, int m, int jp, const double *__restrict__ xb,
+                             double *__restrict__ dvec, double *__restrict__ move) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double dn = T[(size_t)i * ldt + jp];
+    double d = -dn;
+    if (fabs(d) < 1e-13) d = 0;
+    dvec[i] = dn;
+    move[i] = (d >= 0) ? __builtin_inf() : xb[i] / fabs(d);
+}
+
+// ---- launch wrappers ---------------------------------------------------------------------------
+
+static inline int grid_rows_t(int rows) {
+    int g = (rows + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (g > kMaxPartials) g = kMaxPartials;
+    return g < 1 ? 1 : g;
+}
+
+int launch_tableau_pivot(const TabArgs &a, int flags, int nparts, long long t, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const int g = grid_rows_t(a.m);
+    const int nch = a.ldt / 128;  // ldt is a multiple of 512 doubles (tab_ld), so U = 4 always divides nch
+    const size_t lds = (size_t)a.ldt * sizeof(double);
+    if (nch % 16 == 0)
+        hipExtLaunchKernelGGL((k_tableau_pivot<16>), dim3(g), dim3(kBlock), lds, s, e0, e1, 0, a, flags, nparts, t);
+    else if (nch % 8 == 0)
+        hipExtLaunchKernelGGL((k_tableau_pivot<8>), dim3(g), dim3(kBlock), lds, s, e0, e1, 0, a, flags, nparts, t);
+    else
+        hipExtLaunchKernelGGL((k_tableau_pivot<4>), dim3(g), dim3(kBlock), lds, s, e0, e1, 0, a, flags, nparts, t);
+    return g;
+}
+void launch_tab_gather(const double *At, int ld, int m, int nn, const int32_t *nonbasic, const int32_t *rho, double *T, int ldt,
+                       hipStream_t s) {
+    dim3 grid((m + 31) / 32, (nn + 31) / 32), block(32, 8);
+    hipLaunchKernelGGL(k_tab_gather, grid, block, 0, s, At, ld, m, nn, nonbasic, rho, T, ldt);
+}
+int tab_ld(int nn) { return ((nn + 511) / 512) * 512; }
+void launch_tab_permute_cols(const double *Tin, int ld_in, double *Tout, int ld_out, int m, int nn_out, const int32_t *srcpos,
+                             hipStream_t s) {
+    dim3 grid((ld_out + 255) / 256, m);
+    hipLaunchKernelGGL(k_tab_permute_cols, grid, dim3(256), 0, s, Tin, ld_in, Tout, ld_out, m, nn_out, srcpos);
+}
+int tab_r_chunks(int m) { int c = (m + 63) / 64; return c > 64 ? 64 : c; }
+void launch_tab_r(const double *T, int ldt, int m, int nn, const double *cost, const int32_t *basic, const int32_t *nonbasic,
+                  double *scratch, double *r, hipStream_t s) {
+    const int nchunks = tab_r_chunks(m);
+    const int rpc = (m + nchunks - 1) / nchunks;
+    dim3 grid((ldt + kBlock - 1) / kBlock, nchunks);
+    hipLaunchKernelGGL(k_tab_r_partial, grid, dim3(kBlock), 0, s, T, ldt, m, nn, cost, basic, scratch, rpc);
+    hipLaunchKernelGGL(k_tab_r_reduce, dim3((ldt + 255) / 256), dim3(256), 0, s, scratch, ldt, nn, nchunks, cost, nonbasic, r);
+}
+void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb, double *dvec, double *move, hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_column, dim3((m + 255) / 256), dim3(256), 0, s, T, ldt, m, jp, xb, dvec, move);
+}
+
+}  // namespace gomilp

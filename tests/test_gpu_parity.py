@@ -73,15 +73,31 @@ def test_dense_lp_matches_oracle_bitwise(ctx, m, seed):
     assert g.stats["pivots_phase2"] > 0
 
 
-@pytest.mark.parametrize("m,seed,fused", [(128, 9, 1), (128, 9, 0), (256, 11, 1), (512, 3, 1), (512, 3, 0)])
-def test_fused_and_unfused_pipelines_match_oracle(m, seed, fused):
-    """ld = 128*NV sizes take the fused two-kernel pipeline (fused_kernels.hip); knob fused=0 forces the
-    three-kernel path on the same input.  Both must reproduce the oracle's pivot sequence and bits."""
+@pytest.mark.parametrize("m,seed,pipe", [(128, 9, "fused"), (128, 9, "three-kernel"), (256, 11, "fused"), (512, 3, "fused"),
+                                         (512, 3, "three-kernel"), (512, 3, "tableau"), (300, 5, "tableau")])
+def test_all_pivot_pipelines_match_oracle(m, seed, pipe):
+    """Three device formulations of the pivot: single-kernel tableau (default when n-m < 2m), fused
+    two-kernel revised simplex (ld = 128*NV), three-kernel revised simplex (any shape).  Each must reproduce the
+    oracle's pivot sequence and the reference's bits."""
     c, A, b = synth.dense_lp_standard_form(m, seed)
-    cx = lp.Context(fused=fused, chunk=16)
+    knobs = {"tableau": dict(tableau=1), "fused": dict(tableau=0, fused=1), "three-kernel": dict(tableau=0, fused=0)}[pipe]
+    cx = lp.Context(chunk=16, **knobs)
     try:
         g, o = _check_against_oracle(cx, c, A, b)
-        assert g.stats["kernel_launches"] > 0
+        assert g.stats["pipeline"] == pipe
+    finally:
+        cx.close()
+
+
+@pytest.mark.parametrize("pipe", ["tableau", "three-kernel"])
+@pytest.mark.parametrize("signs", [(-1,), (1, -1, 1)])
+def test_children_on_each_pipeline(pipe, signs):
+    c, A, b = _child(24, 3, signs)
+    knobs = {"tableau": dict(tableau=1), "three-kernel": dict(tableau=0, fused=0)}[pipe]
+    cx = lp.Context(chunk=8, **knobs)
+    try:
+        g, o = _check_against_oracle(cx, c, A, b)
+        assert g.stats["pipeline"] == pipe
     finally:
         cx.close()
 
