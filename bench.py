@@ -167,7 +167,13 @@ def main() -> int:
         value = piv_all / dt_max
         nn = n - m
         bytes_pivot = 8.0 * (m * nn + 3.0 * m * m)      # pricing m(n-m) + FTRAN m^2 + update 2 m^2
-        bytes_update = 16.0 * m * m                      # the dominant kernel's share: read + write B^-1
+        pipeline = last.stats["pipeline"]
+        if pipeline == "tableau":
+            # one launch = one whole pivot: the launch is credited with the SURVEY per-pivot figure; what the
+            # single-kernel formulation really moves is 16*m*(n-m) bytes (read + write T = B^-1 A_N)
+            kernel_name, bytes_update, bytes_moved = "k_tableau_pivot", bytes_pivot, 16.0 * m * nn
+        else:
+            kernel_name, bytes_update, bytes_moved = "k_update", 16.0 * m * m, 16.0 * m * m   # read + write B^-1
         nsamp = max(ksec[3], 1.0)
         t_upd = ksec[2] / nsamp
         achieved = bytes_update / t_upd / 1e9 if t_upd > 0 else 0.0
@@ -186,11 +192,12 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": "%s: %dx%d dense LP, splitmix64 seed %d (+rank), one full solve per step"
                                    % (args.workload, m, n, synth.CONFIGS[args.workload][1]),
-                       "pivots_per_solve": int(last.stats["pivots_phase2"]), "parallelism": "1 relaxation per GPU",
+                       "pivots_per_solve": int(last.stats["pivots_phase2"]), "parallelism": "1 relaxation per GPU", "pipeline": last.stats["pipeline"],
                        "chunk": args.chunk, "refresh": args.refresh},
-            "roofline": {"bound": "hbm", "kernel": "k_update", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "pipeline": pipeline, "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_launch": bytes_update, "avg_launch_us": 1e6 * t_upd,
+                         "bytes_moved_model": bytes_moved, "moved_GBs": bytes_moved / t_upd / 1e9 if t_upd > 0 else 0.0,
                          "avg_us": {"k_price": 1e6 * ksec[0] / nsamp, "k_ftran": 1e6 * ksec[1] / nsamp,
                                     "k_update": 1e6 * ksec[2] / nsamp, "sampled_pivots": int(ksec[3])},
                          "per_pivot": {"bytes": bytes_pivot, "achieved_GBs": value / world * bytes_pivot / 1e9,
