@@ -1,0 +1,309 @@
+// Blocked tableau pivoting with deferred rank-K updates (gfx950) — the default pipeline when n - m < 2m.
+//
+// A simplex pivot only LOOKS at one column (the entering one: ratio test) and one row (the leaving one:
+// reduced-cost update) of the tableau T = B^-1 A_N; the rank-1 update of all m*(n-m) entries is bookkeeping that
+// can be deferred.  So pivots run in blocks of K:
+//
+//   k_bt_inner   ONE workgroup (1024 threads) performs up to K complete pivots.  It reads the needed column and row
+//                of the stale T and corrects them with the block's earlier rank-1 terms,
+//                   T_cur = T_stale + sum_j u_j v_j'^T,
+//                keeps r and x_B in LDS, takes every decision exactly like the other pipelines (first-index argmin,
+//                1e-13 rounding, unbounded / degenerate tests, Bland rule of simplex.go:347-383 in-kernel), and
+//                emits u_k (m) and v_k' (n-m) per pivot.  No grid-wide step, no launch per pivot.
+//   k_bt_update  all CUs: T += sum_k u_k v_k'^T in one streaming read+write pass (K FMAs per element, in place —
+//                an element depends only on its own old value).
+//
+// HBM traffic per pivot: 16*m*(n-m)/K + O(K*(m + n-m)) bytes instead of 16*m*(n-m).
+// One pivot as a pure rank-1 term:  with d = column q, v = row p, d_p = pivot element:
+//   u_i = -d_i/d_p (i != p), u_p = 1/d_p - 1;  v'_j = v_j (j != q), v'_q = d_p + 1
+//   => T + u v'^T has row p = v/d_p, rows i = T_i - (d_i/d_p) v, and column q = the leaving variable's column.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+
+#include "device_types.h"
+#include "kernels_common.h"
+
+namespace gomilp {
+
+constexpr int kBtThreads = 1024;
+constexpr int kBtWaves = kBtThreads / 64;
+constexpr int kBtMaxK = 32;
+
+struct BtCand {
+    unsigned long long k;
+    unsigned int i;
+    double d;
+};
+__device__ __forceinline__ void bt_take(BtCand &a, const BtCand &b) {
+    if (b.k < a.k || (b.k == a.k && b.i < a.i)) a = b;
+}
+// argmin over the whole 1024-thread workgroup; result in every thread
+__device__ __forceinline__ void bt_block_argmin(BtCand &a, BtCand *sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        BtCand b;
+        b.k = __shfl_xor(a.k, o, 64); b.i = __shfl_xor(a.i, o, 64); b.d = __shfl_xor(a.d, o, 64);
+        bt_take(a, b);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sm[w] = a;
+    __syncthreads();
+    a = sm[0];
+#pragma unroll
+    for (int t = 1; t < kBtWaves; t++) bt_take(a, sm[t]);
+    __syncthreads();
+}
+
+// RI / CJ: rows / columns per thread (m <= RI*1024, n-m <= CJ*1024)
+template <int RI, int CJ>
+__global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double *r_s = sh;                 // ldt
+    double *xb_s = sh + a.ldt;        // ldu
+    __shared__ BtCand sm[kBtWaves];
+    __shared__ double vq[kBtMaxK], up[kBtMaxK];
+    __shared__ double s_bcast[2];
+    DevState *st = a.st;
+    const int tid = threadIdx.x;
+    if (st->done) {
+        if (tid == 0) st->kdone = 0;
+        return;
+    }
+    for (int j = tid; j < a.ldt; j += kBtThreads) r_s[j] = a.r[j];
+    for (int i = tid; i < a.ldu; i += kBtThreads) xb_s[i] = a.xb[i];
+    __syncthreads();
+    const double inf = __builtin_inf();
+    int kd = 0, status = ST_RUNNING, blands = 0;
+
+    // column q of the current tableau for this thread's rows
+    auto column = [&](int q, int k, double (&dcol)[RI]) {
+        if (tid < k) vq[tid] = __hip_atomic_load(a.V + (size_t)tid * a.ldt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            const int i = tid + s * kBtThreads;
+            double d = 0;
+            if (i < a.m) {
+                d = a.T[(size_t)i * a.ldt + q];
+                for (int j = 0; j < k; j++) d += a.U[(size_t)j * a.ldu + i] * vq[j];
+            }
+            dcol[s] = d;
+        }
+    };
+    // ratio vector (simplex.go:321-340) and its first-index argmin, winner carries d_i
+    auto ratio = [&](const double (&dcol)[RI], double (&mvv)[RI]) -> BtCand {
+        BtCand c;
+        c.k = ~0ull; c.i = 0xFFFFFFFFu; c.d = 0;
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            const int i = tid + s * kBtThreads;
+            mvv[s] = inf;
+            if (i < a.m) {
+                double d = -dcol[s];
+                if (fabs(d) < 1e-13) d = 0;
+                mvv[s] = (d >= 0) ? inf : xb_s[i] / fabs(d);
+                BtCand b;
+                b.k = ordkey(mvv[s]); b.i = (unsigned int)i; b.d = dcol[s];
+                bt_take(c, b);
+            }
+        }
+        bt_block_argmin(c, sm);
+        return c;
+    };
+
+    for (int k = 0; k < a.kmax; k++) {
+        const bool forced = (k == 0 && a.forced_q >= 0);
+        int q, p;
+        double rq, dpv;
+        bool bland = false;
+        double dcol[RI], mvv[RI];
+        if (!forced) {
+            // ---- entering position: first index of min r (simplex.go:247)
+            BtCand c;
+            c.k = ~0ull; c.i = 0xFFFFFFFFu; c.d = 0;
+            for (int j = tid; j < a.nn; j += kBtThreads) {
+                BtCand b;
+                b.k = ordkey(r_s[j]); b.i = (unsigned int)j; b.d = 0;
+                bt_take(c, b);
+            }
+            bt_block_argmin(c, sm);
+            q = (int)c.i;
+            rq = r_s[q];
+            if (rq >= -a.tol) { status = ST_OPTIMAL; break; }  // simplex.go:248
+            column(q, k, dcol);
+            BtCand w = ratio(dcol, mvv);
+            p = (int)w.i; dpv = w.d;
+            const double mv = orddecode(w.k);
+            if (mv == inf) { status = ST_UNBOUNDED; break; }  // simplex.go:328-330
+            if (mv <= 0) {
+                // ---- replaceBland (simplex.go:347-383): candidates in position order with r_i <= -1e-14 after the
+                // 1e-13 rounding of :252-256; the mat.Cond guard of :377 is replaced by |d| >= 1e-13
+                bland = true;
+                blands++;
+                int cand = -1;
+                bool found = false;
+                for (;;) {
+                    BtCand f;
+                    f.k = ~0ull; f.i = 0xFFFFFFFFu; f.d = 0;
+                    for (int j = tid; j < a.nn; j += kBtThreads) {
+                        if (j <= cand) continue;
+                        double rv = r_s[j];
+                        if (fabs(rv) < 1e-13) rv = 0;
+                        if (!(rv > -1e-14)) { f.k = 0; f.i = (unsigned int)j; break; }  // first such j of this thread
+                    }
+                    bt_block_argmin(f, sm);
+                    if (f.i == 0xFFFFFFFFu) break;  // candidates exhausted -> ErrBland
+                    cand = (int)f.i;
+                    column(cand, k, dcol);
+                    BtCand w2 = ratio(dcol, mvv);
+                    const double mv2 = orddecode(w2.k);
+                    if (mv2 == inf) { status = ST_UNBOUNDED; break; }  // computeMove inside Bland, :356-360
+                    if (fabs(mv2) > 1e-12) { q = cand; p = (int)w2.i; dpv = w2.d; found = true; break; }  // :362
+                    BtCand g;
+                    g.k = ~0ull; g.i = 0xFFFFFFFFu; g.d = 0;
+#pragma unroll
+                    for (int s = 0; s < RI; s++) {
+                        const int i = tid + s * kBtThreads;
+                        if (i < a.m && !(mvv[s] > 1e-12)) { BtCand b; b.k = 0; b.i = (unsigned int)i; b.d = dcol[s]; bt_take(g, b); }
+                    }
+                    bt_block_argmin(g, sm);
+                    if (g.i != 0xFFFFFFFFu) { q = cand; p = (int)g.i; dpv = g.d; found = true; break; }  // :368-379
+                }
+                if (status == ST_UNBOUNDED) break;
+                if (!found) { status = ST_BLAND_FAILED; break; }
+                rq = r_s[q];
+            }
+        } else {
+            q = a.forced_q; p = a.forced_p; rq = 0;
+            column(q, k, dcol);
+            if (tid == (p % kBtThreads)) s_bcast[0] = dcol[p / kBtThreads];
+            __syncthreads();
+            dpv = s_bcast[0];
+        }
+        // ---- row p of the current tableau for this thread's columns
+        if (tid < k) up[tid] = __hip_atomic_load(a.U + (size_t)tid * a.ldu + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const double mult = rq / dpv;
+        const double theta = xb_s[p] / dpv;
+        __syncthreads();  // everybody has read xb_s[p] before it is overwritten
+        double *Vk = a.V + (size_t)k * a.ldt;
+        double *Uk = a.U + (size_t)k * a.ldu;
+#pragma unroll
+        for (int s = 0; s < CJ; s++) {
+            const int j = tid + s * kBtThreads;
+            if (j < a.ldt) {
+                double v = 0;
+                if (j < a.nn) {
+                    v = a.T[(size_t)p * a.ldt + j];
+                    for (int jj = 0; jj < k; jj++) v += up[jj] * a.V[(size_t)jj * a.ldt + j];
+                    // reduced costs (positional): r_j - (r_q/d_p) v_j ; the leaving variable takes slot q
+                    r_s[j] = (j == q) ? -mult : r_s[j] - mult * v;
+                }
+                Vk[j] = (j == q) ? dpv + 1.0 : v;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            const int i = tid + s * kBtThreads;
+            if (i < a.ldu) {
+                double u = 0;
+                if (i < a.m) {
+                    u = (i == p) ? 1.0 / dpv - 1.0 : -dcol[s] / dpv;
+                    xb_s[i] = (i == p) ? theta : xb_s[i] - theta * dcol[s];
+                }
+                Uk[i] = u;
+            }
+        }
+        if (tid == 0 && !(forced && a.forced_nocommit)) {  // simplex.go:280
+            const int ent = a.nonbasic[q], lea = a.basic[p];
+            a.basic[p] = ent; a.nonbasic[q] = lea;
+            if (a.trace && st->trace_len < a.trace_cap) {
+                DevPivot &tr = a.trace[st->trace_len];
+                tr.phase = a.phase; tr.bland = bland ? 1 : 0; tr.min_idx = q; tr.replace = p; tr.entering = ent; tr.leaving = lea;
+            }
+            st->trace_len += 1;
+            st->pivots += 1;
+        }
+        kd = k + 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // u_k / v_k reach L2 before other waves read them (sc1 loads)
+        __syncthreads();
+    }
+    for (int j = tid; j < a.ldt; j += kBtThreads) a.r[j] = r_s[j];
+    for (int i = tid; i < a.ldu; i += kBtThreads) a.xb[i] = xb_s[i];
+    if (tid == 0) {
+        st->kdone = kd;
+        st->bland_steps += blands;
+        if (status != ST_RUNNING) { st->done = 1; st->status = status; }
+    }
+}
+
+// T[i, j] += sum_{k < kdone} U[k][i] * V[k][j]  — in place, one streaming pass.
+// Workgroup = 4 waves x 128 columns (one double2 per lane) over `rows_per_wg` rows; each lane keeps its V column
+// pair for all k in registers, the u scalars of the row block sit in LDS.
+template <int KMAX>
+__global__ __launch_bounds__(kBlock) void k_bt_update(BTArgs a, int rows_per_wg) {
+    __shared__ double us[KMAX][64];
+    const int kd = a.st->kdone;
+    if (kd <= 0) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c2 = (blockIdx.x * kWavesPerBlock + wv) * 64 + lane;  // double2 column index
+    const int ld2 = a.ldt >> 1;
+    const int i0 = blockIdx.y * rows_per_wg;
+    const int nrows = min(rows_per_wg, a.m - i0);
+    for (int idx = threadIdx.x; idx < KMAX * 64; idx += kBlock) {
+        const int k = idx / 64, rr = idx % 64;
+        us[k][rr] = (k < kd && rr < nrows) ? a.U[(size_t)k * a.ldu + i0 + rr] : 0.0;
+    }
+    double2 vv[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        vv[k].x = 0; vv[k].y = 0;
+        if (k < kd && c2 < ld2) vv[k] = reinterpret_cast<const double2 *>(a.V + (size_t)k * a.ldt)[c2];
+    }
+    __syncthreads();
+    if (c2 >= ld2) return;
+    for (int rr = 0; rr < nrows; rr++) {
+        double2 *cell = reinterpret_cast<double2 *>(a.T + (size_t)(i0 + rr) * a.ldt) + c2;
+        double2 t = *cell;
+#pragma unroll
+        for (int k = 0; k < KMAX; k++) {
+            const double u = us[k][rr];
+            t.x += u * vv[k].x;
+            t.y += u * vv[k].y;
+        }
+        *cell = t;
+    }
+}
+
+// ---- launch wrappers ---------------------------------------------------------------------------
+
+bool bt_supported(int m, int nn) { return m <= 4 * kBtThreads && nn <= 4 * kBtThreads; }
+int bt_max_k() { return kBtMaxK; }
+
+void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const size_t lds = (size_t)(a.ldt + a.ldu) * sizeof(double);
+    const int ri = (a.m + kBtThreads - 1) / kBtThreads, cj = (a.ldt + kBtThreads - 1) / kBtThreads;
+    const int sel = (ri <= 1 && cj <= 1) ? 1 : (ri <= 2 && cj <= 2) ? 2 : 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_done = true;
+    }
+    if (sel == 1) hipExtLaunchKernelGGL((k_bt_inner<1, 1>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
+    else if (sel == 2) hipExtLaunchKernelGGL((k_bt_inner<2, 2>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
+    else hipExtLaunchKernelGGL((k_bt_inner<4, 4>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
+}
+void launch_bt_update(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const int ld2 = a.ldt / 2;
+    const int gx = (ld2 + kWavesPerBlock * 64 - 1) / (kWavesPerBlock * 64);
+    int rows = 64;
+    // aim for >= 512 workgroups
+    while (rows > 8 && gx * ((a.m + rows - 1) / rows) < 512) rows >>= 1;
+    dim3 grid(gx, (a.m + rows - 1) / rows);
+    if (a.kmax <= 8) hipExtLaunchKernelGGL((k_bt_update<8>), grid, dim3(kBlock), 0, s, e0, e1, 0, a, rows);
+    else if (a.kmax <= 16) hipExtLaunchKernelGGL((k_bt_update<16>), grid, dim3(kBlock), 0, s, e0, e1, 0, a, rows);
+    else hipExtLaunchKernelGGL((k_bt_update<32>), grid, dim3(kBlock), 0, s, e0, e1, 0, a, rows);
+}
+
+}  // namespace gomilp

@@ -11,7 +11,8 @@ enum : int32_t {
     ST_UNBOUNDED = 2,   // no d_i < 0                         (simplex.go:328-330)
     ST_NEED_BLAND = 3,  // move[replace] <= 0: degenerate     (simplex.go:269)
     ST_MAX_PIVOTS = 4,  // safety cap hit
-    ST_LU_SINGULAR = 5  // exact zero pivot in the final gonum-order LU
+    ST_LU_SINGULAR = 5,  // exact zero pivot in the final gonum-order LU
+    ST_BLAND_FAILED = 6  // replaceBland exhausted its candidates (lp.ErrBland, simplex.go:382)
 };
 
 constexpr int kMaxPartials = 1024;  // per-workgroup partial arg-reductions (grid <= 1024 workgroups)
@@ -44,6 +45,9 @@ struct DevState {
     int32_t nent[2];   // its variable id
     double nrq[2];     // its reduced cost
     int64_t stop_at;   // launches with index >= stop_at are no-ops (set by launch t to t + 1)
+    // blocked tableau pipeline: pivots of the last inner-kernel block whose rank-1 terms the update kernel must apply
+    int32_t kdone;
+    int32_t bland_steps;  // degenerate steps resolved inside the inner kernel (cumulative over the loop)
 };
 
 struct DevPivot {  // mirrors gomilp_pivot
@@ -100,6 +104,24 @@ struct TabArgs {
     DevState *st;
     DevPivot *trace;
     int64_t trace_cap;
+};
+
+// Arguments of the blocked tableau kernels (bt_kernels.hip).
+struct BTArgs {
+    int32_t m, nn;      // rows, nonbasic positions
+    int32_t ldt, ldu;   // padded row length of T / V (multiple of 512 doubles) and of U (multiple of 2)
+    int32_t phase, kmax;
+    double tol;
+    double *T;          // m x ldt, STALE by the rank-1 terms of the running block; updated in place by k_bt_update
+    double *U;          // kmax x ldu : u_k
+    double *V;          // kmax x ldt : v_k'
+    double *r, *xb;
+    int32_t *basic, *nonbasic;
+    DevState *st;
+    DevPivot *trace;
+    int64_t trace_cap;
+    int32_t forced_q, forced_p, forced_nocommit;  // first pivot of the block chosen by the host (set-up pivots)
+    int32_t pad;
 };
 
 // Arguments of the gonum-order LU kernels (final basis solve).

@@ -36,6 +36,8 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "fused") fused_ = v ? 1 : 0;
     else if (key == "lu_blocked") lu_blocked_ = v ? 1 : 0;
     else if (key == "tableau") tableau_ = v ? 1 : 0;
+    else if (key == "blocked") blocked_ = v ? 1 : 0;
+    else if (key == "block_k") { if (v < 1 || v > bt_max_k()) return GOMILP_ERR_BAD_SHAPE; block_k_ = v; }
     else return GOMILP_ERR_BAD_SHAPE;
     return GOMILP_OK;
 }
@@ -641,18 +643,20 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     // 8*[m(n-m) + 2m^2] in two: the tableau wins while n - m < 2m
     const int nn_max = n + 1 - m;
     const bool use_tab = tableau_ && (n - m) < 2 * m && (size_t)tab_ld(nn_max) * sizeof(double) <= 64 * 1024;
-    st->reserved = use_tab ? 2 : ((fused_ && fused_supported(P.ld)) ? 1 : 0);
+    use_bt_ = use_tab && blocked_ && bt_supported(m, nn_max);
+    st->reserved = use_tab ? (use_bt_ ? 3 : 2) : ((fused_ && fused_supported(P.ld)) ? 1 : 0);
     int loop_rc = GOMILP_OK;
     if (use_tab) {
         const int ldt = tab_ld(nn_max);
         if (w.cap_T < (size_t)m * ldt || w.cap_ldt < ldt) {
-            for (double **pp : {&w.T[0], &w.T[1], &w.R[0], &w.R[1], &w.tscratch}) { if (*pp) hipFree(*pp); *pp = nullptr; }
+            for (double **pp : {&w.T[0], &w.T[1], &w.R[0], &w.R[1], &w.tscratch, &w.btU, &w.btV}) { if (*pp) hipFree(*pp); *pp = nullptr; }
             if (w.srcpos) hipFree(w.srcpos); w.srcpos = nullptr;
             const size_t cap = std::max(w.cap_T, (size_t)m * ldt);
             const int cl = std::max(w.cap_ldt, ldt);
             HIP_TRY(dmalloc(&w.T[0], cap)); HIP_TRY(dmalloc(&w.T[1], cap));
             HIP_TRY(dmalloc(&w.R[0], (size_t)cl)); HIP_TRY(dmalloc(&w.R[1], (size_t)cl));
             HIP_TRY(dmalloc(&w.tscratch, (size_t)64 * cl)); HIP_TRY(dmalloc(&w.srcpos, (size_t)cl));
+            HIP_TRY(dmalloc(&w.btU, (size_t)bt_max_k() * (w.cap_ld > P.ld ? w.cap_ld : P.ld))); HIP_TRY(dmalloc(&w.btV, (size_t)bt_max_k() * cl));
             w.cap_T = cap; w.cap_ldt = cl;
         }
         HIP_TRY(hipMemsetAsync(w.R[0], 0, (size_t)w.cap_ldt * sizeof(double), stream_));

@@ -56,6 +56,9 @@ class Engine {
                          int lea, int flags, long long t);
     int solve_tableau(const Problem &P, double tol, std::vector<int32_t> &basic, const std::vector<int32_t> &rho,
                       std::vector<double> &xb, bool feasible, gomilp_lp_stats *st, int *loop_rc);
+    BTArgs make_bt_args(const Problem &P, int phase, double tol, int nn, int kmax);
+    int bt_forced_pivot(const Problem &P, int phase, double tol, int nn, int q, int p, int nocommit);
+    int run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_lp_stats *st);
     void account_samples(gomilp_lp_stats *st, const std::vector<int64_t> &sample_t, int64_t executed, int nk);
     int host_bland(const Problem &P, LPArgs &a, gomilp_lp_stats *st);
     int refresh_xb_y(const Problem &P, const double *cost);
@@ -69,12 +72,13 @@ class Engine {
     std::vector<std::unique_ptr<Problem>> problems_;
     std::unique_ptr<Work> w_;
     // knobs
-    int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 1, tableau_ = 1;
+    int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 1, tableau_ = 1, blocked_ = 1, block_k_ = 16;
     // per-solve state
     int cur_ = 0;   // which Binv buffer is current
     int ycur_ = 0;  // which y buffer is current
     int grid_ratio_ = 1;
-    int tcur_ = 0, rcur_ = 0, ldt_ = 0;  // tableau pipeline: current T / r buffer, row length of T  // workgroups of the last ratio-test kernel (partials to reduce)
+    int tcur_ = 0, rcur_ = 0, ldt_ = 0;
+    bool use_bt_ = false;  // blocked tableau (deferred rank-K updates) instead of one launch per pivot  // tableau pipeline: current T / r buffer, row length of T  // workgroups of the last ratio-test kernel (partials to reduce)
     int64_t launches_ = 0;
     double fs_device_ = 0, fs_host_ = 0;
     std::vector<gomilp_pivot> last_trace_;
@@ -106,6 +110,11 @@ int tab_r_chunks(int m);
 void launch_tab_r(const double *T, int ldt, int m, int nn, const double *cost, const int32_t *basic, const int32_t *nonbasic,
                   double *scratch, double *r, hipStream_t s);
 void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb, double *dvec, double *move, hipStream_t s);
+// bt_kernels.hip
+bool bt_supported(int m, int nn);
+int bt_max_k();
+void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+void launch_bt_update(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 void launch_transpose_in(const double *A, int64_t lda, int m, int n, double *At, int ld, hipStream_t s);
 void launch_col_stats(const double *At, int ld, int m, int n, int32_t *nnz, int32_t *lastrow, int32_t *allone,
                       int32_t *rowflag, hipStream_t s);

@@ -177,6 +177,103 @@ int Engine::run_loop_tab(const Problem &P, int phase, double tol, int nn, gomilp
     return ret;
 }
 
+// ---- blocked tableau (bt_kernels.hip) -----------------------------------------------------------------------
+
+BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int kmax) {
+    Work &w = *w_;
+    BTArgs a;
+    memset(&a, 0, sizeof(a));
+    a.m = P.m; a.nn = nn; a.ldt = ldt_; a.ldu = P.ld; a.phase = phase; a.kmax = kmax; a.tol = tol;
+    a.T = w.T[tcur_]; a.U = w.btU; a.V = w.btV; a.r = w.R[rcur_]; a.xb = w.xb;
+    a.basic = w.basic; a.nonbasic = w.nonbasic; a.st = w.st;
+    a.trace = trace_on_ ? w.trace : nullptr; a.trace_cap = w.trace_cap;
+    a.forced_q = a.forced_p = -1; a.forced_nocommit = 0;
+    return a;
+}
+
+// one host-chosen pivot (Phase-I set-up / artificial exchange): a block of one forced pivot + its update
+int Engine::bt_forced_pivot(const Problem &P, int phase, double tol, int nn, int q, int p, int nocommit) {
+    Work &w = *w_;
+    DevState &hs = *w.st_host;
+    hs.done = 0; hs.status = ST_RUNNING; hs.kdone = 0;
+    sync_state_to_device();
+    BTArgs a = make_bt_args(P, phase, tol, nn, 1);
+    a.forced_q = q; a.forced_p = p; a.forced_nocommit = nocommit;
+    launch_bt_inner(a, stream_, nullptr, nullptr);
+    launch_bt_update(a, stream_, nullptr, nullptr);
+    launches_ += 2;
+    return GOMILP_OK;
+}
+
+// Pivot loop: blocks of block_k_ pivots (one single-workgroup launch) followed by one rank-K update launch.
+int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_lp_stats *st) {
+    Work &w = *w_;
+    DevState &hs = *w.st_host;
+    hs.done = 0; hs.status = ST_RUNNING; hs.pivots = 0; hs.kdone = 0; hs.bland_steps = 0; hs.lu_singular = 0;
+    sync_state_to_device();
+    HIP_TRY(hipEventRecord(w.ev[0], stream_));
+    int ret = GOMILP_OK;
+    const int K = (int)block_k_;
+    const int64_t blocks_per_chunk = std::max<int64_t>(1, chunk_ / K);
+    const bool sampling = sample_events_ > 0;
+    int64_t block_no = 0;
+    for (;;) {
+        const int64_t before = hs.pivots;
+        size_t nsamp = 0;
+        for (int64_t bkk = 0; bkk < blocks_per_chunk; bkk++, block_no++) {
+            int kmax = K;
+            if (max_pivots_ > 0) kmax = (int)std::max<int64_t>(1, std::min<int64_t>(K, max_pivots_ - before - bkk * K));
+            BTArgs a = make_bt_args(P, phase, tol, nn, kmax);
+            a.kmax = K;  // the update kernel is instantiated for the configured block size
+            BTArgs ai = a; ai.kmax = kmax;
+            const bool sample = sampling && (block_no % std::max<int64_t>(1, sample_events_ / K) == 0);
+            hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+            if (sample) {
+                while (w.sample_ev.size() < (nsamp + 1) * 6) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); w.sample_ev.push_back(ev); }
+                for (int k = 0; k < 4; k++) e[k] = w.sample_ev[nsamp * 6 + k];
+                nsamp++;
+            }
+            launch_bt_inner(ai, stream_, e[0], e[1]);
+            launch_bt_update(a, stream_, e[2], e[3]);
+            launches_ += 2;
+        }
+        HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(hipGetLastError());
+        const int64_t executed = hs.pivots - before;
+        if (st && nsamp && executed == blocks_per_chunk * K) {  // only chunks made of full blocks are samples
+            for (size_t s = 0; s < nsamp; s++) {
+                float ms0 = 0, ms1 = 0;
+                if (hipEventElapsedTime(&ms0, w.sample_ev[s * 6], w.sample_ev[s * 6 + 1]) != hipSuccess) continue;
+                if (hipEventElapsedTime(&ms1, w.sample_ev[s * 6 + 2], w.sample_ev[s * 6 + 3]) != hipSuccess) continue;
+                st->pivot_kernel_seconds[0] += ms0 * 1e-3;  // inner kernel: K pivots
+                st->pivot_kernel_seconds[2] += ms1 * 1e-3;  // rank-K update
+                st->pivot_kernel_seconds[1] += 1.0;         // sampled blocks
+                st->pivot_kernel_seconds[3] += (double)K;   // sampled pivots
+            }
+        }
+        if (!hs.done) {
+            if (max_pivots_ > 0 && hs.pivots >= max_pivots_) { ret = GOMILP_ERR_UNSUPPORTED; break; }
+            continue;
+        }
+        if (hs.status == ST_OPTIMAL) break;
+        if (hs.status == ST_UNBOUNDED) { ret = GOMILP_ERR_UNBOUNDED; break; }
+        if (hs.status == ST_BLAND_FAILED) { ret = GOMILP_ERR_BLAND; break; }
+        ret = GOMILP_ERR_DEVICE;
+        break;
+    }
+    HIP_TRY(hipEventRecord(w.ev[1], stream_));
+    HIP_TRY(hipEventSynchronize(w.ev[1]));
+    float ms = 0;
+    hipEventElapsedTime(&ms, w.ev[0], w.ev[1]);
+    if (st) {
+        st->seconds_pivot_loop += ms * 1e-3;
+        st->bland_steps += hs.bland_steps;
+        if (phase == 1) st->pivots_phase1 += hs.pivots; else st->pivots_phase2 += hs.pivots;
+    }
+    return ret;
+}
+
 // Phase I / Phase II on the tableau pipeline.  Called by Engine::solve after the initial (slack) basis is known.
 // On return `basic` / `xb` hold the final basis positions and updated x_B; *loop_rc is the Phase-II loop result.
 int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &basic, const std::vector<int32_t> &rho,
@@ -227,7 +324,9 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         launches_++;
         const double dp = art[rho[minidx]];
         const int slack = basic[minidx];
-        if ((rc = tab_forced_pivot(P, 1, 1e-10, nn, qa, n, 0.0, (int)minidx, dp, xb[minidx], slack, 4, 0)) != GOMILP_OK) return rc;
+        if (use_bt_) rc = bt_forced_pivot(P, 1, 1e-10, nn, qa, (int)minidx, 1);
+        else rc = tab_forced_pivot(P, 1, 1e-10, nn, qa, n, 0.0, (int)minidx, dp, xb[minidx], slack, 4, 0);
+        if (rc != GOMILP_OK) return rc;
         basic[minidx] = n;
         nonbasic[qa] = slack;  // ascending order is preserved: every structural id < slack id < n
         if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return rc;
@@ -236,7 +335,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
         for (int i = 0; i < m; i++) if (w.h_vec[i] < -1e-13) return GOMILP_ERR_PANIC;  // simplex.go:155-158
-        rc = run_loop_tab(P, 1, 1e-10, nn, st);
+        rc = use_bt_ ? run_loop_bt(P, 1, 1e-10, nn, st) : run_loop_tab(P, 1, 1e-10, nn, st);
         if (rc == GOMILP_ERR_DEVICE) return rc;
         if (rc != GOMILP_OK) { st->wrapped_status = rc; return GOMILP_ERR_PHASE1_WRAPPED; }  // :557-559
         HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
@@ -276,7 +375,9 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
                     if (v < -1e-13) feas = false;
                 }
                 if (!feas) continue;
-                if ((rc = tab_forced_pivot(P, 1, 1e-10, nn, jp, cv.first, 0.0, added, dpv, xb[added], n, 4, 0)) != GOMILP_OK) return rc;
+                if (use_bt_) rc = bt_forced_pivot(P, 1, 1e-10, nn, jp, added, 1);
+                else rc = tab_forced_pivot(P, 1, 1e-10, nn, jp, cv.first, 0.0, added, dpv, xb[added], n, 4, 0);
+                if (rc != GOMILP_OK) return rc;
                 basic[added] = cv.first;
                 nonbasic[jp] = n;
                 exchanged = true;
@@ -312,7 +413,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
     // ---- Phase II ----
     launch_tab_r(w.T[tcur_], ldt_, m, nn, P.dc, w.basic, w.nonbasic, w.tscratch, w.R[rcur_], stream_);
     launches_ += 2;
-    *loop_rc = run_loop_tab(P, 2, tol, nn, st);
+    *loop_rc = use_bt_ ? run_loop_bt(P, 2, tol, nn, st) : run_loop_tab(P, 2, tol, nn, st);
     return GOMILP_OK;
 }
 

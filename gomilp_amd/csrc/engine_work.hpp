@@ -68,7 +68,8 @@ struct Engine::Work {
     unsigned int *pi_price = nullptr, *pi_ratio = nullptr, *lpl[2] = {nullptr, nullptr}, *lpr[2] = {nullptr, nullptr};
     unsigned int *pv_price = nullptr, *pb_ratio = nullptr;
     double *pd_ratio = nullptr, *px_ratio = nullptr;
-    double *T[2] = {nullptr, nullptr}, *R[2] = {nullptr, nullptr}, *tscratch = nullptr;  // tableau pipeline
+    double *T[2] = {nullptr, nullptr}, *R[2] = {nullptr, nullptr}, *tscratch = nullptr;  // tableau pipelines
+    double *btU = nullptr, *btV = nullptr;  // blocked tableau: rank-1 terms of the running block
     int32_t *srcpos = nullptr;
     size_t cap_T = 0;  // doubles per T buffer
     int cap_ldt = 0;
@@ -97,7 +98,7 @@ struct Engine::Work {
         for (auto **p : {&pi_price, &pi_ratio, &lpl[0], &lpl[1], &lpr[0], &lpr[1], &pv_price, &pb_ratio}) { if (*p) hipFree(*p); *p = nullptr; }
         if (pd_ratio) hipFree(pd_ratio); pd_ratio = nullptr;
         if (px_ratio) hipFree(px_ratio); px_ratio = nullptr;
-        for (double **p : {&T[0], &T[1], &R[0], &R[1], &tscratch}) { if (*p) hipFree(*p); *p = nullptr; }
+        for (double **p : {&T[0], &T[1], &R[0], &R[1], &tscratch, &btU, &btV}) { if (*p) hipFree(*p); *p = nullptr; }
         if (srcpos) hipFree(srcpos); srcpos = nullptr;
         cap_T = 0; cap_ldt = 0;
         if (st) hipFree(st); st = nullptr;

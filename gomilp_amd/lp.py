@@ -125,7 +125,7 @@ class LPResult:
 
 def _stats_dict(s: Stats) -> dict:
     d = {k: getattr(s, k) for k, _ in Stats._fields_ if k not in ("pivot_kernel_seconds", "reserved")}
-    d["pipeline"] = {0: "three-kernel", 1: "fused", 2: "tableau"}.get(s.reserved, str(s.reserved))
+    d["pipeline"] = {0: "three-kernel", 1: "fused", 2: "tableau", 3: "blocked"}.get(s.reserved, str(s.reserved))
     d["pivot_kernel_seconds"] = list(s.pivot_kernel_seconds)
     return d
 

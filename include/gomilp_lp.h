@@ -50,7 +50,8 @@ typedef struct gomilp_lp_stats {
     int32_t phase1_used;        /* 1 when the initial basis was infeasible and Phase I ran */
     int32_t device_id;
     int32_t wrapped_status;     /* inner status when the result is GOMILP_ERR_PHASE1_WRAPPED */
-    int32_t reserved;           /* pivot pipeline that ran: 0 three-kernel, 1 fused two-kernel, 2 single-kernel tableau */
+    int32_t reserved;           /* pivot pipeline that ran: 0 three-kernel, 1 fused two-kernel, 2 single-kernel tableau,
+                                   3 blocked tableau (deferred rank-K updates) */
     double seconds_total;       /* host wall clock of the call (upload included for the flat call) */
     double seconds_upload;      /* host->device copies + layout conversion */
     double seconds_pivot_loop;  /* HIP-event time of all pivot-loop kernels (Phase I + II) */

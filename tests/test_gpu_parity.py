@@ -73,15 +73,19 @@ def test_dense_lp_matches_oracle_bitwise(ctx, m, seed):
     assert g.stats["pivots_phase2"] > 0
 
 
+PIPE_KNOBS = {"blocked": dict(tableau=1, blocked=1), "tableau": dict(tableau=1, blocked=0),
+              "fused": dict(tableau=0, fused=1), "three-kernel": dict(tableau=0, fused=0)}
+
+
 @pytest.mark.parametrize("m,seed,pipe", [(128, 9, "fused"), (128, 9, "three-kernel"), (256, 11, "fused"), (512, 3, "fused"),
-                                         (512, 3, "three-kernel"), (512, 3, "tableau"), (300, 5, "tableau")])
+                                         (512, 3, "three-kernel"), (512, 3, "tableau"), (300, 5, "tableau"),
+                                         (512, 3, "blocked"), (300, 5, "blocked"), (64, 7, "blocked")])
 def test_all_pivot_pipelines_match_oracle(m, seed, pipe):
-    """Three device formulations of the pivot: single-kernel tableau (default when n-m < 2m), fused
-    two-kernel revised simplex (ld = 128*NV), three-kernel revised simplex (any shape).  Each must reproduce the
-    oracle's pivot sequence and the reference's bits."""
+    """Four device formulations of the pivot: blocked tableau with deferred rank-K updates (default when
+    n-m < 2m), single-kernel tableau, fused two-kernel revised simplex (ld = 128*NV), three-kernel revised simplex
+    (any shape).  Each must reproduce the oracle's pivot sequence and the reference's bits."""
     c, A, b = synth.dense_lp_standard_form(m, seed)
-    knobs = {"tableau": dict(tableau=1), "fused": dict(tableau=0, fused=1), "three-kernel": dict(tableau=0, fused=0)}[pipe]
-    cx = lp.Context(chunk=16, **knobs)
+    cx = lp.Context(chunk=16, block_k=8 if pipe == "blocked" else 16, **PIPE_KNOBS[pipe])
     try:
         g, o = _check_against_oracle(cx, c, A, b)
         assert g.stats["pipeline"] == pipe
@@ -89,12 +93,11 @@ def test_all_pivot_pipelines_match_oracle(m, seed, pipe):
         cx.close()
 
 
-@pytest.mark.parametrize("pipe", ["tableau", "three-kernel"])
+@pytest.mark.parametrize("pipe", ["blocked", "tableau", "three-kernel"])
 @pytest.mark.parametrize("signs", [(-1,), (1, -1, 1)])
 def test_children_on_each_pipeline(pipe, signs):
     c, A, b = _child(24, 3, signs)
-    knobs = {"tableau": dict(tableau=1), "three-kernel": dict(tableau=0, fused=0)}[pipe]
-    cx = lp.Context(chunk=8, **knobs)
+    cx = lp.Context(chunk=8, **PIPE_KNOBS[pipe])
     try:
         g, o = _check_against_oracle(cx, c, A, b)
         assert g.stats["pipeline"] == pipe
