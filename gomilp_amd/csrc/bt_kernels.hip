@@ -55,9 +55,22 @@ __device__ __forceinline__ void bt_block_argmin(BtCand &a, BtCand *sm) {
     __syncthreads();
 }
 
-// RI / CJ: rows / columns per thread (m <= RI*1024, n-m <= CJ*1024)
-template <int RI, int CJ>
+// RI / CJ: rows / columns per thread (m <= RI*1024, n-m <= CJ*1024).
+// KREG > 0: the block's rank-1 terms of a thread's OWN rows / columns live in registers (newest first, shifted
+// every pivot), foreign scalars travel through LDS — the single CU that runs this kernel then touches global memory
+// only for the stale column, the stale row and the u_k / v_k stores.  KREG = 0: terms are re-read from global (L2).
+template <int RI, int CJ, int KREG>
 __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
+    constexpr int KR = KREG > 0 ? KREG : 1;
+    double ureg[RI][KR], vreg[CJ][KR];
+#pragma unroll
+    for (int s = 0; s < RI; s++)
+#pragma unroll
+        for (int j = 0; j < KR; j++) ureg[s][j] = 0;
+#pragma unroll
+    for (int s = 0; s < CJ; s++)
+#pragma unroll
+        for (int j = 0; j < KR; j++) vreg[s][j] = 0;
     extern __shared__ __attribute__((aligned(16))) double sh[];
     double *r_s = sh;                 // ldt
     double *xb_s = sh + a.ldt;        // ldu
@@ -78,7 +91,20 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
 
     // column q of the current tableau for this thread's rows
     auto column = [&](int q, int k, double (&dcol)[RI]) {
-        if (tid < k) vq[tid] = __hip_atomic_load(a.V + (size_t)tid * a.ldt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (KREG > 0) {
+            // the owner of column q publishes its K newest-first v entries (static register indices)
+            if (tid == (q & (kBtThreads - 1))) {
+                const int sq = q / kBtThreads;
+#pragma unroll
+                for (int s = 0; s < CJ; s++)
+                    if (s == sq) {
+#pragma unroll
+                        for (int j = 0; j < KR; j++) vq[j] = vreg[s][j];
+                    }
+            }
+        } else if (tid < k) {
+            vq[tid] = __hip_atomic_load(a.V + (size_t)tid * a.ldt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < RI; s++) {
@@ -86,7 +112,19 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
             double d = 0;
             if (i < a.m) {
                 d = a.T[(size_t)i * a.ldt + q];
-                for (int j = 0; j < k; j++) d += a.U[(size_t)j * a.ldu + i] * vq[j];
+                if (KREG > 0) {
+#pragma unroll
+                    for (int j = 0; j < KR; j++) d += ureg[s][j] * vq[j];
+                } else {
+                    // batches of 8 independent loads: a plain `for (j < k)` serialises one L2 round trip per term
+                    for (int j0 = 0; j0 < k; j0 += 8) {
+                        double uu[8];
+#pragma unroll
+                        for (int t = 0; t < 8; t++) uu[t] = (j0 + t < k) ? a.U[(size_t)(j0 + t) * a.ldu + i] : 0.0;
+#pragma unroll
+                        for (int t = 0; t < 8; t++) d += uu[t] * ((j0 + t < k) ? vq[j0 + t] : 0.0);
+                    }
+                }
             }
             dcol[s] = d;
         }
@@ -182,7 +220,19 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
             dpv = s_bcast[0];
         }
         // ---- row p of the current tableau for this thread's columns
-        if (tid < k) up[tid] = __hip_atomic_load(a.U + (size_t)tid * a.ldu + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (KREG > 0) {
+            if (tid == (p & (kBtThreads - 1))) {
+                const int sp = p / kBtThreads;
+#pragma unroll
+                for (int s = 0; s < RI; s++)
+                    if (s == sp) {
+#pragma unroll
+                        for (int j = 0; j < KR; j++) up[j] = ureg[s][j];
+                    }
+            }
+        } else if (tid < k) {
+            up[tid] = __hip_atomic_load(a.U + (size_t)tid * a.ldu + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
         const double mult = rq / dpv;
         const double theta = xb_s[p] / dpv;
@@ -196,11 +246,28 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
                 double v = 0;
                 if (j < a.nn) {
                     v = a.T[(size_t)p * a.ldt + j];
-                    for (int jj = 0; jj < k; jj++) v += up[jj] * a.V[(size_t)jj * a.ldt + j];
+                    if (KREG > 0) {
+#pragma unroll
+                        for (int jj = 0; jj < KR; jj++) v += up[jj] * vreg[s][jj];
+                    } else {
+                        for (int j0 = 0; j0 < k; j0 += 8) {
+                            double vv8[8];
+#pragma unroll
+                            for (int t = 0; t < 8; t++) vv8[t] = (j0 + t < k) ? a.V[(size_t)(j0 + t) * a.ldt + j] : 0.0;
+#pragma unroll
+                            for (int t = 0; t < 8; t++) v += ((j0 + t < k) ? up[j0 + t] : 0.0) * vv8[t];
+                        }
+                    }
                     // reduced costs (positional): r_j - (r_q/d_p) v_j ; the leaving variable takes slot q
                     r_s[j] = (j == q) ? -mult : r_s[j] - mult * v;
                 }
-                Vk[j] = (j == q) ? dpv + 1.0 : v;
+                const double vprime = (j == q) ? dpv + 1.0 : v;
+                Vk[j] = vprime;
+                if (KREG > 0) {
+#pragma unroll
+                    for (int jj = KR - 1; jj > 0; jj--) vreg[s][jj] = vreg[s][jj - 1];
+                    vreg[s][0] = vprime;
+                }
             }
         }
 #pragma unroll
@@ -213,6 +280,11 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
                     xb_s[i] = (i == p) ? theta : xb_s[i] - theta * dcol[s];
                 }
                 Uk[i] = u;
+                if (KREG > 0) {
+#pragma unroll
+                    for (int jj = KR - 1; jj > 0; jj--) ureg[s][jj] = ureg[s][jj - 1];
+                    ureg[s][0] = u;
+                }
             }
         }
         if (tid == 0 && !(forced && a.forced_nocommit)) {  // simplex.go:280
@@ -226,7 +298,7 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
             st->pivots += 1;
         }
         kd = k + 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // u_k / v_k reach L2 before other waves read them (sc1 loads)
+        if (KREG == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // u_k / v_k reach L2 before the sc1 loads of other waves
         __syncthreads();
     }
     for (int j = tid; j < a.ldt; j += kBtThreads) a.r[j] = r_s[j];
@@ -278,21 +350,37 @@ __global__ __launch_bounds__(kBlock) void k_bt_update(BTArgs a, int rows_per_wg)
 
 // ---- launch wrappers ---------------------------------------------------------------------------
 
-bool bt_supported(int m, int nn) { return m <= 4 * kBtThreads && nn <= 4 * kBtThreads; }
+bool bt_supported(int m, int nn) { return m <= 8 * kBtThreads && nn + 511 <= 8 * kBtThreads; }
 int bt_max_k() { return kBtMaxK; }
 
+// register-resident block terms cost (RI + CJ) * KREG doubles per thread; with 16 waves per workgroup the budget is
+// 128 VGPRs, so KREG = 8 fits for RI = CJ <= 2 (m, n-m <= 2048)
+int bt_reg_k(int m, int ldt) {
+    const int ri = (m + kBtThreads - 1) / kBtThreads, cj = (ldt + kBtThreads - 1) / kBtThreads;
+    return (ri <= 2 && cj <= 2) ? 8 : 0;
+}
 void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const size_t lds = (size_t)(a.ldt + a.ldu) * sizeof(double);
     const int ri = (a.m + kBtThreads - 1) / kBtThreads, cj = (a.ldt + kBtThreads - 1) / kBtThreads;
-    const int sel = (ri <= 1 && cj <= 1) ? 1 : (ri <= 2 && cj <= 2) ? 2 : 4;
+    const int sel = (ri <= 1 && cj <= 1) ? 1 : (ri <= 2 && cj <= 2) ? 2 : (ri <= 4 && cj <= 4) ? 4 : 8;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner<4, 4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner<8, 8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
         attr_done = true;
     }
-    if (sel == 1) hipExtLaunchKernelGGL((k_bt_inner<1, 1>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
-    else if (sel == 2) hipExtLaunchKernelGGL((k_bt_inner<2, 2>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
-    else hipExtLaunchKernelGGL((k_bt_inner<4, 4>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
+    const bool reg = a.kmax <= 8 && bt_reg_k(a.m, a.ldt) > 0;
+    if (sel == 1) {
+        if (reg) hipExtLaunchKernelGGL((k_bt_inner<1, 1, 8>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
+        else hipExtLaunchKernelGGL((k_bt_inner<1, 1, 0>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
+    } else if (sel == 2) {
+        if (reg) hipExtLaunchKernelGGL((k_bt_inner<2, 2, 8>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
+        else hipExtLaunchKernelGGL((k_bt_inner<2, 2, 0>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
+    } else if (sel == 4) {
+        hipExtLaunchKernelGGL((k_bt_inner<4, 4, 0>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
+    } else {
+        hipExtLaunchKernelGGL((k_bt_inner<8, 8, 0>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
+    }
 }
 void launch_bt_update(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const int ld2 = a.ldt / 2;

@@ -37,7 +37,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "lu_blocked") lu_blocked_ = v ? 1 : 0;
     else if (key == "tableau") tableau_ = v ? 1 : 0;
     else if (key == "blocked") blocked_ = v ? 1 : 0;
-    else if (key == "block_k") { if (v < 1 || v > bt_max_k()) return GOMILP_ERR_BAD_SHAPE; block_k_ = v; }
+    else if (key == "block_k") { if (v < 0 || v > bt_max_k()) return GOMILP_ERR_BAD_SHAPE; block_k_ = v; }
     else return GOMILP_ERR_BAD_SHAPE;
     return GOMILP_OK;
 }

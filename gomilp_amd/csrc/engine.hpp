@@ -72,7 +72,7 @@ class Engine {
     std::vector<std::unique_ptr<Problem>> problems_;
     std::unique_ptr<Work> w_;
     // knobs
-    int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 1, tableau_ = 1, blocked_ = 1, block_k_ = 16;
+    int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 1, tableau_ = 1, blocked_ = 1, block_k_ = 0;  // block_k_ 0 = auto
     // per-solve state
     int cur_ = 0;   // which Binv buffer is current
     int ycur_ = 0;  // which y buffer is current
@@ -113,6 +113,7 @@ void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb
 // bt_kernels.hip
 bool bt_supported(int m, int nn);
 int bt_max_k();
+int bt_reg_k(int m, int ldt);
 void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 void launch_bt_update(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 void launch_transpose_in(const double *A, int64_t lda, int m, int n, double *At, int ld, hipStream_t s);

@@ -213,7 +213,8 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
     sync_state_to_device();
     HIP_TRY(hipEventRecord(w.ev[0], stream_));
     int ret = GOMILP_OK;
-    const int K = (int)block_k_;
+    // block size: 8 when the block's rank-1 terms fit in registers (bt_kernels.hip), else 16
+    const int K = block_k_ > 0 ? (int)block_k_ : (bt_reg_k(P.m, ldt_) > 0 ? 8 : 16);
     const int64_t blocks_per_chunk = std::max<int64_t>(1, chunk_ / K);
     const bool sampling = sample_events_ > 0;
     int64_t block_no = 0;

@@ -79,13 +79,14 @@ PIPE_KNOBS = {"blocked": dict(tableau=1, blocked=1), "tableau": dict(tableau=1, 
 
 @pytest.mark.parametrize("m,seed,pipe", [(128, 9, "fused"), (128, 9, "three-kernel"), (256, 11, "fused"), (512, 3, "fused"),
                                          (512, 3, "three-kernel"), (512, 3, "tableau"), (300, 5, "tableau"),
-                                         (512, 3, "blocked"), (300, 5, "blocked"), (64, 7, "blocked")])
+                                         (512, 3, "blocked"), (300, 5, "blocked"), (64, 7, "blocked"), (300, 5, "blocked16")])
 def test_all_pivot_pipelines_match_oracle(m, seed, pipe):
     """Four device formulations of the pivot: blocked tableau with deferred rank-K updates (default when
     n-m < 2m), single-kernel tableau, fused two-kernel revised simplex (ld = 128*NV), three-kernel revised simplex
     (any shape).  Each must reproduce the oracle's pivot sequence and the reference's bits."""
     c, A, b = synth.dense_lp_standard_form(m, seed)
-    cx = lp.Context(chunk=16, block_k=8 if pipe == "blocked" else 16, **PIPE_KNOBS[pipe])
+    cx = lp.Context(chunk=16, block_k=16 if pipe == "blocked16" else 0, **PIPE_KNOBS[pipe.replace("16", "")])
+    pipe = pipe.replace("16", "")
     try:
         g, o = _check_against_oracle(cx, c, A, b)
         assert g.stats["pipeline"] == pipe
