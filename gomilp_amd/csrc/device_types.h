@@ -134,6 +134,7 @@ struct LUArgs {
     unsigned int *pl[2];        // logical position of the candidate
     unsigned int *pr[2];        // physical row of the candidate
     DevState *st;
+    const int32_t *unit_row;    // per column: row of the 1 when the column of ab is a unit vector, else -1 (nullable)
 };
 
 }  // namespace gomilp

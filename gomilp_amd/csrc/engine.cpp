@@ -72,6 +72,7 @@ int Engine::ensure_work(int m, int ncols) {
     HIP_TRY(dmalloc(&w.yscratch, (size_t)64 * nld));
     HIP_TRY(dmalloc(&w.basic, (size_t)nm)); HIP_TRY(dmalloc(&w.nonbasic, (size_t)nc));
     HIP_TRY(dmalloc(&w.lpos, (size_t)nm)); HIP_TRY(dmalloc(&w.rowstep, (size_t)nm)); HIP_TRY(dmalloc(&w.rho, (size_t)nm));
+    HIP_TRY(dmalloc(&w.unitrow, (size_t)nm));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_W), (size_t)nm * nld * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_vec), (size_t)std::max(nld, nc) * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_idx), (size_t)std::max(nm, nc) * sizeof(int32_t), hipHostMallocDefault));
@@ -506,10 +507,22 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     const double tf0 = now_s();
     const int m = P.m, ldw = P.ld;
     launch_gather_w(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
+    // unit columns of ab (from the column statistics of the upload): the blocked LU skips their elimination steps
+    HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    {
+        std::vector<int32_t> ur(m);
+        for (int pos = 0; pos < m; pos++) {
+            const int j = w.h_idx[pos];
+            ur[pos] = (j < P.n && P.nnz[j] == 1 && P.allone[j]) ? P.lastrow[j] : -1;
+        }
+        HIP_TRY(hipMemcpy(w.unitrow, ur.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     LUArgs a;
     a.W = w.W; a.ldw = ldw; a.m = m; a.lpos = w.lpos; a.rowstep = w.rowstep;
     for (int t = 0; t < 2; t++) { a.pk[t] = w.lpk[t]; a.pl[t] = w.lpl[t]; a.pr[t] = w.lpr[t]; }
     a.st = w.st;
+    a.unit_row = w.unitrow;
     w.st_host->lu_singular = 0;
     sync_state_to_device();
     if (lu_blocked_ && lu_blocked_supported(m)) launches_ += launch_lu_blocked(a, w.rho, stream_) + 1;

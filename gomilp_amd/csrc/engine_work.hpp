@@ -71,6 +71,7 @@ struct Engine::Work {
     double *T[2] = {nullptr, nullptr}, *R[2] = {nullptr, nullptr}, *tscratch = nullptr;  // tableau pipelines
     double *btU = nullptr, *btV = nullptr;  // blocked tableau: rank-1 terms of the running block
     int32_t *srcpos = nullptr;
+    int32_t *unitrow = nullptr;  // final solve: unit-column rows per basis position
     size_t cap_T = 0;  // doubles per T buffer
     int cap_ldt = 0;
     DevState *st = nullptr;
@@ -86,7 +87,7 @@ struct Engine::Work {
     void release() {
         for (auto &p : binv) { if (p) hipFree(p); p = nullptr; }
         for (double **p : {&xb, &yb[0], &yb[1], &dvec, &move, &rvec, &yscratch, &W}) { if (*p) hipFree(*p); *p = nullptr; }
-        for (int32_t **p : {&basic, &nonbasic, &lpos, &rowstep, &rho}) { if (*p) hipFree(*p); *p = nullptr; }
+        for (int32_t **p : {&basic, &nonbasic, &lpos, &rowstep, &rho, &unitrow}) { if (*p) hipFree(*p); *p = nullptr; }
         if (h_W) hipHostFree(h_W); h_W = nullptr;
         if (h_vec) hipHostFree(h_vec); h_vec = nullptr;
         if (h_idx) hipHostFree(h_idx); h_idx = nullptr;

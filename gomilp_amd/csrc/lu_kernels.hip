@@ -44,6 +44,8 @@ __global__ __launch_bounds__(T) void k_lu_panel(LUArgs a, int k0, int nb, int32_
     __shared__ double prow[2][NB];
     __shared__ unsigned long long sk[NW];
     __shared__ unsigned int sl[NW], sr[NW];
+    __shared__ unsigned char s_active[T * RPT];  // row still available as a pivot row
+    __shared__ int s_jp[2];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     PanelRow<NB> rows[RPT];
 #define GOMILP_FOR_ROWS(F)                              \
@@ -59,27 +61,45 @@ __global__ __launch_bounds__(T) void k_lu_panel(LUArgs a, int k0, int nb, int32_
         for (int c = 0; c < NB; c++) row.v[c] = (row.act && c < nb) ? src[c] : 0.0;
     };
     GOMILP_FOR_ROWS(load_row);
+    auto mark_row = [&](PanelRow<NB> &row, int) { s_active[row.R] = row.act ? 1 : 0; };
+    GOMILP_FOR_ROWS(mark_row);
+    __syncthreads();
 #pragma unroll 1
     for (int s = 0; s < nb; s++) {
         const int k = k0 + s;
-        unsigned long long bk = ~0ull;
-        unsigned int bl = 0xFFFFFFFFu, br = 0xFFFFFFFFu;
-        auto cand = [&](PanelRow<NB> &row, int) {
-            if (row.act) lu_take3(bk, bl, br, ordkey(-fabs(row.v[0])), (unsigned int)row.lp, (unsigned int)row.R);
-        };
-        GOMILP_FOR_ROWS(cand);
+        // Unit-column fast path.  If column k of ab is the unit vector e_r and row r has not been a pivot row yet, no
+        // earlier step can have touched the column (fill-in in column k only comes through row r), so Idamax picks
+        // row r (pivot exactly 1), every multiplier is exactly 0 and the step is pure bookkeeping: no reduction, no
+        // elimination arithmetic.  Most basis columns of a B&B relaxation are slack columns, so most steps are trivial.
+        // (s_active[ur] is only cleared between this step's two barriers, i.e. after every thread took this test.)
+        const int ur = a.unit_row ? a.unit_row[k] : -1;
+        const bool trivial = (ur >= 0) && (s_active[ur] != 0);
+        int P, jp;
+        if (!trivial) {
+            unsigned long long bk = ~0ull;
+            unsigned int bl = 0xFFFFFFFFu, br = 0xFFFFFFFFu;
+            auto cand = [&](PanelRow<NB> &row, int) {
+                if (row.act) lu_take3(bk, bl, br, ordkey(-fabs(row.v[0])), (unsigned int)row.lp, (unsigned int)row.R);
+            };
+            GOMILP_FOR_ROWS(cand);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            unsigned long long k2 = __shfl_xor(bk, o, 64);
-            unsigned int l2 = __shfl_xor(bl, o, 64), r2x = __shfl_xor(br, o, 64);
-            lu_take3(bk, bl, br, k2, l2, r2x);
+            for (int o = 32; o > 0; o >>= 1) {
+                unsigned long long k2 = __shfl_xor(bk, o, 64);
+                unsigned int l2 = __shfl_xor(bl, o, 64), r2x = __shfl_xor(br, o, 64);
+                lu_take3(bk, bl, br, k2, l2, r2x);
+            }
+            if (lane == 0) { sk[w] = bk; sl[w] = bl; sr[w] = br; }
+            __syncthreads();
+            bk = sk[0]; bl = sl[0]; br = sr[0];
+#pragma unroll
+            for (int t = 1; t < NW; t++) lu_take3(bk, bl, br, sk[t], sl[t], sr[t]);
+            P = (int)br; jp = (int)bl;
+        } else {
+            auto tell = [&](PanelRow<NB> &row, int) { if (row.act && row.R == ur) s_jp[s & 1] = row.lp; };
+            GOMILP_FOR_ROWS(tell);
+            __syncthreads();
+            P = ur; jp = s_jp[s & 1];
         }
-        if (lane == 0) { sk[w] = bk; sl[w] = bl; sr[w] = br; }
-        __syncthreads();
-        bk = sk[0]; bl = sl[0]; br = sr[0];
-#pragma unroll
-        for (int t = 1; t < NW; t++) lu_take3(bk, bl, br, sk[t], sl[t], sr[t]);
-        const int P = (int)br, jp = (int)bl;
         double *pr = prow[s & 1];
         auto publish = [&](PanelRow<NB> &row, int) {
             if (!row.act) return;
@@ -89,6 +109,7 @@ __global__ __launch_bounds__(T) void k_lu_panel(LUArgs a, int k0, int nb, int32_
 #pragma unroll
                 for (int c = 0; c < NB; c++) { pr[c] = row.v[c]; if (c < nb - s) dst[c] = row.v[c]; }
                 row.act = false; row.lp = k;
+                s_active[P] = 0;
                 a.rowstep[P] = k; pivrow[k] = P;
             } else if (row.lp == k) {
                 row.lp = jp;  // the row that sat at logical k moves to jp (dlaswp.go)
@@ -97,16 +118,17 @@ __global__ __launch_bounds__(T) void k_lu_panel(LUArgs a, int k0, int nb, int32_
         GOMILP_FOR_ROWS(publish);
         __syncthreads();
         const double piv = pr[0];
-        const bool singular = (piv == 0);  // dgetf2.go:48-49: no scaling, the rank-1 update is a no-op
+        const bool singular = (!trivial) && (piv == 0);  // dgetf2.go:48-49: no scaling, the rank-1 update is a no-op
         if (singular && tid == 0) a.st->lu_singular = 1;
+        const bool skip = trivial || singular;
         const double rinv = 1.0 / piv;
         auto elim = [&](PanelRow<NB> &row, int) {
             if (!row.act) return;
-            const double l = singular ? row.v[0] : __dmul_rn(row.v[0], rinv);
-            a.W[(size_t)row.R * a.ldw + k] = l;
+            const double l = skip ? row.v[0] : __dmul_rn(row.v[0], rinv);
+            if (!trivial) a.W[(size_t)row.R * a.ldw + k] = l;  // trivial: the entry is the 0 already in W
             const double nl = -l;
 #pragma unroll
-            for (int c = 1; c < NB; c++) row.v[c - 1] = singular ? row.v[c] : __dadd_rn(__dmul_rn(nl, pr[c]), row.v[c]);
+            for (int c = 1; c < NB; c++) row.v[c - 1] = skip ? row.v[c] : __dadd_rn(__dmul_rn(nl, pr[c]), row.v[c]);
             row.v[NB - 1] = 0.0;
         };
         GOMILP_FOR_ROWS(elim);

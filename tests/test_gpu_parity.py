@@ -169,7 +169,7 @@ def test_exactly_constrained_m_equals_n(ctx):
     _check_against_oracle(ctx, c, A, b)
 
 
-@pytest.mark.parametrize("m,seed", [(200, 2), (700, 3), (1024, 1), (2048, 2)])
+@pytest.mark.parametrize("m,seed", [(200, 2), (448, 3), (512, 3), (513, 3), (700, 3), (1024, 1), (2048, 2)])
 def test_blocked_lu_equals_per_column_lu_bitwise(m, seed):
     """The blocked final solve (lu_kernels.hip: register panel + trailing rank-nb update) must give the same bits
     as the one-launch-per-column schedule (simplex_kernels.hip k_lu_step), which the small cases pin to the oracle."""
@@ -186,6 +186,16 @@ def test_blocked_lu_equals_per_column_lu_bitwise(m, seed):
     assert res[0].status == lp.OK == res[1].status
     assert np.array_equal(res[0].basis, res[1].basis)
     assert np.array_equal(res[0].x, res[1].x) and res[0].z == res[1].z
+    # the unit-column fast path of the panel kernel must be deterministic (it once raced: repeat the solve)
+    cx = lp.Context()
+    try:
+        rl = cx.upload(c, A, b)
+        for _ in range(3):
+            again = rl.solve(0.0)
+            assert again.status == lp.OK and np.array_equal(again.x, res[1].x) and again.z == res[1].z
+        rl.free()
+    finally:
+        cx.close()
 
 
 def test_full_size_properties_C2(ctx):
