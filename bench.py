@@ -168,14 +168,28 @@ def main() -> int:
         nn = n - m
         bytes_pivot = 8.0 * (m * nn + 3.0 * m * m)      # pricing m(n-m) + FTRAN m^2 + update 2 m^2
         pipeline = last.stats["pipeline"]
-        if pipeline == "tableau":
+        nsamp = max(ksec[3], 1.0)
+        extra = {}
+        if pipeline == "blocked":
+            # K pivots per k_bt_inner launch (one workgroup, latency-bound: no HBM roofline applies to it) followed by ONE
+            # streaming launch k_bt_update that reads and writes T = B^-1 A_N once: 16*m*(n-m) bytes, HBM-bound.
+            nblocks = max(ksec[1], 1.0)
+            kernel_name, bytes_update, bytes_moved = "k_bt_update", 16.0 * m * nn, 16.0 * m * nn
+            t_upd = ksec[2] / nblocks
+            t_inner = ksec[0] / nblocks
+            extra = {"block_pivots": nsamp / nblocks, "k_bt_inner_us_per_launch": 1e6 * t_inner,
+                     "k_bt_inner_us_per_pivot": 1e6 * ksec[0] / nsamp, "k_bt_update_us_per_pivot": 1e6 * ksec[2] / nsamp,
+                     "time_share_inner": ksec[0] / max(ksec[0] + ksec[2], 1e-30),
+                     "note": "k_bt_inner is a single-workgroup latency-bound kernel (it touches one column and one row of T "
+                             "per pivot); the roofline entry prices the streaming kernel"}
+        elif pipeline == "tableau":
             # one launch = one whole pivot: the launch is credited with the SURVEY per-pivot figure; what the
             # single-kernel formulation really moves is 16*m*(n-m) bytes (read + write T = B^-1 A_N)
             kernel_name, bytes_update, bytes_moved = "k_tableau_pivot", bytes_pivot, 16.0 * m * nn
+            t_upd = ksec[2] / nsamp
         else:
             kernel_name, bytes_update, bytes_moved = "k_update", 16.0 * m * m, 16.0 * m * m   # read + write B^-1
-        nsamp = max(ksec[3], 1.0)
-        t_upd = ksec[2] / nsamp
+            t_upd = ksec[2] / nsamp
         achieved = bytes_update / t_upd / 1e9 if t_upd > 0 else 0.0
         out = {
             "metric": "simplex pivots/sec on %dx%d fp64 dense LP" % (m, n),
@@ -198,8 +212,7 @@ def main() -> int:
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_launch": bytes_update, "avg_launch_us": 1e6 * t_upd,
                          "bytes_moved_model": bytes_moved, "moved_GBs": bytes_moved / t_upd / 1e9 if t_upd > 0 else 0.0,
-                         "avg_us": {"k_price": 1e6 * ksec[0] / nsamp, "k_ftran": 1e6 * ksec[1] / nsamp,
-                                    "k_update": 1e6 * ksec[2] / nsamp, "sampled_pivots": int(ksec[3])},
+                         "sampled_pivots": int(ksec[3]), "detail": extra,
                          "per_pivot": {"bytes": bytes_pivot, "achieved_GBs": value / world * bytes_pivot / 1e9,
                                        "frac": value / world * bytes_pivot / 1e9 / HBM_PEAK_GBS}},
             "breakdown": {"pivot_loop_s": loop_s, "final_solve_s": final_s, "final_device_s": final_dev, "final_host_s": final_host, "wall_s": dt, "drift_xb": last.stats["drift_xb"],

@@ -18,10 +18,13 @@ Engine::Engine(int device) : device_(device), w_(new Work) {}
 
 Engine::~Engine() {
     hipSetDevice(device_);
-    for (auto &p : problems_) {
-        if (!p) continue;
-        hipFree(p->dAt); hipFree(p->dc); hipFree(p->dc1); hipFree(p->db);
-    }
+    for (auto *vec : {&problems_, &child_pool_})
+        for (auto &p : *vec) {
+            if (!p) continue;
+            hipFree(p->dAt); hipFree(p->dc); hipFree(p->dc1); hipFree(p->db);
+            if (p->dvar) hipFree(p->dvar);
+            if (p->dsign) hipFree(p->dsign);
+        }
     w_->release_all();
     if (stream_) hipStreamDestroy(stream_);
 }
@@ -161,46 +164,70 @@ int64_t Engine::upload_child(int64_t root, int K, const int32_t *var, const doub
     for (int k = 0; k < K; k++) if (var[k] < 0 || var[k] >= n0) return -GOMILP_ERR_BAD_SHAPE;
     if ((size_t)ld * sizeof(double) > 64 * 1024) return -GOMILP_ERR_UNSUPPORTED;
     if (hipSetDevice(device_) != hipSuccess) return -GOMILP_ERR_DEVICE;
+    if (!stream_ && hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) return -GOMILP_ERR_DEVICE;
     const double t0 = now_s();
-    std::unique_ptr<Problem> P(new Problem);
-    P->m = m; P->n = n; P->ld = ld;
-    int32_t *dvar = nullptr;
-    double *dsign = nullptr;
-    auto fail = [&](int code) -> int64_t {
-        if (dvar) hipFree(dvar);
-        if (dsign) hipFree(dsign);
-        if (P->dAt) hipFree(P->dAt);
-        if (P->dc) hipFree(P->dc);
-        if (P->dc1) hipFree(P->dc1);
-        if (P->db) hipFree(P->db);
-        return -code;
+    const size_t need_at = (size_t)(n + 1) * ld, need_c = (size_t)n + 1, need_b = (size_t)ld;
+    std::unique_ptr<Problem> P;
+    for (size_t i = 0; i < child_pool_.size(); i++) {
+        Problem &c = *child_pool_[i];
+        if (c.cap_at >= need_at && c.cap_c >= need_c && c.cap_b >= need_b && c.cap_k >= K) {
+            P = std::move(child_pool_[i]);
+            child_pool_.erase(child_pool_.begin() + i);
+            break;
+        }
+    }
+    auto release = [&](Problem &q) {
+        if (q.dAt) hipFree(q.dAt);
+        if (q.dc) hipFree(q.dc);
+        if (q.dc1) hipFree(q.dc1);
+        if (q.db) hipFree(q.db);
+        if (q.dvar) hipFree(q.dvar);
+        if (q.dsign) hipFree(q.dsign);
+        q.dAt = q.dc = q.dc1 = q.db = q.dsign = nullptr; q.dvar = nullptr;
     };
+    if (!P) {
+        P.reset(new Problem);
+        P->is_child = true;
+        // some head-room so that deeper children of the same root reuse the slot
+        const int kcap = K + 8, mcap = m0 + kcap, ncap = n0 + kcap, ldcap = (mcap + 1) & ~1;
+        P->cap_at = (size_t)(ncap + 1) * ldcap; P->cap_c = (size_t)ncap + 1; P->cap_b = (size_t)ldcap; P->cap_k = kcap;
+        if (dmalloc(&P->dAt, P->cap_at) != hipSuccess || dmalloc(&P->dc, P->cap_c) != hipSuccess ||
+            dmalloc(&P->dc1, P->cap_c) != hipSuccess || dmalloc(&P->db, P->cap_b) != hipSuccess ||
+            dmalloc(&P->dvar, (size_t)P->cap_k) != hipSuccess || dmalloc(&P->dsign, (size_t)P->cap_k) != hipSuccess) {
+            release(*P);
+            return -GOMILP_ERR_DEVICE;
+        }
+    }
+    P->m = m; P->n = n; P->ld = ld;
+    auto fail = [&](int code) -> int64_t { release(*P); return -code; };
 #define UP_TRY(expr) do { if ((expr) != hipSuccess) return fail(GOMILP_ERR_DEVICE); } while (0)
-    UP_TRY(dmalloc(&P->dAt, (size_t)(n + 1) * ld));
-    UP_TRY(dmalloc(&P->dc, (size_t)n + 1));
-    UP_TRY(dmalloc(&P->dc1, (size_t)n + 1));
-    UP_TRY(dmalloc(&P->db, (size_t)ld));
-    UP_TRY(dmalloc(&dvar, (size_t)K));
-    UP_TRY(dmalloc(&dsign, (size_t)K));
     P->hc = R.hc; P->hc.resize(n, 0.0);        // c' = [c, 0]   (subproblem.go:110-114)
     P->hb = R.hb; P->hb.insert(P->hb.end(), rhs, rhs + K);  // b' = [b; h]  (:117-119)
-    std::vector<double> hb_pad(ld, 0.0), hc_pad((size_t)n + 1, 0.0), hc1((size_t)n + 1, 0.0);
-    std::copy(P->hb.begin(), P->hb.end(), hb_pad.begin());
-    std::copy(P->hc.begin(), P->hc.end(), hc_pad.begin());
-    hc1[n] = 1.0;
-    if (K) {
-        UP_TRY(hipMemcpyAsync(dvar, var, (size_t)K * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-        UP_TRY(hipMemcpyAsync(dsign, sign, (size_t)K * sizeof(double), hipMemcpyHostToDevice, stream_));
+    // one pinned staging block: [b (ld) | c (n+1) | c1 (n+1) | sign (K)] doubles, then var (K) ints
+    Work &w = *w_;
+    const size_t stage_doubles = (size_t)ld + 2 * ((size_t)n + 1) + (size_t)K;
+    if (w.child_stage_cap < stage_doubles * sizeof(double) + (size_t)K * sizeof(int32_t) + 64) {
+        if (w.child_stage) hipHostFree(w.child_stage);
+        w.child_stage_cap = 2 * (stage_doubles * sizeof(double) + (size_t)K * sizeof(int32_t) + 64);
+        UP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.child_stage), w.child_stage_cap, hipHostMallocDefault));
     }
-    UP_TRY(hipMemcpyAsync(P->db, hb_pad.data(), (size_t)ld * sizeof(double), hipMemcpyHostToDevice, stream_));
-    UP_TRY(hipMemcpyAsync(P->dc, hc_pad.data(), ((size_t)n + 1) * sizeof(double), hipMemcpyHostToDevice, stream_));
-    UP_TRY(hipMemcpyAsync(P->dc1, hc1.data(), ((size_t)n + 1) * sizeof(double), hipMemcpyHostToDevice, stream_));
-    launch_child_assemble(R.dAt, R.ld, m0, n0, P->dAt, ld, K, dvar, dsign, stream_);
-    UP_TRY(hipStreamSynchronize(stream_));
+    double *sb = reinterpret_cast<double *>(w.child_stage);
+    double *sc = sb + ld, *sc1 = sc + (n + 1), *ss = sc1 + (n + 1);
+    int32_t *sv = reinterpret_cast<int32_t *>(ss + K);
+    for (int i = 0; i < ld; i++) sb[i] = i < m ? P->hb[i] : 0.0;
+    for (int j = 0; j <= n; j++) { sc[j] = j < n ? P->hc[j] : 0.0; sc1[j] = j == n ? 1.0 : 0.0; }
+    for (int k = 0; k < K; k++) { ss[k] = sign[k]; sv[k] = var[k]; }
+    if (K) {
+        UP_TRY(hipMemcpyAsync(P->dvar, sv, (size_t)K * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        UP_TRY(hipMemcpyAsync(P->dsign, ss, (size_t)K * sizeof(double), hipMemcpyHostToDevice, stream_));
+    }
+    UP_TRY(hipMemcpyAsync(P->db, sb, (size_t)ld * sizeof(double), hipMemcpyHostToDevice, stream_));
+    UP_TRY(hipMemcpyAsync(P->dc, sc, ((size_t)n + 1) * sizeof(double), hipMemcpyHostToDevice, stream_));
+    UP_TRY(hipMemcpyAsync(P->dc1, sc1, ((size_t)n + 1) * sizeof(double), hipMemcpyHostToDevice, stream_));
+    launch_child_assemble(R.dAt, R.ld, m0, n0, P->dAt, ld, K, P->dvar, P->dsign, stream_);
+    UP_TRY(hipStreamSynchronize(stream_));  // the staging block is reused by the next child
     UP_TRY(hipGetLastError());
 #undef UP_TRY
-    hipFree(dvar); dvar = nullptr;
-    hipFree(dsign); dsign = nullptr;
     // column statistics follow from the root's: a branched column gains one entry per constraint on it
     P->nnz = R.nnz; P->lastrow = R.lastrow; P->allone = R.allone;
     P->nnz.resize(n); P->lastrow.resize(n); P->allone.resize(n);
@@ -221,6 +248,11 @@ int Engine::free_problem(int64_t id) {
     std::lock_guard<std::mutex> g(mu_);
     if (id < 0 || (size_t)id >= problems_.size() || !problems_[id]) return GOMILP_ERR_BAD_SHAPE;
     hipSetDevice(device_);
+    if (problems_[id]->is_child) {  // keep the buffers for the next child (no hipFree: it synchronises the device)
+        child_pool_.push_back(std::move(problems_[id]));
+        problems_[id].reset();
+        return GOMILP_OK;
+    }
     Problem &P = *problems_[id];
     hipFree(P.dAt); hipFree(P.dc); hipFree(P.dc1); hipFree(P.db);
     problems_[id].reset();

@@ -26,6 +26,13 @@ struct Problem {
     std::vector<int32_t> nnz, lastrow, allone;  // per column of A
     int verify_status = GOMILP_OK;              // verifyInputs, simplex.go:385-439
     double seconds_upload = 0;
+    // children are recycled: their device buffers go back to a per-engine pool instead of hipFree (which synchronises
+    // the whole device and would serialise the worker streams of a frontier pool)
+    bool is_child = false;
+    size_t cap_at = 0, cap_c = 0, cap_b = 0;    // capacities in doubles
+    int32_t *dvar = nullptr;                    // child: branched variables / signs on the device
+    double *dsign = nullptr;
+    int cap_k = 0;
 };
 
 class Engine {
@@ -70,6 +77,7 @@ class Engine {
     hipStream_t stream_ = nullptr;
     std::mutex mu_;
     std::vector<std::unique_ptr<Problem>> problems_;
+    std::vector<std::unique_ptr<Problem>> child_pool_;  // released children, buffers kept
     std::unique_ptr<Work> w_;
     // knobs
     int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 1, tableau_ = 1, blocked_ = 1, block_k_ = 0;  // block_k_ 0 = auto

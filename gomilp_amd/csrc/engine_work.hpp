@@ -81,6 +81,8 @@ struct Engine::Work {
     double *h_W = nullptr;  // pinned, cap_m * cap_ld
     double *h_vec = nullptr;  // pinned, max(cap_ld, cap_cols)
     int32_t *h_idx = nullptr; // pinned, max(cap_m, cap_cols)
+    char *child_stage = nullptr;  // pinned staging block of upload_child
+    size_t child_stage_cap = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> sample_ev;  // pairs around sampled kernels
 
@@ -104,6 +106,7 @@ struct Engine::Work {
         cap_T = 0; cap_ldt = 0;
         if (st) hipFree(st); st = nullptr;
         if (st_host) hipHostFree(st_host); st_host = nullptr;
+        if (child_stage) hipHostFree(child_stage); child_stage = nullptr; child_stage_cap = 0;
         if (trace) hipFree(trace); trace = nullptr;
         for (auto &e : ev) { if (e) hipEventDestroy(e); e = nullptr; }
         for (auto &e : sample_ev) hipEventDestroy(e);

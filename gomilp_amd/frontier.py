@@ -2,8 +2,8 @@
 
 The frontier of an enumeration tree is a set of independent LP relaxations that share the root data
 (/root/reference/subproblem.go:20-29); the reference spreads them over goroutine workers
-(/root/reference/tree.go:98-100,196-205).  Here: one process per GPU, child i of the wave goes to rank i % world
-(round-robin keeps the per-GPU batches equal and the result order independent of the GPU count), every rank
+(/root/reference/tree.go:98-100,196-205).  Here: one process per GPU, the children of the wave are dealt round-robin over a fixed shuffle
+(equal batch sizes; results do not depend on the GPU count), every rank
 solves its shard on its own GPU through gomilp_frontier_solve, and the only exchange is the incumbent bound:
 one all-reduce(min) per wave (RCCL over xGMI on the GPU box, gloo in the CPU tests).  The bound is used exactly
 like /root/reference/tree.go:228-230 uses it — after the solves, for pruning — never inside a solve.
@@ -18,9 +18,22 @@ import numpy as np
 BIG_INDEX = 2 ** 62
 
 
+def _mix(i: int) -> int:
+    """Fixed 32-bit mixing of the child index (deterministic, same on every rank)."""
+    x = (i * 2654435761) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 2246822519) & 0xFFFFFFFF
+    return x ^ (x >> 13)
+
+
 def shard_indices(count: int, rank: int, world: int) -> List[int]:
-    """Children owned by `rank`: i % world == rank."""
-    return list(range(rank, count, world))
+    """Children owned by `rank`: round-robin over a fixed pseudo-random order of the wave.
+
+    Plain `i % world` piles up the expensive children of a sign-pattern frontier (the few feasible ones are the
+    patterns 0, 1, 2, 4, 8, ... — mostly multiples of the GPU count) on rank 0; a fixed shuffle spreads them.  The
+    per-child results do not depend on the assignment, and incumbent ties are resolved by the child index."""
+    order = sorted(range(count), key=lambda i: (_mix(i), i))
+    return sorted(order[rank::world])
 
 
 def is_all_integer(v: float) -> bool:

@@ -70,7 +70,10 @@ def test_shard_indices_partition():
         for world in (1, 2, 3, 8):
             seen = sorted(i for r in range(world) for i in frontier.shard_indices(count, r, world))
             assert seen == list(range(count))
-    assert frontier.shard_indices(256, 3, 8)[:3] == [3, 11, 19] and len(frontier.shard_indices(256, 3, 8)) == 32
+    assert len(frontier.shard_indices(256, 3, 8)) == 32
+    heavy = [0, 1, 2, 4, 8, 16, 32, 64, 128]  # the feasible children of the C5 wave
+    per_rank = [len(set(heavy) & set(frontier.shard_indices(256, r, 8))) for r in range(8)]
+    assert max(per_rank) <= 3
 
 
 def test_integrality_semantics_follow_tree_go():
