@@ -26,6 +26,7 @@
 
 namespace gomilp {
 
+__device__ long long g_bt_prof[16];
 constexpr int kBtThreads = 1024;
 constexpr int kBtWaves = kBtThreads / 64;
 constexpr int kBtMaxK = 32;
@@ -38,21 +39,59 @@ struct BtCand {
 __device__ __forceinline__ void bt_take(BtCand &a, const BtCand &b) {
     if (b.k < a.k || (b.k == a.k && b.i < a.i)) a = b;
 }
-// argmin over the whole 1024-thread workgroup; result in every thread
+// ---- DPP reductions.  A ds_bpermute-based __shfl_xor butterfly costs ~400 cycles per round (5 dwords through the
+// LDS crossbar); the two workgroup-wide argmins per pivot were 2/3 of the inner kernel's time.  DPP row shifts are
+// plain VALU moves: 4 row_shr steps leave each 16-lane row's result in its last lane, v_readlane combines the rows.
+template <int CTRL>
+__device__ __forceinline__ unsigned int dpp_u32(unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);  // lanes without a source keep v
+}
+template <int CTRL>
+__device__ __forceinline__ BtCand dpp_cand(const BtCand &a) {
+    BtCand b;
+    const unsigned int klo = dpp_u32<CTRL>((unsigned int)a.k), khi = dpp_u32<CTRL>((unsigned int)(a.k >> 32));
+    b.k = ((unsigned long long)khi << 32) | klo;
+    b.i = dpp_u32<CTRL>(a.i);
+    const unsigned long long db = (unsigned long long)__double_as_longlong(a.d);
+    const unsigned int dlo = dpp_u32<CTRL>((unsigned int)db), dhi = dpp_u32<CTRL>((unsigned int)(db >> 32));
+    b.d = __longlong_as_double((long long)(((unsigned long long)dhi << 32) | dlo));
+    return b;
+}
+__device__ __forceinline__ BtCand readlane_cand(const BtCand &a, int lane) {
+    BtCand b;
+    const unsigned int klo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)a.k, lane);
+    const unsigned int khi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(a.k >> 32), lane);
+    b.k = ((unsigned long long)khi << 32) | klo;
+    b.i = (unsigned int)__builtin_amdgcn_readlane((int)a.i, lane);
+    const unsigned long long db = (unsigned long long)__double_as_longlong(a.d);
+    const unsigned int dlo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)db, lane);
+    const unsigned int dhi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(db >> 32), lane);
+    b.d = __longlong_as_double((long long)(((unsigned long long)dhi << 32) | dlo));
+    return b;
+}
+// reduce within each row of 16 lanes: afterwards lane 15 of every row holds that row's argmin
+__device__ __forceinline__ void row_argmin(BtCand &a) {
+    bt_take(a, dpp_cand<0x111>(a));  // row_shr:1
+    bt_take(a, dpp_cand<0x112>(a));  // row_shr:2
+    bt_take(a, dpp_cand<0x114>(a));  // row_shr:4
+    bt_take(a, dpp_cand<0x118>(a));  // row_shr:8
+}
+// argmin over the whole 1024-thread workgroup; result (uniform) in every thread.  `sm` is double buffered by the
+// caller (sm + 16*parity) so that one barrier per reduction is enough.
 __device__ __forceinline__ void bt_block_argmin(BtCand &a, BtCand *sm) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        BtCand b;
-        b.k = __shfl_xor(a.k, o, 64); b.i = __shfl_xor(a.i, o, 64); b.d = __shfl_xor(a.d, o, 64);
-        bt_take(a, b);
-    }
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) sm[w] = a;
+    row_argmin(a);
+    BtCand w = readlane_cand(a, 15);
+    bt_take(w, readlane_cand(a, 31));
+    bt_take(w, readlane_cand(a, 47));
+    bt_take(w, readlane_cand(a, 63));
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sm[wv] = w;
     __syncthreads();
-    a = sm[0];
-#pragma unroll
-    for (int t = 1; t < kBtWaves; t++) bt_take(a, sm[t]);
-    __syncthreads();
+    BtCand c;
+    c.k = ~0ull; c.i = 0xFFFFFFFFu; c.d = 0;
+    if (lane < kBtWaves) c = sm[lane];
+    row_argmin(c);  // kBtWaves == 16: one row
+    a = readlane_cand(c, 15);
 }
 
 // RI / CJ: rows / columns per thread (m <= RI*1024, n-m <= CJ*1024).
@@ -74,7 +113,8 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     double *r_s = sh;                 // ldt
     double *xb_s = sh + a.ldt;        // ldu
-    __shared__ BtCand sm[kBtWaves];
+    __shared__ BtCand sm2[2 * kBtWaves];
+    int sm_par = 0;
     __shared__ double vq[kBtMaxK], up[kBtMaxK];
     __shared__ double s_bcast[2];
     DevState *st = a.st;
@@ -146,12 +186,15 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
                 bt_take(c, b);
             }
         }
-        bt_block_argmin(c, sm);
+        bt_block_argmin(c, sm2 + kBtWaves * (sm_par ^= 1));
         return c;
     };
 
+    long long tstamp = clock64();
+    auto stamp = [&](int slot) { if (a.pad && tid == 0) { long long now = clock64(); g_bt_prof[slot] += now - tstamp; tstamp = now; } };
     for (int k = 0; k < a.kmax; k++) {
         const bool forced = (k == 0 && a.forced_q >= 0);
+        stamp(0);
         int q, p;
         double rq, dpv;
         bool bland = false;
@@ -165,12 +208,15 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
                 b.k = ordkey(r_s[j]); b.i = (unsigned int)j; b.d = 0;
                 bt_take(c, b);
             }
-            bt_block_argmin(c, sm);
+            bt_block_argmin(c, sm2 + kBtWaves * (sm_par ^= 1));
             q = (int)c.i;
             rq = r_s[q];
+            stamp(1);
             if (rq >= -a.tol) { status = ST_OPTIMAL; break; }  // simplex.go:248
             column(q, k, dcol);
+            stamp(2);
             BtCand w = ratio(dcol, mvv);
+            stamp(3);
             p = (int)w.i; dpv = w.d;
             const double mv = orddecode(w.k);
             if (mv == inf) { status = ST_UNBOUNDED; break; }  // simplex.go:328-330
@@ -190,7 +236,7 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
                         if (fabs(rv) < 1e-13) rv = 0;
                         if (!(rv > -1e-14)) { f.k = 0; f.i = (unsigned int)j; break; }  // first such j of this thread
                     }
-                    bt_block_argmin(f, sm);
+                    bt_block_argmin(f, sm2 + kBtWaves * (sm_par ^= 1));
                     if (f.i == 0xFFFFFFFFu) break;  // candidates exhausted -> ErrBland
                     cand = (int)f.i;
                     column(cand, k, dcol);
@@ -205,7 +251,7 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
                         const int i = tid + s * kBtThreads;
                         if (i < a.m && !(mvv[s] > 1e-12)) { BtCand b; b.k = 0; b.i = (unsigned int)i; b.d = dcol[s]; bt_take(g, b); }
                     }
-                    bt_block_argmin(g, sm);
+                    bt_block_argmin(g, sm2 + kBtWaves * (sm_par ^= 1));
                     if (g.i != 0xFFFFFFFFu) { q = cand; p = (int)g.i; dpv = g.d; found = true; break; }  // :368-379
                 }
                 if (status == ST_UNBOUNDED) break;
@@ -234,6 +280,7 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
             up[tid] = __hip_atomic_load(a.U + (size_t)tid * a.ldu + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
+        stamp(4);
         const double mult = rq / dpv;
         const double theta = xb_s[p] / dpv;
         __syncthreads();  // everybody has read xb_s[p] before it is overwritten
@@ -287,6 +334,7 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
                 }
             }
         }
+        stamp(5);
         if (tid == 0 && !(forced && a.forced_nocommit)) {  // simplex.go:280
             const int ent = a.nonbasic[q], lea = a.basic[p];
             a.basic[p] = ent; a.nonbasic[q] = lea;
@@ -300,6 +348,8 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
         kd = k + 1;
         if (KREG == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // u_k / v_k reach L2 before the sc1 loads of other waves
         __syncthreads();
+        stamp(6);
+        if (a.pad && tid == 0) g_bt_prof[15] += 1;
     }
     for (int j = tid; j < a.ldt; j += kBtThreads) a.r[j] = r_s[j];
     for (int i = tid; i < a.ldu; i += kBtThreads) a.xb[i] = xb_s[i];
@@ -352,6 +402,8 @@ __global__ __launch_bounds__(kBlock) void k_bt_update(BTArgs a, int rows_per_wg)
 
 bool bt_supported(int m, int nn) { return m <= 8 * kBtThreads && nn + 511 <= 8 * kBtThreads; }
 int bt_max_k() { return kBtMaxK; }
+void bt_prof_read(long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bt_prof), sizeof(long long) * 16); }
+void bt_prof_reset() { long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_bt_prof), z, sizeof(z)); }
 
 // register-resident block terms cost (RI + CJ) * KREG doubles per thread; with 16 waves per workgroup the budget is
 // 128 VGPRs, so KREG = 8 fits for RI = CJ <= 2 (m, n-m <= 2048)

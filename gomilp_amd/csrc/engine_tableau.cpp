@@ -1,6 +1,8 @@
 // Host control of the single-kernel tableau pipeline (tableau_kernels.hip).  Same reference control flow as
 // engine.cpp (simplex.go:93-302); only the per-pivot device work differs: T = B^-1 A_N is kept explicitly and
 // one launch applies a whole pivot.
+#include <stdlib.h>
+
 #include "engine_work.hpp"
 
 namespace gomilp {
@@ -188,6 +190,7 @@ BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int
     a.basic = w.basic; a.nonbasic = w.nonbasic; a.st = w.st;
     a.trace = trace_on_ ? w.trace : nullptr; a.trace_cap = w.trace_cap;
     a.forced_q = a.forced_p = -1; a.forced_nocommit = 0;
+    a.pad = getenv("GOMILP_BT_PROF") ? 1 : 0;
     return a;
 }
 
