@@ -20,6 +20,9 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
 
 #include "device_types.h"
 #include "kernels_common.h"
@@ -78,6 +81,7 @@ __device__ __forceinline__ void row_argmin(BtCand &a) {
 }
 // argmin over the whole 1024-thread workgroup; result (uniform) in every thread.  `sm` is double buffered by the
 // caller (sm + 16*parity) so that one barrier per reduction is enough.
+template <int NW>
 __device__ __forceinline__ void bt_block_argmin(BtCand &a, BtCand *sm) {
     row_argmin(a);
     BtCand w = readlane_cand(a, 15);
@@ -89,8 +93,8 @@ __device__ __forceinline__ void bt_block_argmin(BtCand &a, BtCand *sm) {
     __syncthreads();
     BtCand c;
     c.k = ~0ull; c.i = 0xFFFFFFFFu; c.d = 0;
-    if (lane < kBtWaves) c = sm[lane];
-    row_argmin(c);  // kBtWaves == 16: one row
+    if (lane < NW) c = sm[lane];
+    row_argmin(c);  // NW <= 16: one row
     a = readlane_cand(c, 15);
 }
 
@@ -98,8 +102,10 @@ __device__ __forceinline__ void bt_block_argmin(BtCand &a, BtCand *sm) {
 // KREG > 0: the block's rank-1 terms of a thread's OWN rows / columns live in registers (newest first, shifted
 // every pivot), foreign scalars travel through LDS — the single CU that runs this kernel then touches global memory
 // only for the stale column, the stale row and the u_k / v_k stores.  KREG = 0: terms are re-read from global (L2).
-template <int RI, int CJ, int KREG>
-__global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
+template <int NT, int RI, int CJ, int KREG>
+__global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
+    constexpr int kBtThreads = NT;   // shadows the namespace-level default inside this kernel
+    constexpr int kBtWaves = NT / 64;
     constexpr int KR = KREG > 0 ? KREG : 1;
     double ureg[RI][KR], vreg[CJ][KR];
 #pragma unroll
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     double *r_s = sh;                 // ldt
     double *xb_s = sh + a.ldt;        // ldu
-    __shared__ BtCand sm2[2 * kBtWaves];
+    __shared__ BtCand sm2[2 * 16];
     int sm_par = 0;
     __shared__ double vq[kBtMaxK], up[kBtMaxK];
     __shared__ double s_bcast[2];
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
                 bt_take(c, b);
             }
         }
-        bt_block_argmin(c, sm2 + kBtWaves * (sm_par ^= 1));
+        bt_block_argmin<kBtWaves>(c, sm2 + kBtWaves * (sm_par ^= 1));
         return c;
     };
 
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
                 b.k = ordkey(r_s[j]); b.i = (unsigned int)j; b.d = 0;
                 bt_take(c, b);
             }
-            bt_block_argmin(c, sm2 + kBtWaves * (sm_par ^= 1));
+            bt_block_argmin<kBtWaves>(c, sm2 + kBtWaves * (sm_par ^= 1));
             q = (int)c.i;
             rq = r_s[q];
             stamp(1);
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
                         if (fabs(rv) < 1e-13) rv = 0;
                         if (!(rv > -1e-14)) { f.k = 0; f.i = (unsigned int)j; break; }  // first such j of this thread
                     }
-                    bt_block_argmin(f, sm2 + kBtWaves * (sm_par ^= 1));
+                    bt_block_argmin<kBtWaves>(f, sm2 + kBtWaves * (sm_par ^= 1));
                     if (f.i == 0xFFFFFFFFu) break;  // candidates exhausted -> ErrBland
                     cand = (int)f.i;
                     column(cand, k, dcol);
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(kBtThreads) void k_bt_inner(BTArgs a) {
                         const int i = tid + s * kBtThreads;
                         if (i < a.m && !(mvv[s] > 1e-12)) { BtCand b; b.k = 0; b.i = (unsigned int)i; b.d = dcol[s]; bt_take(g, b); }
                     }
-                    bt_block_argmin(g, sm2 + kBtWaves * (sm_par ^= 1));
+                    bt_block_argmin<kBtWaves>(g, sm2 + kBtWaves * (sm_par ^= 1));
                     if (g.i != 0xFFFFFFFFu) { q = cand; p = (int)g.i; dpv = g.d; found = true; break; }  // :368-379
                 }
                 if (status == ST_UNBOUNDED) break;
@@ -400,39 +406,57 @@ __global__ __launch_bounds__(kBlock) void k_bt_update(BTArgs a, int rows_per_wg)
 
 // ---- launch wrappers ---------------------------------------------------------------------------
 
-bool bt_supported(int m, int nn) { return m <= 8 * kBtThreads && nn + 511 <= 8 * kBtThreads; }
 int bt_max_k() { return kBtMaxK; }
 void bt_prof_read(long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bt_prof), sizeof(long long) * 16); }
 void bt_prof_reset() { long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_bt_prof), z, sizeof(z)); }
 
-// register-resident block terms cost (RI + CJ) * KREG doubles per thread; with 16 waves per workgroup the budget is
-// 128 VGPRs, so KREG = 8 fits for RI = CJ <= 2 (m, n-m <= 2048)
-int bt_reg_k(int m, int ldt) {
-    const int ri = (m + kBtThreads - 1) / kBtThreads, cj = (ldt + kBtThreads - 1) / kBtThreads;
-    return (ri <= 2 && cj <= 2) ? 8 : 0;
+// Thread count: the per-pivot reductions are instruction-issue bound and every wave repeats them, so the kernel runs
+// with ONE wave per SIMD (256 threads) whenever the rows/columns per thread still fit in registers.
+// Register-resident block terms cost (RI + CJ) * KREG doubles per thread.
+struct BtCfg { int nt, ri, cj, kreg; };
+static BtCfg bt_cfg(int m, int ldt) {
+    auto per = [](int x, int nt) { return (x + nt - 1) / nt; };
+    int force = 0;
+    if (const char *e = getenv("GOMILP_BT_NT")) force = atoi(e);
+    for (int nt : {256, 512, 1024}) {
+        if (force && nt != force) continue;
+        const int r = std::max(per(m, nt), per(ldt, nt));
+        if (!force) {
+            // measured on gfx950: fat threads (many rows per thread) lose more on the column gather / row update than
+            // they gain on the reductions; keep at most 2 rows per thread unless the problem is small
+            // (m = 2048: 256 thr 13.8 us/pivot, 512 thr 9.2, 1024 thr 8.6; m = 1024: 8.0 / 6.1 / 6.6; m = 512: 5.4 / 4.9 / 5.6)
+            if (nt == 256) continue;
+            if (nt == 512 && r > 2) continue;
+        }
+        if (r <= 2) return {nt, 2, 2, 8};
+        if (r <= 4) return {nt, 4, 4, nt <= 512 ? 8 : 0};
+        if (r <= 8) return {nt, 8, 8, nt <= 256 ? 8 : 0};
+    }
+    return {1024, 8, 8, 0};
+}
+bool bt_supported(int m, int nn) { return m <= 8 * 1024 && nn + 511 <= 8 * 1024; }
+int bt_reg_k(int m, int ldt) { return bt_cfg(m, ldt).kreg; }
+template <int NT>
+static void bt_launch_nt(const BTArgs &a, const BtCfg &c, bool reg, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+#define GOMILP_BT_LAUNCH(RI, CJ, KR) hipExtLaunchKernelGGL((k_bt_inner<NT, RI, CJ, KR>), dim3(1), dim3(NT), lds, s, e0, e1, 0, a)
+    if (c.ri == 2) { if (reg) GOMILP_BT_LAUNCH(2, 2, 8); else GOMILP_BT_LAUNCH(2, 2, 0); }
+    else if (c.ri == 4) { if (reg && NT <= 512) GOMILP_BT_LAUNCH(4, 4, (NT <= 512 ? 8 : 0)); else GOMILP_BT_LAUNCH(4, 4, 0); }
+    else { if (reg && NT <= 256) GOMILP_BT_LAUNCH(8, 8, (NT <= 256 ? 8 : 0)); else GOMILP_BT_LAUNCH(8, 8, 0); }
+#undef GOMILP_BT_LAUNCH
 }
 void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const size_t lds = (size_t)(a.ldt + a.ldu) * sizeof(double);
-    const int ri = (a.m + kBtThreads - 1) / kBtThreads, cj = (a.ldt + kBtThreads - 1) / kBtThreads;
-    const int sel = (ri <= 1 && cj <= 1) ? 1 : (ri <= 2 && cj <= 2) ? 2 : (ri <= 4 && cj <= 4) ? 4 : 8;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner<4, 4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner<8, 8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner<1024, 4, 4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner<1024, 8, 8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
         attr_done = true;
     }
-    const bool reg = a.kmax <= 8 && bt_reg_k(a.m, a.ldt) > 0;
-    if (sel == 1) {
-        if (reg) hipExtLaunchKernelGGL((k_bt_inner<1, 1, 8>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
-        else hipExtLaunchKernelGGL((k_bt_inner<1, 1, 0>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
-    } else if (sel == 2) {
-        if (reg) hipExtLaunchKernelGGL((k_bt_inner<2, 2, 8>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
-        else hipExtLaunchKernelGGL((k_bt_inner<2, 2, 0>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
-    } else if (sel == 4) {
-        hipExtLaunchKernelGGL((k_bt_inner<4, 4, 0>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
-    } else {
-        hipExtLaunchKernelGGL((k_bt_inner<8, 8, 0>), dim3(1), dim3(kBtThreads), lds, s, e0, e1, 0, a);
-    }
+    const BtCfg c = bt_cfg(a.m, a.ldt);
+    const bool reg = c.kreg > 0 && a.kmax <= c.kreg;
+    if (c.nt == 256) bt_launch_nt<256>(a, c, reg, lds, s, e0, e1);
+    else if (c.nt == 512) bt_launch_nt<512>(a, c, reg, lds, s, e0, e1);
+    else bt_launch_nt<1024>(a, c, reg, lds, s, e0, e1);
 }
 void launch_bt_update(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const int ld2 = a.ldt / 2;
