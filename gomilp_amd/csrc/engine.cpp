@@ -141,6 +141,10 @@ int64_t Engine::upload(const double *c, const double *A, int64_t lda, const doub
     P->allone.assign(hs.begin() + 2 * n, hs.begin() + 3 * n);
     P->hb.assign(b, b + m);
     P->hc.assign(c, c + n);
+    if ((size_t)m * n <= ((size_t)1 << 22)) {  // small: keep A for the general initial-basis path
+        P->hA.resize((size_t)m * n);
+        for (int i = 0; i < m; i++) memcpy(&P->hA[(size_t)i * n], A + (size_t)i * lda, sizeof(double) * (size_t)n);
+    }
     // verifyInputs (simplex.go:404-438): rows first, then columns, first offender decides
     P->verify_status = GOMILP_OK;
     for (int i = 0; i < m && P->verify_status == GOMILP_OK; i++)
@@ -237,6 +241,12 @@ int64_t Engine::upload_child(int64_t root, int K, const int32_t *var, const doub
         P->nnz[n0 + k] = 1; P->lastrow[n0 + k] = m0 + k; P->allone[n0 + k] = 1;
     }
     P->verify_status = R.verify_status;  // bnb rows and their slack columns are never empty
+    P->hA.clear();
+    if (!R.hA.empty() && (size_t)m * n <= ((size_t)1 << 22)) {  // [[A0, 0], [G#, I]]
+        P->hA.assign((size_t)m * n, 0.0);
+        for (int i = 0; i < m0; i++) memcpy(&P->hA[(size_t)i * n], &R.hA[(size_t)i * n0], sizeof(double) * (size_t)n0);
+        for (int k = 0; k < K; k++) { P->hA[(size_t)(m0 + k) * n + var[k]] = sign[k]; P->hA[(size_t)(m0 + k) * n + n0 + k] = 1.0; }
+    }
     P->seconds_upload = now_s() - t0;
     for (size_t i = 0; i < problems_.size(); i++)
         if (!problems_[i]) { problems_[i] = std::move(P); return (int64_t)i; }
@@ -661,22 +671,42 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     // findLinearlyIndependent (simplex.go:611-637), unit-column fast path: the descending scan meets m distinct
     // unit vectors (always true for GoMILP's [.. | I] standard forms, subproblem.go:81-139); cond == 1 there.
     std::vector<int32_t> basic(m), rho(m);
+    bool unit_basis = true;
     {
         std::vector<char> used(m, 0);
         for (int pos = 0; pos < m; pos++) {
             const int j = n - 1 - pos;
-            if (!(P.nnz[j] == 1 && P.allone[j]) || used[P.lastrow[j]]) return finish(GOMILP_ERR_UNSUPPORTED);
+            if (!(P.nnz[j] == 1 && P.allone[j]) || used[P.lastrow[j]]) { unit_basis = false; break; }
             rho[pos] = P.lastrow[j]; used[rho[pos]] = 1; basic[pos] = j;
         }
     }
-    // ab = permutation, xb = ab^-1 b exactly (initializeFromBasic, simplex.go:447-471)
-    std::vector<double> xb(m);
+    const int nn_max = n + 1 - m;
+    const bool use_tab = tableau_ && (n - m) < 2 * m && (size_t)tab_ld(nn_max) * sizeof(double) <= 64 * 1024;
+    std::vector<double> xb(m, 0.0), binv_host;
     bool feasible = true;
-    for (int pos = 0; pos < m; pos++) { xb[pos] = P.hb[rho[pos]]; if (xb[pos] < -1e-13) feasible = false; }
+    if (unit_basis) {
+        // ab = permutation, xb = ab^-1 b exactly (initializeFromBasic, simplex.go:447-471)
+        for (int pos = 0; pos < m; pos++) { xb[pos] = P.hb[rho[pos]]; if (xb[pos] < -1e-13) feasible = false; }
+    } else {
+        // general case (engine_general.cpp): host search over a kept copy of A, small problems on the tableau pipelines
+        if (P.hA.empty() || !use_tab || m > 512) return finish(GOMILP_ERR_UNSUPPORTED);
+        rc = general_find_linearly_independent(P.hA, m, n, basic);
+        if (rc != GOMILP_OK) return finish(rc);  // ErrSingular, simplex.go:495-497
+        if (!general_basis_inverse(P.hA, m, n, basic, n, std::vector<double>(), binv_host)) return finish(GOMILP_ERR_SINGULAR);
+        // xb = ab^-1 b with the reference's own arithmetic (gonum-order LU on the device): the feasibility test of
+        // simplex.go:459-469 then sees the same bits
+        if ((rc = upload_index_lists(basic, {})) != GOMILP_OK) return finish(rc);
+        bool sing = false;
+        if ((rc = final_solve(P, n, xb_exact, &sing)) != GOMILP_OK) return finish(rc);
+        if (sing) { feasible = false; }  // "singular" also sends the reference to Phase I (simplex.go:504-507), xb stays zero
+        else { xb = xb_exact; for (int pos = 0; pos < m; pos++) if (xb[pos] < -1e-13) feasible = false; }
+    }
     cur_ = 0;
-    HIP_TRY(hipMemsetAsync(w.binv[0], 0, (size_t)m * P.ld * sizeof(double), stream_));
-    HIP_TRY(hipMemcpyAsync(w.rho, rho.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-    launch_set_binv_perm(w.binv[0], P.ld, m, w.rho, stream_);
+    if (unit_basis && !use_tab) {
+        HIP_TRY(hipMemsetAsync(w.binv[0], 0, (size_t)m * P.ld * sizeof(double), stream_));
+        HIP_TRY(hipMemcpyAsync(w.rho, rho.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        launch_set_binv_perm(w.binv[0], P.ld, m, w.rho, stream_);
+    }
     HIP_TRY(hipMemsetAsync(w.xb, 0, (size_t)P.ld * sizeof(double), stream_));
     ycur_ = 0;
     HIP_TRY(hipMemsetAsync(w.yb[0], 0, (size_t)P.ld * sizeof(double), stream_));
@@ -686,8 +716,6 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
 
     // pipeline choice: the explicit tableau moves 16*m*(n-m) bytes per pivot in one launch, the revised form
     // 8*[m(n-m) + 2m^2] in two: the tableau wins while n - m < 2m
-    const int nn_max = n + 1 - m;
-    const bool use_tab = tableau_ && (n - m) < 2 * m && (size_t)tab_ld(nn_max) * sizeof(double) <= 64 * 1024;
     use_bt_ = use_tab && blocked_ && bt_supported(m, nn_max);
     st->reserved = use_tab ? (use_bt_ ? 3 : 2) : ((fused_ && fused_supported(P.ld)) ? 1 : 0);
     int loop_rc = GOMILP_OK;
@@ -706,7 +734,7 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
         }
         HIP_TRY(hipMemsetAsync(w.R[0], 0, (size_t)w.cap_ldt * sizeof(double), stream_));
         HIP_TRY(hipMemsetAsync(w.R[1], 0, (size_t)w.cap_ldt * sizeof(double), stream_));
-        rc = solve_tableau(P, tol, basic, rho, xb, feasible, st, &loop_rc);
+        rc = solve_tableau(P, tol, basic, rho, xb, feasible, st, &loop_rc, unit_basis ? nullptr : &binv_host);
         if (rc != GOMILP_OK) return finish(rc);
     } else {
     std::vector<int32_t> nonbasic;

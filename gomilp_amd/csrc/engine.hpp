@@ -23,6 +23,7 @@ struct Problem {
     double *dc1 = nullptr;    // n+1 : Phase-I cost e_n
     double *db = nullptr;     // ld  : b, zero padded
     std::vector<double> hb, hc;
+    std::vector<double> hA;   // host copy of A (row-major m x n), kept for small problems: general initial basis (S7)
     std::vector<int32_t> nnz, lastrow, allone;  // per column of A
     int verify_status = GOMILP_OK;              // verifyInputs, simplex.go:385-439
     double seconds_upload = 0;
@@ -62,7 +63,8 @@ class Engine {
     int tab_forced_pivot(const Problem &P, int phase, double tol, int nn, int q, int ent, double rq, int p, double dp, double xp,
                          int lea, int flags, long long t);
     int solve_tableau(const Problem &P, double tol, std::vector<int32_t> &basic, const std::vector<int32_t> &rho,
-                      std::vector<double> &xb, bool feasible, gomilp_lp_stats *st, int *loop_rc);
+                      std::vector<double> &xb, bool feasible, gomilp_lp_stats *st, int *loop_rc,
+                      const std::vector<double> *binv_host);
     BTArgs make_bt_args(const Problem &P, int phase, double tol, int nn, int kmax);
     int bt_forced_pivot(const Problem &P, int phase, double tol, int nn, int q, int p, int nocommit);
     int run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_lp_stats *st);
@@ -92,6 +94,11 @@ class Engine {
     std::vector<gomilp_pivot> last_trace_;
     int64_t last_trace_total_ = 0;
 };
+
+// engine_general.cpp
+int general_find_linearly_independent(const std::vector<double> &A, int m, int n, std::vector<int32_t> &idxs);
+bool general_basis_inverse(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, int ncols_with_art,
+                           const std::vector<double> &art, std::vector<double> &binv);
 
 int device_count();
 const char *compiled_arch();

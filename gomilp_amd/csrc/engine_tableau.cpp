@@ -281,7 +281,8 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
 // Phase I / Phase II on the tableau pipeline.  Called by Engine::solve after the initial (slack) basis is known.
 // On return `basic` / `xb` hold the final basis positions and updated x_B; *loop_rc is the Phase-II loop result.
 int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &basic, const std::vector<int32_t> &rho,
-                          std::vector<double> &xb, bool feasible, gomilp_lp_stats *st, int *loop_rc) {
+                          std::vector<double> &xb, bool feasible, gomilp_lp_stats *st, int *loop_rc,
+                          const std::vector<double> *binv_host) {
     Work &w = *w_;
     const int m = P.m, n = P.n;
     int rc;
@@ -293,15 +294,32 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         for (int j = 0; j < ncols; j++) if (!inb[j]) nonbasic.push_back(j);
     };
     tcur_ = 0; rcur_ = 0;
-    HIP_TRY(hipMemcpyAsync(w.rho, rho.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    if (!binv_host) HIP_TRY(hipMemcpyAsync(w.rho, rho.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipMemsetAsync(w.xb, 0, (size_t)P.ld * sizeof(double), stream_));
     HIP_TRY(hipMemcpyAsync(w.xb, xb.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
-    auto set_up_T = [&](int nn) -> int {  // T = B^-1 A_N for the slack basis (B^-1 = permutation rho)
+    std::vector<double> art(P.ld, 0.0);  // Phase-I artificial column (simplex.go:533-542)
+    auto set_up_T = [&](int nn) -> int {  // T = B^-1 A_N
         ldt_ = tab_ld(nn);
         HIP_TRY(hipMemsetAsync(w.T[0], 0, (size_t)m * ldt_ * sizeof(double), stream_));
-        launch_tab_gather(P.dAt, P.ld, m, nn, w.nonbasic, w.rho, w.T[0], ldt_, stream_);
-        launches_++;
+        if (!binv_host) {  // slack basis: B^-1 is the permutation rho
+            launch_tab_gather(P.dAt, P.ld, m, nn, w.nonbasic, w.rho, w.T[0], ldt_, stream_);
+            launches_++;
+            return GOMILP_OK;
+        }
+        // general basis (small problems): T on the host from the kept copy of A
+        std::vector<double> Th((size_t)m * ldt_, 0.0);
+        for (int jp = 0; jp < nn; jp++) {
+            const int j = nonbasic[jp];
+            for (int pos = 0; pos < m; pos++) {
+                double s = 0;
+                const double *bi = binv_host->data() + (size_t)pos * m;
+                if (j < n) for (int i = 0; i < m; i++) s += bi[i] * P.hA[(size_t)i * n + j];
+                else for (int i = 0; i < m; i++) s += bi[i] * art[i];
+                Th[(size_t)pos * ldt_ + jp] = s;
+            }
+        }
+        HIP_TRY(hipMemcpy(w.T[0], Th.data(), Th.size() * sizeof(double), hipMemcpyHostToDevice));
         return GOMILP_OK;
     };
     int nn;
@@ -309,9 +327,15 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         // ---- Phase I (simplex.go:529-606) ----
         st->phase1_used = 1;
         const int64_t minidx = min_idx(xb.data(), m);
-        std::vector<double> art(P.ld, 0.0);
         for (int k = 0; k < m; k++) art[k] = P.hb[k];
-        for (int i = 0; i < m; i++) { if (i == minidx) continue; art[rho[i]] = -1 * 1.0 + art[rho[i]]; }  // floats.Sub, :536-542
+        if (!binv_host) {
+            for (int i = 0; i < m; i++) { if (i == minidx) continue; art[rho[i]] = -1 * 1.0 + art[rho[i]]; }  // floats.Sub, :536-542
+        } else {
+            for (int i = 0; i < m; i++) {  // same loop over full columns
+                if (i == minidx) continue;
+                for (int k = 0; k < m; k++) art[k] = -1 * P.hA[(size_t)k * n + basic[i]] + art[k];
+            }
+        }
         bool art_zero = true;
         for (int k = 0; k < m; k++) if (art[k] != 0) { art_zero = false; break; }
         if (art_zero) { st->wrapped_status = GOMILP_ERR_ZERO_COLUMN; return GOMILP_ERR_PHASE1_WRAPPED; }
@@ -326,13 +350,30 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         const int qa = nn - 1;  // position of the artificial
         launch_tab_column(w.T[0], ldt_, m, qa, w.xb, w.dvec, w.move, stream_);
         launches_++;
-        const double dp = art[rho[minidx]];
+        double dp = 0;  // pivot element of the forced pivot: (B^-1 a_art)[minidx]
+        if (!binv_host) dp = art[rho[minidx]];
+        else for (int i = 0; i < m; i++) dp += (*binv_host)[(size_t)minidx * m + i] * art[i];
         const int slack = basic[minidx];
         if (use_bt_) rc = bt_forced_pivot(P, 1, 1e-10, nn, qa, (int)minidx, 1);
         else rc = tab_forced_pivot(P, 1, 1e-10, nn, qa, n, 0.0, (int)minidx, dp, xb[minidx], slack, 4, 0);
         if (rc != GOMILP_OK) return rc;
         basic[minidx] = n;
-        nonbasic[qa] = slack;  // ascending order is preserved: every structural id < slack id < n
+        nonbasic[qa] = slack;  // slack basis: ascending order is preserved (every structural id < slack id < n)
+        {
+            // general basis: the replaced variable may belong earlier in the ascending list of simplex.go:174-184
+            std::vector<int32_t> asc = nonbasic;
+            std::sort(asc.begin(), asc.end());
+            if (asc != nonbasic) {
+                std::vector<int32_t> pos_of(n + 1, -1), srcpos(nn);
+                for (int jp = 0; jp < nn; jp++) pos_of[nonbasic[jp]] = jp;
+                for (int jp = 0; jp < nn; jp++) srcpos[jp] = pos_of[asc[jp]];
+                HIP_TRY(hipMemcpy(w.srcpos, srcpos.data(), (size_t)nn * sizeof(int32_t), hipMemcpyHostToDevice));
+                launch_tab_permute_cols(w.T[tcur_], ldt_, w.T[tcur_ ^ 1], ldt_, m, nn, w.srcpos, stream_);
+                launches_++;
+                tcur_ ^= 1;
+                nonbasic = asc;
+            }
+        }
         if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return rc;
         launch_tab_r(w.T[tcur_], ldt_, m, nn, P.dc1, w.basic, w.nonbasic, w.tscratch, w.R[rcur_], stream_);
         launches_ += 2;

@@ -268,3 +268,53 @@ def test_frontier_pool_matches_oracle(workers):
             assert np.array_equal(res.x[i], o.x[:n0]) and res.z[i] == o.z
     assert res.stats["relaxations"] == len(children) and res.stats["workers"] == workers
     assert O.OK in statuses
+
+
+# ---- reference golden vectors through the C-ABI (general initial basis: no slack structure in K2-K8) ----------------
+
+def _gpu_simplex_fn(ctx):
+    def fn(c, A, b):
+        rl = ctx.upload(c, A, b)
+        r = rl.solve(0.0)
+        rl.free()
+        return O.LPResult(status=r.status, z=r.z, x=r.x, basis=r.basis)
+    return fn
+
+
+@pytest.mark.parametrize("kat", KATS["milp"], ids=[k["id"] for k in KATS["milp"]])
+def test_reference_milp_goldens_on_gpu(ctx, kat):
+    """K1-K8 of /root/reference/ilp_test.go and api_test.go: every LP relaxation of the branch-and-bound runs on the
+    GPU (through the C-ABI); the expected x and z are the literals the reference asserts with reflect.DeepEqual / ==."""
+    arr = lambda v: None if v is None else np.array(v, dtype=np.float64)
+    res = O.solve_milp(arr(kat["c"]), arr(kat["A"]), arr(kat["b"]), arr(kat["G"]), arr(kat["h"]), kat["integrality"],
+                       max_nodes=60, simplex_fn=_gpu_simplex_fn(ctx))
+    assert res.error == kat["want_err"]
+    if kat["want_err"] is None:
+        assert np.array_equal(res.x, arr(kat["want_x"])), (res.x.tolist(), kat["want_x"])
+        if kat["want_z"] is not None:
+            assert res.z == kat["want_z"]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_general_initial_basis_random_equality_lps(ctx, seed):
+    """LPs with equality rows and no slack structure (getRandomMILP-style N(0,1) data, ilp_test.go:370-429):
+    findLinearlyIndependent's general case + Phase I from a non-permutation basis."""
+    rng = np.random.default_rng(seed)
+    m, n = 6 + seed, 15 + 2 * seed
+    A = rng.standard_normal((m, n))
+    x0 = np.abs(rng.standard_normal(n))
+    b = A @ x0                      # feasible by construction
+    c = np.abs(rng.standard_normal(n))  # bounded below on x >= 0
+    _check_against_oracle_general(ctx, c, A, b)
+
+
+def _check_against_oracle_general(ctx, c, A, b):
+    o = O.simplex(c, A, b, 0.0, None, trace=True)
+    rl = ctx.upload(c, A, b)
+    g = rl.solve(0.0, trace=True)
+    rl.free()
+    assert g.status == o.status, (lp.STATUS_NAMES[g.status], O.STATUS_NAMES[o.status])
+    if o.x is not None:
+        assert _same_trace(g.pivots, o.pivots)
+        assert np.array_equal(g.basis, o.basis)
+        assert np.array_equal(g.x, o.x) and g.z == o.z
