@@ -42,6 +42,7 @@ def main() -> int:
     ap.add_argument("--frontier-vars", type=int, default=8, help="C5: 2^k children from the k highest fractional integer vars (0 = skip)")
     ap.add_argument("--workers", type=int, default=8, help="engine contexts (HIP streams) per GPU for the frontier")
     ap.add_argument("--frontier-cpu-children", type=int, default=8, help="children timed on the CPU oracle")
+    ap.add_argument("--milp-nodes", type=int, default=127, help="C3: node budget of the host B&B over GPU relaxations (0 = skip)")
     args = ap.parse_args()
 
     import numpy as np
@@ -163,6 +164,25 @@ def main() -> int:
         }
         pool.close()
 
+    # ---- C3: host branch-and-bound (tree.go semantics, gomilp_amd/bnb.py) driving GPU relaxations, rank 0 only ----
+    milp_out = None
+    if args.milp_nodes > 0 and rank == 0:
+        from gomilp_amd import bnb
+        m3, seed3 = synth.CONFIGS["C3"]
+        c3, G3, h3 = synth.dense_lp_inequality_form(m3, seed3)
+        int3 = [j % 4 == 0 for j in range(m3)]
+        bnb.solve_milp(c3, None, None, G3, h3, int3, max_nodes=15, workers=args.workers, device=local_rank)  # warm-up
+        tm0 = time.perf_counter()
+        mres = bnb.solve_milp(c3, None, None, G3, h3, int3, max_nodes=args.milp_nodes, workers=args.workers, device=local_rank)
+        tm = time.perf_counter() - tm0
+        milp_out = {"workload": "C3: random MILP %dx%d (seed %d), 25%% integer vars, FIFO B&B, node budget %d"
+                                % (m3, 2 * m3, seed3, args.milp_nodes),
+                    "relaxations": mres.relaxations, "waves": mres.waves, "pivots": mres.pivots, "seconds": tm,
+                    "relaxations_per_s": mres.relaxations / tm, "result": mres.error or "optimal",
+                    "incumbent_z": None if mres.x is None else mres.z}
+    if dist is not None:
+        dist.barrier()
+
     if rank == 0:
         value = piv_all / dt_max
         nn = n - m
@@ -250,6 +270,8 @@ def main() -> int:
                                                 "kind": "port", "sample": "first %d children of the same wave, one oracle "
                                                 "solve per host thread (mirrors Problem.SetWorkers), %.1f s wall" % (len(sample), tcb)}
             out["frontier"] = frontier_out
+        if milp_out is not None:
+            out["milp_c3"] = milp_out
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
