@@ -34,10 +34,9 @@ constexpr int kBtThreads = 1024;
 constexpr int kBtWaves = kBtThreads / 64;
 constexpr int kBtMaxK = 32;
 
-struct BtCand {
-    unsigned long long k;
+struct BtCand {   // (sort key, index): payloads (pivot element, x_B[p]) are published through LDS by the owner of the
+    unsigned long long k;   // winning row after the reduction, so the reduction moves 3 dwords instead of 5
     unsigned int i;
-    double d;
 };
 __device__ __forceinline__ void bt_take(BtCand &a, const BtCand &b) {
     if (b.k < a.k || (b.k == a.k && b.i < a.i)) a = b;
@@ -55,9 +54,6 @@ __device__ __forceinline__ BtCand dpp_cand(const BtCand &a) {
     const unsigned int klo = dpp_u32<CTRL>((unsigned int)a.k), khi = dpp_u32<CTRL>((unsigned int)(a.k >> 32));
     b.k = ((unsigned long long)khi << 32) | klo;
     b.i = dpp_u32<CTRL>(a.i);
-    const unsigned long long db = (unsigned long long)__double_as_longlong(a.d);
-    const unsigned int dlo = dpp_u32<CTRL>((unsigned int)db), dhi = dpp_u32<CTRL>((unsigned int)(db >> 32));
-    b.d = __longlong_as_double((long long)(((unsigned long long)dhi << 32) | dlo));
     return b;
 }
 __device__ __forceinline__ BtCand readlane_cand(const BtCand &a, int lane) {
@@ -66,10 +62,6 @@ __device__ __forceinline__ BtCand readlane_cand(const BtCand &a, int lane) {
     const unsigned int khi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(a.k >> 32), lane);
     b.k = ((unsigned long long)khi << 32) | klo;
     b.i = (unsigned int)__builtin_amdgcn_readlane((int)a.i, lane);
-    const unsigned long long db = (unsigned long long)__double_as_longlong(a.d);
-    const unsigned int dlo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)db, lane);
-    const unsigned int dhi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(db >> 32), lane);
-    b.d = __longlong_as_double((long long)(((unsigned long long)dhi << 32) | dlo));
     return b;
 }
 // reduce within each row of 16 lanes: afterwards lane 15 of every row holds that row's argmin
@@ -92,7 +84,7 @@ __device__ __forceinline__ void bt_block_argmin(BtCand &a, BtCand *sm) {
     if (lane == 0) sm[wv] = w;
     __syncthreads();
     BtCand c;
-    c.k = ~0ull; c.i = 0xFFFFFFFFu; c.d = 0;
+    c.k = ~0ull; c.i = 0xFFFFFFFFu;
     if (lane < NW) c = sm[lane];
     row_argmin(c);  // NW <= 16: one row
     a = readlane_cand(c, 15);
@@ -119,6 +111,8 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     double *r_s = sh;                 // ldt
     double *xb_s = sh + a.ldt;        // ldu
+    int *basic_s = reinterpret_cast<int *>(sh + a.ldt + a.ldu);  // m   (the commit is LDS-only: no dependent global loads
+    int *nonbasic_s = basic_s + a.ldu;                           // nn   on the critical path; written back at the end)
     __shared__ BtCand sm2[2 * 16];
     int sm_par = 0;
     __shared__ double vq[kBtMaxK], up[kBtMaxK];
@@ -131,6 +125,8 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
     }
     for (int j = tid; j < a.ldt; j += kBtThreads) r_s[j] = a.r[j];
     for (int i = tid; i < a.ldu; i += kBtThreads) xb_s[i] = a.xb[i];
+    for (int i = tid; i < a.m; i += kBtThreads) basic_s[i] = a.basic[i];
+    for (int j = tid; j < a.nn; j += kBtThreads) nonbasic_s[j] = a.nonbasic[j];
     __syncthreads();
     const double inf = __builtin_inf();
     int kd = 0, status = ST_RUNNING, blands = 0;
@@ -178,7 +174,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
     // ratio vector (simplex.go:321-340) and its first-index argmin, winner carries d_i
     auto ratio = [&](const double (&dcol)[RI], double (&mvv)[RI]) -> BtCand {
         BtCand c;
-        c.k = ~0ull; c.i = 0xFFFFFFFFu; c.d = 0;
+        c.k = ~0ull; c.i = 0xFFFFFFFFu;
 #pragma unroll
         for (int s = 0; s < RI; s++) {
             const int i = tid + s * kBtThreads;
@@ -188,7 +184,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
                 if (fabs(d) < 1e-13) d = 0;
                 mvv[s] = (d >= 0) ? inf : xb_s[i] / fabs(d);
                 BtCand b;
-                b.k = ordkey(mvv[s]); b.i = (unsigned int)i; b.d = dcol[s];
+                b.k = ordkey(mvv[s]); b.i = (unsigned int)i;
                 bt_take(c, b);
             }
         }
@@ -202,16 +198,16 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
         const bool forced = (k == 0 && a.forced_q >= 0);
         stamp(0);
         int q, p;
-        double rq, dpv;
+        double rq, dpv = 1.0;
         bool bland = false;
         double dcol[RI], mvv[RI];
         if (!forced) {
             // ---- entering position: first index of min r (simplex.go:247)
             BtCand c;
-            c.k = ~0ull; c.i = 0xFFFFFFFFu; c.d = 0;
+            c.k = ~0ull; c.i = 0xFFFFFFFFu;
             for (int j = tid; j < a.nn; j += kBtThreads) {
                 BtCand b;
-                b.k = ordkey(r_s[j]); b.i = (unsigned int)j; b.d = 0;
+                b.k = ordkey(r_s[j]); b.i = (unsigned int)j;
                 bt_take(c, b);
             }
             bt_block_argmin<kBtWaves>(c, sm2 + kBtWaves * (sm_par ^= 1));
@@ -223,7 +219,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
             stamp(2);
             BtCand w = ratio(dcol, mvv);
             stamp(3);
-            p = (int)w.i; dpv = w.d;
+            p = (int)w.i;
             const double mv = orddecode(w.k);
             if (mv == inf) { status = ST_UNBOUNDED; break; }  // simplex.go:328-330
             if (mv <= 0) {
@@ -235,7 +231,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
                 bool found = false;
                 for (;;) {
                     BtCand f;
-                    f.k = ~0ull; f.i = 0xFFFFFFFFu; f.d = 0;
+                    f.k = ~0ull; f.i = 0xFFFFFFFFu;
                     for (int j = tid; j < a.nn; j += kBtThreads) {
                         if (j <= cand) continue;
                         double rv = r_s[j];
@@ -249,16 +245,16 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
                     BtCand w2 = ratio(dcol, mvv);
                     const double mv2 = orddecode(w2.k);
                     if (mv2 == inf) { status = ST_UNBOUNDED; break; }  // computeMove inside Bland, :356-360
-                    if (fabs(mv2) > 1e-12) { q = cand; p = (int)w2.i; dpv = w2.d; found = true; break; }  // :362
+                    if (fabs(mv2) > 1e-12) { q = cand; p = (int)w2.i; found = true; break; }  // :362
                     BtCand g;
-                    g.k = ~0ull; g.i = 0xFFFFFFFFu; g.d = 0;
+                    g.k = ~0ull; g.i = 0xFFFFFFFFu;
 #pragma unroll
                     for (int s = 0; s < RI; s++) {
                         const int i = tid + s * kBtThreads;
-                        if (i < a.m && !(mvv[s] > 1e-12)) { BtCand b; b.k = 0; b.i = (unsigned int)i; b.d = dcol[s]; bt_take(g, b); }
+                        if (i < a.m && !(mvv[s] > 1e-12)) { BtCand b; b.k = 0; b.i = (unsigned int)i; bt_take(g, b); }
                     }
                     bt_block_argmin<kBtWaves>(g, sm2 + kBtWaves * (sm_par ^= 1));
-                    if (g.i != 0xFFFFFFFFu) { q = cand; p = (int)g.i; dpv = g.d; found = true; break; }  // :368-379
+                    if (g.i != 0xFFFFFFFFu) { q = cand; p = (int)g.i; found = true; break; }  // :368-379
                 }
                 if (status == ST_UNBOUNDED) break;
                 if (!found) { status = ST_BLAND_FAILED; break; }
@@ -267,29 +263,28 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
         } else {
             q = a.forced_q; p = a.forced_p; rq = 0;
             column(q, k, dcol);
-            if (tid == (p % kBtThreads)) s_bcast[0] = dcol[p / kBtThreads];
-            __syncthreads();
-            dpv = s_bcast[0];
         }
-        // ---- row p of the current tableau for this thread's columns
-        if (KREG > 0) {
-            if (tid == (p & (kBtThreads - 1))) {
-                const int sp = p / kBtThreads;
+        // ---- row p of the current tableau for this thread's columns; its owner publishes the pivot element d_p and
+        // x_B[p] (so the reductions carry no payload) and, when the block terms live in registers, its u entries
+        if (tid == (p & (kBtThreads - 1))) {
+            const int sp = p / kBtThreads;
 #pragma unroll
-                for (int s = 0; s < RI; s++)
-                    if (s == sp) {
+            for (int s = 0; s < RI; s++)
+                if (s == sp) {
+                    s_bcast[0] = dcol[s];
+                    s_bcast[1] = xb_s[p];
+                    if (KREG > 0) {
 #pragma unroll
                         for (int j = 0; j < KR; j++) up[j] = ureg[s][j];
                     }
-            }
-        } else if (tid < k) {
-            up[tid] = __hip_atomic_load(a.U + (size_t)tid * a.ldu + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
         }
+        if (KREG == 0 && tid < k) up[tid] = __hip_atomic_load(a.U + (size_t)tid * a.ldu + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         stamp(4);
+        dpv = s_bcast[0];
         const double mult = rq / dpv;
-        const double theta = xb_s[p] / dpv;
-        __syncthreads();  // everybody has read xb_s[p] before it is overwritten
+        const double theta = s_bcast[1] / dpv;
         double *Vk = a.V + (size_t)k * a.ldt;
         double *Uk = a.U + (size_t)k * a.ldu;
 #pragma unroll
@@ -342,8 +337,8 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
         }
         stamp(5);
         if (tid == 0 && !(forced && a.forced_nocommit)) {  // simplex.go:280
-            const int ent = a.nonbasic[q], lea = a.basic[p];
-            a.basic[p] = ent; a.nonbasic[q] = lea;
+            const int ent = nonbasic_s[q], lea = basic_s[p];
+            basic_s[p] = ent; nonbasic_s[q] = lea;
             if (a.trace && st->trace_len < a.trace_cap) {
                 DevPivot &tr = a.trace[st->trace_len];
                 tr.phase = a.phase; tr.bland = bland ? 1 : 0; tr.min_idx = q; tr.replace = p; tr.entering = ent; tr.leaving = lea;
@@ -359,6 +354,8 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
     }
     for (int j = tid; j < a.ldt; j += kBtThreads) a.r[j] = r_s[j];
     for (int i = tid; i < a.ldu; i += kBtThreads) a.xb[i] = xb_s[i];
+    for (int i = tid; i < a.m; i += kBtThreads) a.basic[i] = basic_s[i];
+    for (int j = tid; j < a.nn; j += kBtThreads) a.nonbasic[j] = nonbasic_s[j];
     if (tid == 0) {
         st->kdone = kd;
         st->bland_steps += blands;
@@ -434,7 +431,10 @@ static BtCfg bt_cfg(int m, int ldt) {
     }
     return {1024, 8, 8, 0};
 }
-bool bt_supported(int m, int nn) { return m <= 8 * 1024 && nn + 511 <= 8 * 1024; }
+bool bt_supported(int m, int nn) {  // r, x_B (doubles) and the two index lists (ints) live in LDS: 12 bytes per row + column
+    const long ldt = ((nn + 511) / 512) * 512, ldu = (m + 1) & ~1;
+    return m <= 8 * 1024 && ldt <= 8 * 1024 && (ldt + ldu) * 12 <= 140 * 1024;
+}
 int bt_reg_k(int m, int ldt) { return bt_cfg(m, ldt).kreg; }
 template <int NT>
 static void bt_launch_nt(const BTArgs &a, const BtCfg &c, bool reg, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
@@ -445,7 +445,7 @@ static void bt_launch_nt(const BTArgs &a, const BtCfg &c, bool reg, size_t lds, 
 #undef GOMILP_BT_LAUNCH
 }
 void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    const size_t lds = (size_t)(a.ldt + a.ldu) * sizeof(double);
+    const size_t lds = (size_t)(a.ldt + a.ldu) * sizeof(double) + (size_t)(a.ldu + a.ldt) * sizeof(int);
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner<1024, 4, 4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);

@@ -558,7 +558,8 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
             const int j = w.h_idx[pos];
             ur[pos] = (j < P.n && P.nnz[j] == 1 && P.allone[j]) ? P.lastrow[j] : -1;
         }
-        HIP_TRY(hipMemcpy(w.unitrow, ur.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(w.unitrow, ur.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
     }
     LUArgs a;
     a.W = w.W; a.ldw = ldw; a.m = m; a.lpos = w.lpos; a.rowstep = w.rowstep;

@@ -301,8 +301,8 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
     std::vector<double> art(P.ld, 0.0);  // Phase-I artificial column (simplex.go:533-542)
     auto set_up_T = [&](int nn) -> int {  // T = B^-1 A_N
         ldt_ = tab_ld(nn);
-        HIP_TRY(hipMemsetAsync(w.T[0], 0, (size_t)m * ldt_ * sizeof(double), stream_));
         if (!binv_host) {  // slack basis: B^-1 is the permutation rho
+            HIP_TRY(hipMemsetAsync(w.T[0], 0, (size_t)m * ldt_ * sizeof(double), stream_));
             launch_tab_gather(P.dAt, P.ld, m, nn, w.nonbasic, w.rho, w.T[0], ldt_, stream_);
             launches_++;
             return GOMILP_OK;
@@ -319,7 +319,9 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
                 Th[(size_t)pos * ldt_ + jp] = s;
             }
         }
-        HIP_TRY(hipMemcpy(w.T[0], Th.data(), Th.size() * sizeof(double), hipMemcpyHostToDevice));
+        // same stream as everything else (a null-stream copy is not ordered against the non-blocking stream)
+        HIP_TRY(hipMemcpyAsync(w.T[0], Th.data(), Th.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));  // Th is a local
         return GOMILP_OK;
     };
     int nn;
@@ -367,7 +369,8 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
                 std::vector<int32_t> pos_of(n + 1, -1), srcpos(nn);
                 for (int jp = 0; jp < nn; jp++) pos_of[nonbasic[jp]] = jp;
                 for (int jp = 0; jp < nn; jp++) srcpos[jp] = pos_of[asc[jp]];
-                HIP_TRY(hipMemcpy(w.srcpos, srcpos.data(), (size_t)nn * sizeof(int32_t), hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpyAsync(w.srcpos, srcpos.data(), (size_t)nn * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+                HIP_TRY(hipStreamSynchronize(stream_));
                 launch_tab_permute_cols(w.T[tcur_], ldt_, w.T[tcur_ ^ 1], ldt_, m, nn, w.srcpos, stream_);
                 launches_++;
                 tcur_ ^= 1;
