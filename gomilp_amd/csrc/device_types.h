@@ -135,6 +135,7 @@ struct LUArgs {
     unsigned int *pr[2];        // physical row of the candidate
     DevState *st;
     const int32_t *unit_row;    // per column: row of the 1 when the column of ab is a unit vector, else -1 (nullable)
+    int32_t *dense_flag;        // per step: 1 when the step did arithmetic (0 = unit-column fast path); nullable
 };
 
 }  // namespace gomilp

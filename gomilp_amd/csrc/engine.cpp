@@ -75,7 +75,8 @@ int Engine::ensure_work(int m, int ncols) {
     HIP_TRY(dmalloc(&w.yscratch, (size_t)64 * nld));
     HIP_TRY(dmalloc(&w.basic, (size_t)nm)); HIP_TRY(dmalloc(&w.nonbasic, (size_t)nc));
     HIP_TRY(dmalloc(&w.lpos, (size_t)nm)); HIP_TRY(dmalloc(&w.rowstep, (size_t)nm)); HIP_TRY(dmalloc(&w.rho, (size_t)nm));
-    HIP_TRY(dmalloc(&w.unitrow, (size_t)nm));
+    HIP_TRY(dmalloc(&w.unitrow, (size_t)nm)); HIP_TRY(dmalloc(&w.denseflag, (size_t)nm)); HIP_TRY(dmalloc(&w.dlist, (size_t)nm));
+    HIP_TRY(dmalloc(&w.ludiag, (size_t)nm)); HIP_TRY(dmalloc(&w.Wd, (size_t)nm * nld));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_W), (size_t)nm * nld * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_vec), (size_t)std::max(nld, nc) * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_idx), (size_t)std::max(nm, nc) * sizeof(int32_t), hipHostMallocDefault));
@@ -566,11 +567,32 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     for (int t = 0; t < 2; t++) { a.pk[t] = w.lpk[t]; a.pl[t] = w.lpl[t]; a.pr[t] = w.lpr[t]; }
     a.st = w.st;
     a.unit_row = w.unitrow;
+    const bool blocked = lu_blocked_ && lu_blocked_supported(m);
+    a.dense_flag = blocked ? w.denseflag : nullptr;
     w.st_host->lu_singular = 0;
     sync_state_to_device();
-    if (lu_blocked_ && lu_blocked_supported(m)) launches_ += launch_lu_blocked(a, w.rho, stream_) + 1;
+    if (blocked) launches_ += launch_lu_blocked(a, w.rho, stream_) + 1;
     else { launch_lu(a, stream_); launches_ += m + 2; }
-    HIP_TRY(hipMemcpyAsync(w.h_W, w.W, (size_t)m * ldw * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    // Only the columns whose elimination step did arithmetic carry non-zero L / off-diagonal U entries (a unit-column
+    // step has zero multipliers and its column is zero in every earlier pivot row), so the host solves need those
+    // columns and the diagonal only: m*(nd+1) doubles cross PCIe instead of m*m.
+    std::vector<int32_t> dl;
+    if (blocked) {
+        HIP_TRY(hipMemcpyAsync(w.h_idx, w.denseflag, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        for (int k = 0; k < m; k++) if (w.h_idx[k]) dl.push_back(k);
+    } else {
+        for (int k = 0; k < m; k++) dl.push_back(k);
+    }
+    const int nd = (int)dl.size();
+    lu_dense_ = nd;
+    if (nd) HIP_TRY(hipMemcpyAsync(w.dlist, dl.data(), (size_t)nd * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    double *Wd = w.Wd;
+    launch_lu_pack(a, w.dlist, nd, Wd, w.ludiag, stream_);
+    launches_++;
+    if (nd) HIP_TRY(hipMemcpyAsync(w.h_W, Wd, (size_t)m * nd * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(w.h_vec, w.ludiag, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(w.h_idx, w.lpos, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -579,9 +601,10 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     fs_device_ += tf1 - tf0;
     std::vector<int32_t> phys(m);
     for (int R = 0; R < m; R++) phys[w.h_idx[R]] = R;
+    const double *diag = w.h_vec;
     // LU.Det() == 0 (mat/lu.go:301, :118-135): exp(sum log|u_ii|) == 0
     double logdet = 0;
-    for (int i = 0; i < m; i++) logdet += log(fabs(w.h_W[(size_t)phys[i] * ldw + i]));
+    for (int i = 0; i < m; i++) logdet += log(fabs(diag[phys[i]]));
     *singular = w.st_host->lu_singular != 0 || exp(logdet) == 0;
     x.assign(m, 0.0);
     if (*singular) return GOMILP_OK;
@@ -589,24 +612,25 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     for (int i = 0; i < m; i++) x[i] = P.hb[phys[i]];
     // Dtrsm(Left, Lower, NoTrans, Unit): ascending k, zero multipliers skipped, (-l)*b_k + b_i
     for (int i = 0; i < m; i++) {
-        const double *row = w.h_W + (size_t)phys[i] * ldw;
+        const double *row = w.h_W + (size_t)phys[i] * nd;
         double bi = x[i];
-        for (int k = 0; k < i; k++) {
-            const double va = row[k];
-            if (va != 0) bi = (-va) * x[k] + bi;
+        for (int t = 0; t < nd && dl[t] < i; t++) {
+            const double va = row[t];
+            if (va != 0) bi = (-va) * x[dl[t]] + bi;
         }
         x[i] = bi;
     }
     // Dtrsm(Left, Upper, NoTrans, NonUnit): rows from the bottom, ascending k, then * (1/u_ii)
     for (int i = m - 1; i >= 0; i--) {
-        const double *row = w.h_W + (size_t)phys[i] * ldw;
+        const double *row = w.h_W + (size_t)phys[i] * nd;
         double bi = x[i];
-        for (int k = i + 1; k < m; k++) {
-            const double va = row[k];
-            if (va != 0) bi = (-va) * x[k] + bi;
+        int t0 = (int)(std::upper_bound(dl.begin(), dl.end(), i) - dl.begin());
+        for (int t = t0; t < nd; t++) {
+            const double va = row[t];
+            if (va != 0) bi = (-va) * x[dl[t]] + bi;
         }
-        const double t = 1 / row[i];
-        x[i] = bi * t;
+        const double tinv = 1 / diag[phys[i]];
+        x[i] = bi * tinv;
     }
     fs_host_ += now_s() - tf1;
     return GOMILP_OK;
@@ -633,6 +657,7 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     auto finish = [&](int code) {
         st->seconds_total = now_s() - t0; st->kernel_launches = launches_;
         st->seconds_final_device = fs_device_; st->seconds_final_host = fs_host_;
+        st->lu_dense_steps = lu_dense_;
         return code;
     };
     launches_ = 0;

@@ -91,6 +91,7 @@ class Engine {
     bool use_bt_ = false;  // blocked tableau (deferred rank-K updates) instead of one launch per pivot  // tableau pipeline: current T / r buffer, row length of T  // workgroups of the last ratio-test kernel (partials to reduce)
     int64_t launches_ = 0;
     double fs_device_ = 0, fs_host_ = 0;
+    int64_t lu_dense_ = 0;
     std::vector<gomilp_pivot> last_trace_;
     int64_t last_trace_total_ = 0;
 };
@@ -147,5 +148,6 @@ void launch_lu(const LUArgs &a, hipStream_t s);
 // lu_kernels.hip
 bool lu_blocked_supported(int m);
 int launch_lu_blocked(const LUArgs &a, int32_t *pivrow, hipStream_t s);
+void launch_lu_pack(const LUArgs &a, const int32_t *dlist, int nd, double *Wd, double *diag, hipStream_t s);
 
 }  // namespace gomilp

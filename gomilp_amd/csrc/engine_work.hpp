@@ -72,6 +72,9 @@ struct Engine::Work {
     double *btU = nullptr, *btV = nullptr;  // blocked tableau: rank-1 terms of the running block
     int32_t *srcpos = nullptr;
     int32_t *unitrow = nullptr;  // final solve: unit-column rows per basis position
+    int32_t *denseflag = nullptr, *dlist = nullptr;  // final solve: steps that did arithmetic / their compact list
+    double *ludiag = nullptr;   // diagonal of U by physical row
+    double *Wd = nullptr;       // packed dense columns of L\\U for the host solves (m x nd)
     size_t cap_T = 0;  // doubles per T buffer
     int cap_ldt = 0;
     DevState *st = nullptr;
@@ -88,8 +91,8 @@ struct Engine::Work {
 
     void release() {
         for (auto &p : binv) { if (p) hipFree(p); p = nullptr; }
-        for (double **p : {&xb, &yb[0], &yb[1], &dvec, &move, &rvec, &yscratch, &W}) { if (*p) hipFree(*p); *p = nullptr; }
-        for (int32_t **p : {&basic, &nonbasic, &lpos, &rowstep, &rho, &unitrow}) { if (*p) hipFree(*p); *p = nullptr; }
+        for (double **p : {&xb, &yb[0], &yb[1], &dvec, &move, &rvec, &yscratch, &W, &ludiag, &Wd}) { if (*p) hipFree(*p); *p = nullptr; }
+        for (int32_t **p : {&basic, &nonbasic, &lpos, &rowstep, &rho, &unitrow, &denseflag, &dlist}) { if (*p) hipFree(*p); *p = nullptr; }
         if (h_W) hipHostFree(h_W); h_W = nullptr;
         if (h_vec) hipHostFree(h_vec); h_vec = nullptr;
         if (h_idx) hipHostFree(h_idx); h_idx = nullptr;

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(T) void k_lu_panel(LUArgs a, int k0, int nb, int32_
         // (s_active[ur] is only cleared between this step's two barriers, i.e. after every thread took this test.)
         const int ur = a.unit_row ? a.unit_row[k] : -1;
         const bool trivial = (ur >= 0) && (s_active[ur] != 0);
+        if (tid == 0 && a.dense_flag) a.dense_flag[k] = trivial ? 0 : 1;
         int P, jp;
         if (!trivial) {
             unsigned long long bk = ~0ull;
@@ -228,6 +229,16 @@ __global__ __launch_bounds__(256) void k_lu_trail(LUArgs a, int k0, int nb, cons
     }
 }
 
+// Wd[R*nd + t] = W[R][dlist[t]] (the columns whose elimination step did arithmetic) and diag[R] = W[R][lpos[R]]:
+// everything the host triangular solves need, m*(nd+1) doubles instead of m*m
+__global__ void k_lu_pack(LUArgs a, const int32_t *__restrict__ dlist, int nd, double *__restrict__ Wd, double *__restrict__ diag) {
+    const int R = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const double *row = a.W + (size_t)R * a.ldw;
+    if (t < nd) Wd[(size_t)R * nd + t] = row[dlist[t]];
+    if (blockIdx.x == 0 && threadIdx.x == 0) diag[R] = row[a.lpos[R]];
+}
+
 __global__ void k_lu_blocked_init(LUArgs a) {
     const int R = blockIdx.x * blockDim.x + threadIdx.x;
     if (R < a.m) { a.lpos[R] = R; a.rowstep[R] = -1; }
@@ -249,6 +260,11 @@ static void lu_blocked_t(const LUArgs &a, int32_t *pivrow, hipStream_t s) {
 }
 
 bool lu_blocked_supported(int m) { return m <= 4096; }
+
+void launch_lu_pack(const LUArgs &a, const int32_t *dlist, int nd, double *Wd, double *diag, hipStream_t s) {
+    dim3 grid((nd + 255) / 256 > 0 ? (nd + 255) / 256 : 1, a.m);
+    hipLaunchKernelGGL(k_lu_pack, grid, dim3(256), 0, s, a, dlist, nd, Wd, diag);
+}
 
 // returns the number of kernel launches enqueued
 int launch_lu_blocked(const LUArgs &a, int32_t *pivrow, hipStream_t s) {

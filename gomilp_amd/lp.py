@@ -37,7 +37,7 @@ class Stats(C.Structure):
         ("phase1_used", C.c_int32), ("device_id", C.c_int32), ("wrapped_status", C.c_int32), ("reserved", C.c_int32),
         ("seconds_total", C.c_double), ("seconds_upload", C.c_double), ("seconds_pivot_loop", C.c_double),
         ("seconds_final_solve", C.c_double), ("drift_xb", C.c_double), ("pivot_kernel_seconds", C.c_double * 4),
-        ("seconds_final_device", C.c_double), ("seconds_final_host", C.c_double),
+        ("seconds_final_device", C.c_double), ("seconds_final_host", C.c_double), ("lu_dense_steps", C.c_int64),
     ]
 
 

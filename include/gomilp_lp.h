@@ -61,6 +61,7 @@ typedef struct gomilp_lp_stats {
                                        [2] update(+ftran) kernel, [3] number of sampled pivots */
     double seconds_final_device; /* part of seconds_final_solve: gather + LU kernels + device->host copy */
     double seconds_final_host;   /* part of seconds_final_solve: the two triangular solves on the host */
+    int64_t lu_dense_steps;      /* elimination steps of the final LU that did arithmetic (the rest hit the unit-column fast path) */
 } gomilp_lp_stats;
 
 /* One record per pivot, execution order (Phase I first).  Same fields as the oracle's trace. */
