@@ -1,3 +1,5 @@
+"""Developer tool: per-phase cycle counts of k_bt_inner (s_memtime stamps, enabled by GOMILP_BT_PROF=1).
+Run on the GPU box: gpurun -- python tools/btprof.py"""
 import sys, os, ctypes as C; sys.path.insert(0,'/root/repo')
 os.environ['GOMILP_BT_PROF']='1'
 from gomilp_amd import lp, synth

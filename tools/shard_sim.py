@@ -1,3 +1,5 @@
+"""Developer tool: projects the N-GPU time of the C5 frontier wave by solving the N shards of
+frontier.shard_indices one after the other on one GPU."""
 import sys, time; sys.path.insert(0,'/root/repo')
 from gomilp_amd import lp, synth, frontier
 import numpy as np
