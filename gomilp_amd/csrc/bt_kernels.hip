@@ -34,62 +34,6 @@ constexpr int kBtThreads = 1024;
 constexpr int kBtWaves = kBtThreads / 64;
 constexpr int kBtMaxK = 32;
 
-struct BtCand {   // (sort key, index): payloads (pivot element, x_B[p]) are published through LDS by the owner of the
-    unsigned long long k;   // winning row after the reduction, so the reduction moves 3 dwords instead of 5
-    unsigned int i;
-};
-__device__ __forceinline__ void bt_take(BtCand &a, const BtCand &b) {
-    if (b.k < a.k || (b.k == a.k && b.i < a.i)) a = b;
-}
-// ---- DPP reductions.  A ds_bpermute-based __shfl_xor butterfly costs ~400 cycles per round (5 dwords through the
-// LDS crossbar); the two workgroup-wide argmins per pivot were 2/3 of the inner kernel's time.  DPP row shifts are
-// plain VALU moves: 4 row_shr steps leave each 16-lane row's result in its last lane, v_readlane combines the rows.
-template <int CTRL>
-__device__ __forceinline__ unsigned int dpp_u32(unsigned int v) {
-    return (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);  // lanes without a source keep v
-}
-template <int CTRL>
-__device__ __forceinline__ BtCand dpp_cand(const BtCand &a) {
-    BtCand b;
-    const unsigned int klo = dpp_u32<CTRL>((unsigned int)a.k), khi = dpp_u32<CTRL>((unsigned int)(a.k >> 32));
-    b.k = ((unsigned long long)khi << 32) | klo;
-    b.i = dpp_u32<CTRL>(a.i);
-    return b;
-}
-__device__ __forceinline__ BtCand readlane_cand(const BtCand &a, int lane) {
-    BtCand b;
-    const unsigned int klo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)a.k, lane);
-    const unsigned int khi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(a.k >> 32), lane);
-    b.k = ((unsigned long long)khi << 32) | klo;
-    b.i = (unsigned int)__builtin_amdgcn_readlane((int)a.i, lane);
-    return b;
-}
-// reduce within each row of 16 lanes: afterwards lane 15 of every row holds that row's argmin
-__device__ __forceinline__ void row_argmin(BtCand &a) {
-    bt_take(a, dpp_cand<0x111>(a));  // row_shr:1
-    bt_take(a, dpp_cand<0x112>(a));  // row_shr:2
-    bt_take(a, dpp_cand<0x114>(a));  // row_shr:4
-    bt_take(a, dpp_cand<0x118>(a));  // row_shr:8
-}
-// argmin over the whole 1024-thread workgroup; result (uniform) in every thread.  `sm` is double buffered by the
-// caller (sm + 16*parity) so that one barrier per reduction is enough.
-template <int NW>
-__device__ __forceinline__ void bt_block_argmin(BtCand &a, BtCand *sm) {
-    row_argmin(a);
-    BtCand w = readlane_cand(a, 15);
-    bt_take(w, readlane_cand(a, 31));
-    bt_take(w, readlane_cand(a, 47));
-    bt_take(w, readlane_cand(a, 63));
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) sm[wv] = w;
-    __syncthreads();
-    BtCand c;
-    c.k = ~0ull; c.i = 0xFFFFFFFFu;
-    if (lane < NW) c = sm[lane];
-    row_argmin(c);  // NW <= 16: one row
-    a = readlane_cand(c, 15);
-}
-
 // RI / CJ: rows / columns per thread (m <= RI*1024, n-m <= CJ*1024).
 // KREG > 0: the block's rank-1 terms of a thread's OWN rows / columns live in registers (newest first, shifted
 // every pivot), foreign scalars travel through LDS — the single CU that runs this kernel then touches global memory

@@ -124,6 +124,20 @@ struct BTArgs {
     int32_t pad;
 };
 
+// Control block of the compressed LU schedule (lu_compressed.hip): written by the panel kernel of a round, read by the
+// U-solve / trailing kernels of the same round and by the host between batches of rounds.
+struct LUCtl {
+    int32_t k_next;     // first elimination step not performed yet
+    int32_t k0, k1;     // steps [k0, k1) were performed by the last round
+    int32_t nsteps;     // how many of them did arithmetic ("dense" steps)
+    int32_t ncols;      // columns the panel held in registers at its start (>= nsteps)
+    int32_t rounds;     // rounds that did work
+    int32_t pad[2];
+    int32_t steps[32];  // step (= column) index of each dense step, ascending
+    int32_t prow[32];   // its pivot row
+    int32_t cols[32];   // the register columns of the panel, ascending (cols[0..nsteps) == steps)
+};
+
 // Arguments of the gonum-order LU kernels (final basis solve).
 struct LUArgs {
     double *W;          // m x ldw working copy of ab (simplex.go:144), overwritten by L\U in place (rows never move)
@@ -136,6 +150,7 @@ struct LUArgs {
     DevState *st;
     const int32_t *unit_row;    // per column: row of the 1 when the column of ab is a unit vector, else -1 (nullable)
     int32_t *dense_flag;        // per step: 1 when the step did arithmetic (0 = unit-column fast path); nullable
+    LUCtl *ctl;                 // compressed schedule only
 };
 
 }  // namespace gomilp

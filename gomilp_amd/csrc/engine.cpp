@@ -37,7 +37,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "max_pivots") max_pivots_ = v < 0 ? 0 : v;
     else if (key == "sample_events") sample_events_ = v < 0 ? 0 : v;
     else if (key == "fused") fused_ = v ? 1 : 0;
-    else if (key == "lu_blocked") lu_blocked_ = v ? 1 : 0;
+    else if (key == "lu_blocked") lu_blocked_ = v < 0 ? 0 : (v > 2 ? 2 : v);  // 0 per column, 1 blocked panels, 2 compressed rounds
     else if (key == "tableau") tableau_ = v ? 1 : 0;
     else if (key == "blocked") blocked_ = v ? 1 : 0;
     else if (key == "block_k") { if (v < 0 || v > bt_max_k()) return GOMILP_ERR_BAD_SHAPE; block_k_ = v; }
@@ -58,6 +58,8 @@ int Engine::ensure_work(int m, int ncols) {
         }
         HIP_TRY(dmalloc(&w.st, 1));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.st_host), sizeof(DevState), hipHostMallocDefault));
+        HIP_TRY(dmalloc(&w.luctl, 1));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.luctl_host), sizeof(LUCtl), hipHostMallocDefault));
         w.trace_cap = 1 << 18;
         HIP_TRY(dmalloc(&w.trace, (size_t)w.trace_cap));
         HIP_TRY(hipEventCreate(&w.ev[0])); HIP_TRY(hipEventCreate(&w.ev[1]));
@@ -549,6 +551,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     Work &w = *w_;
     const double tf0 = now_s();
     const int m = P.m, ldw = P.ld;
+    int nonunit = 0;
     launch_gather_w(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
     // unit columns of ab (from the column statistics of the upload): the blocked LU skips their elimination steps
     HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
@@ -558,6 +561,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
         for (int pos = 0; pos < m; pos++) {
             const int j = w.h_idx[pos];
             ur[pos] = (j < P.n && P.nnz[j] == 1 && P.allone[j]) ? P.lastrow[j] : -1;
+            if (ur[pos] < 0) nonunit++;
         }
         HIP_TRY(hipMemcpyAsync(w.unitrow, ur.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
@@ -567,11 +571,30 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     for (int t = 0; t < 2; t++) { a.pk[t] = w.lpk[t]; a.pl[t] = w.lpl[t]; a.pr[t] = w.lpr[t]; }
     a.st = w.st;
     a.unit_row = w.unitrow;
-    const bool blocked = lu_blocked_ && lu_blocked_supported(m);
+    const bool compressed = lu_blocked_ >= 2 && lu_compressed_supported(m);
+    const bool blocked = compressed || (lu_blocked_ && lu_blocked_supported(m));
     a.dense_flag = blocked ? w.denseflag : nullptr;
+    a.ctl = w.luctl;
     w.st_host->lu_singular = 0;
     sync_state_to_device();
-    if (blocked) launches_ += launch_lu_blocked(a, w.rho, stream_) + 1;
+    lu_rounds_ = 0;
+    if (compressed) {
+        // rounds are data dependent (lu_compressed.hip): enqueue a batch, read the control block, repeat.  The first
+        // batch is sized from the number of columns that are dense for sure.
+        launch_luc_init(a, stream_);
+        launches_++;
+        const int nb = lu_compressed_nb(m);
+        int batch = std::max(4, (nonunit + nb - 1) / nb + 2);
+        for (;;) {
+            launches_ += launch_luc_rounds(a, w.rho, batch, stream_);
+            HIP_TRY(hipMemcpyAsync(w.luctl_host, w.luctl, sizeof(LUCtl), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipStreamSynchronize(stream_));
+            if (w.luctl_host->k_next >= m) break;
+            batch = std::max(4, (int)(((int64_t)(m - w.luctl_host->k_next) * w.luctl_host->rounds) / std::max(1, w.luctl_host->k_next)) + 2);
+            if (batch > 64) batch = 64;
+        }
+        lu_rounds_ = w.luctl_host->rounds;
+    } else if (blocked) launches_ += launch_lu_blocked(a, w.rho, stream_) + 1;
     else { launch_lu(a, stream_); launches_ += m + 2; }
     // Only the columns whose elimination step did arithmetic carry non-zero L / off-diagonal U entries (a unit-column
     // step has zero multipliers and its column is zero in every earlier pivot row), so the host solves need those
@@ -583,6 +606,14 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
         for (int k = 0; k < m; k++) if (w.h_idx[k]) dl.push_back(k);
     } else {
         for (int k = 0; k < m; k++) dl.push_back(k);
+    }
+    if (const char *dump = getenv("GOMILP_LU_DUMP")) {  // developer aid: pivot rows / dense flags of the schedule that ran
+        std::vector<int32_t> pv(m), df(m, 1);
+        hipMemcpy(pv.data(), w.rho, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (blocked) hipMemcpy(df.data(), w.denseflag, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost);
+        FILE *probe = fopen(dump, "rb");   // keep the first call's dump
+        if (probe) fclose(probe);
+        else if (FILE *f = fopen(dump, "wb")) { fwrite(pv.data(), 4, m, f); fwrite(df.data(), 4, m, f); fclose(f); }
     }
     const int nd = (int)dl.size();
     lu_dense_ = nd;
@@ -657,7 +688,7 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     auto finish = [&](int code) {
         st->seconds_total = now_s() - t0; st->kernel_launches = launches_;
         st->seconds_final_device = fs_device_; st->seconds_final_host = fs_host_;
-        st->lu_dense_steps = lu_dense_;
+        st->lu_dense_steps = lu_dense_; st->lu_rounds = lu_rounds_;
         return code;
     };
     launches_ = 0;

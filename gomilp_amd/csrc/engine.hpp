@@ -82,7 +82,7 @@ class Engine {
     std::vector<std::unique_ptr<Problem>> child_pool_;  // released children, buffers kept
     std::unique_ptr<Work> w_;
     // knobs
-    int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 1, tableau_ = 1, blocked_ = 1, block_k_ = 0;  // block_k_ 0 = auto
+    int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 2, tableau_ = 1, blocked_ = 1, block_k_ = 0;  // block_k_ 0 = auto
     // per-solve state
     int cur_ = 0;   // which Binv buffer is current
     int ycur_ = 0;  // which y buffer is current
@@ -91,7 +91,7 @@ class Engine {
     bool use_bt_ = false;  // blocked tableau (deferred rank-K updates) instead of one launch per pivot  // tableau pipeline: current T / r buffer, row length of T  // workgroups of the last ratio-test kernel (partials to reduce)
     int64_t launches_ = 0;
     double fs_device_ = 0, fs_host_ = 0;
-    int64_t lu_dense_ = 0;
+    int64_t lu_dense_ = 0, lu_rounds_ = 0;
     std::vector<gomilp_pivot> last_trace_;
     int64_t last_trace_total_ = 0;
 };
@@ -148,6 +148,11 @@ void launch_lu(const LUArgs &a, hipStream_t s);
 // lu_kernels.hip
 bool lu_blocked_supported(int m);
 int launch_lu_blocked(const LUArgs &a, int32_t *pivrow, hipStream_t s);
+// lu_compressed.hip
+bool lu_compressed_supported(int m);
+int lu_compressed_nb(int m);
+void launch_luc_init(const LUArgs &a, hipStream_t s);
+int launch_luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t s);
 void launch_lu_pack(const LUArgs &a, const int32_t *dlist, int nd, double *Wd, double *diag, hipStream_t s);
 
 }  // namespace gomilp

@@ -79,6 +79,7 @@ struct Engine::Work {
     int cap_ldt = 0;
     DevState *st = nullptr;
     DevState *st_host = nullptr;  // pinned
+    LUCtl *luctl = nullptr, *luctl_host = nullptr;  // compressed LU schedule: control block (device / pinned)
     DevPivot *trace = nullptr;
     int64_t trace_cap = 0;
     double *h_W = nullptr;  // pinned, cap_m * cap_ld

@@ -62,6 +62,7 @@ typedef struct gomilp_lp_stats {
     double seconds_final_device; /* part of seconds_final_solve: gather + LU kernels + device->host copy */
     double seconds_final_host;   /* part of seconds_final_solve: the two triangular solves on the host */
     int64_t lu_dense_steps;      /* elimination steps of the final LU that did arithmetic (the rest hit the unit-column fast path) */
+    int64_t lu_rounds;           /* panel rounds of the compressed LU schedule (0 for the other schedules) */
 } gomilp_lp_stats;
 
 /* One record per pivot, execution order (Phase I first).  Same fields as the oracle's trace. */

@@ -175,7 +175,7 @@ def test_blocked_lu_equals_per_column_lu_bitwise(m, seed):
     as the one-launch-per-column schedule (simplex_kernels.hip k_lu_step), which the small cases pin to the oracle."""
     c, A, b = synth.dense_lp_standard_form(m, seed)
     res = []
-    for blocked in (1, 0):
+    for blocked in (2, 1, 0):   # compressed rounds (default), blocked panels, one launch per column
         cx = lp.Context(lu_blocked=blocked)
         try:
             rl = cx.upload(c, A, b)
@@ -183,9 +183,11 @@ def test_blocked_lu_equals_per_column_lu_bitwise(m, seed):
             rl.free()
         finally:
             cx.close()
-    assert res[0].status == lp.OK == res[1].status
-    assert np.array_equal(res[0].basis, res[1].basis)
-    assert np.array_equal(res[0].x, res[1].x) and res[0].z == res[1].z
+    for r in res[:2]:
+        assert r.status == lp.OK == res[2].status
+        assert np.array_equal(r.basis, res[2].basis)
+        assert np.array_equal(r.x, res[2].x) and r.z == res[2].z
+    assert res[0].stats["lu_rounds"] > 0 and res[0].stats["lu_dense_steps"] == res[1].stats["lu_dense_steps"]
     # the unit-column fast path of the panel kernel must be deterministic (it once raced: repeat the solve)
     cx = lp.Context()
     try:
