@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "device_types.h"
 #include "kernels_common.h"
@@ -307,6 +308,335 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
     }
 }
 
+// ---- register-resident variant (m <= RI*NT, ldt <= CJ*NT, KR block terms in registers) ----------------------------
+// k_bt_inner above is VALU-issue bound (about 1600 instructions per wave and pivot, 4 waves per SIMD): (key, index)
+// candidates dragged through 64-bit integer compares, five barriers, r / x_B traffic through LDS.  This variant:
+//  * a thread's OWN r_j, u_k[i], v_k'[j] live in registers, x_B[i] in LDS slots only its owner touches;
+//  * first-index argmin without index payloads: v_min_f64 over DPP row shifts gives the minimum M, then
+//    ballot(value == M) + ff1 gives the first lane, slot by slot — exactly floats.MinIdx (NaN never wins because
+//    v_min_f64 returns the other operand, -0 == +0, first index among equals);
+//  * the lane that owns a wave's winner publishes, next to the wave's (M, index), the scalars everybody needs about
+//    it (r_q and v'_k[q]; d_p, x_B[p] and u_k[p]), so the two reductions are the only two barriers of a pivot;
+//  * one division per pivot for the rank-1 term (u_i = d_i * (-1/d_p)) and fused multiply-adds for the block
+//    corrections: these are the engine's own running quantities, not values the reference defines bit by bit
+//    (the returned x comes from the gonum-order solve of the final basis).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned int lo = dpp_u32<CTRL>((unsigned int)b), hi = dpp_u32<CTRL>((unsigned int)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)b, lane);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// min over each 16-lane row, result in lane 15 of the row (NaN operands lose: minnum)
+__device__ __forceinline__ double row_min_f64(double x) {
+    x = __builtin_fmin(x, dpp_f64<0x111>(x));
+    x = __builtin_fmin(x, dpp_f64<0x112>(x));
+    x = __builtin_fmin(x, dpp_f64<0x114>(x));
+    x = __builtin_fmin(x, dpp_f64<0x118>(x));
+    return x;
+}
+__device__ __forceinline__ double wave_min_f64(double x) {
+    x = row_min_f64(x);
+    return __builtin_fmin(__builtin_fmin(readlane_f64(x, 15), readlane_f64(x, 31)), __builtin_fmin(readlane_f64(x, 47), readlane_f64(x, 63)));
+}
+__device__ __forceinline__ unsigned int row_min_u32(unsigned int x) {
+    x = min(x, dpp_u32<0x111>(x));
+    x = min(x, dpp_u32<0x112>(x));
+    x = min(x, dpp_u32<0x114>(x));
+    x = min(x, dpp_u32<0x118>(x));
+    return x;
+}
+
+struct BtWin { double m; unsigned int i; };   // minimum and the first index that attains it (0xFFFFFFFF: none, all NaN)
+
+template <int NT, int RI, int CJ, int KR>
+__global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) double sh2[];
+    double *xb_s = sh2;              // ldu    x_B and r: every thread touches only its own rows / columns (no barrier
+    double *r_s = sh2 + a.ldu;       // CJ*NT  needed); kept out of the register file, which the block terms fill
+    int *basic_s = reinterpret_cast<int *>(sh2 + a.ldu + CJ * NT);  // m   only thread 0 touches the lists inside the loop
+    int *nonbasic_s = basic_s + a.ldu;                    // nn
+    __shared__ double redMA[16], redMB[16];
+    __shared__ unsigned int redIA[16], redIB[16];
+    __shared__ double payA[16][KR + 1];  // per wave: r_q, v'_k[q]
+    __shared__ double payB[16][KR + 2];  // per wave: d_p, x_B[p], u_k[p]
+    DevState *st = a.st;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
+    if (st->done) {
+        if (tid == 0) st->kdone = 0;
+        return;
+    }
+    const double inf = __builtin_inf();
+    const unsigned int ldt = (unsigned int)a.ldt;
+    double ureg[RI][KR], vreg[CJ][KR];
+#pragma unroll
+    for (int s = 0; s < RI; s++) {
+        const int i = tid + s * NT;
+        if (i < a.ldu) xb_s[i] = i < a.m ? a.xb[i] : 0.0;
+#pragma unroll
+        for (int j = 0; j < KR; j++) ureg[s][j] = 0;
+    }
+#pragma unroll
+    for (int s = 0; s < CJ; s++) {
+        const int j = tid + s * NT;
+        r_s[j] = j < a.nn ? a.r[j] : inf;   // padding never wins an argmin
+#pragma unroll
+        for (int j2 = 0; j2 < KR; j2++) vreg[s][j2] = 0;
+    }
+    for (int i = tid; i < a.m; i += NT) basic_s[i] = a.basic[i];
+    for (int j = tid; j < a.nn; j += NT) nonbasic_s[j] = a.nonbasic[j];
+    if (tid < KR + 1) payA[0][tid] = 0;   // a host-chosen first pivot reads v'_k[q] = 0 from here
+    __syncthreads();
+    int kd = 0, status = ST_RUNNING, blands = 0;
+
+    // ---- floats.MinIdx over N slots per thread (slot s of thread t is index t + s*NT)
+    auto wave_first_min = [&](auto &val, auto nslots) -> BtWin {
+        constexpr int N = decltype(nslots)::value;
+        double x = val[0];
+#pragma unroll
+        for (int s = 1; s < N; s++) x = __builtin_fmin(x, val[s]);
+        BtWin w;
+        w.m = wave_min_f64(x);
+        w.i = 0xFFFFFFFFu;
+#pragma unroll
+        for (int s = N - 1; s >= 0; s--) {
+            const unsigned long long mask = __ballot(val[s] == w.m);
+            if (mask) w.i = (unsigned int)(s * NT + wbase + __builtin_ctzll(mask));
+        }
+        return w;
+    };
+    auto block_first_min = [&](const double *redM, const unsigned int *redI) -> BtWin {
+        const double x = lane < NW ? redM[lane] : inf;
+        const unsigned int ii = lane < NW ? redI[lane] : 0xFFFFFFFFu;
+        BtWin f;
+        f.m = readlane_f64(row_min_f64(x), 15);
+        const unsigned int key = (x == f.m) ? ii : 0xFFFFFFFFu;
+        f.i = (unsigned int)__builtin_amdgcn_readlane((int)row_min_u32(key), 15);
+        return f;
+    };
+    // entering column: returns (min, q); r_q and v'_k[q] through payA
+    auto reduce_cols = [&](double (&val)[CJ], double &rq, const double *&vq) -> BtWin {
+        const BtWin w = wave_first_min(val, std::integral_constant<int, CJ>());
+#pragma unroll
+        for (int s = 0; s < CJ; s++)
+            if ((unsigned int)(tid + s * NT) == w.i) {
+                payA[wv][0] = r_s[tid + s * NT];
+#pragma unroll
+                for (int j = 0; j < KR; j++) payA[wv][1 + j] = vreg[s][j];
+            }
+        if (lane == 0) { redMA[wv] = w.m; redIA[wv] = w.i; }
+        __syncthreads();
+        const BtWin f = block_first_min(redMA, redIA);
+        const int ww = (f.i & (NT - 1)) >> 6;
+        rq = payA[ww][0];
+        vq = &payA[ww][1];
+        return f;
+    };
+    // leaving row: returns (min, p); d_p, x_B[p] and u_k[p] through payB
+    auto reduce_rows = [&](double (&val)[RI], const double (&dcol)[RI], double &dp, double &xp, const double *&up) -> BtWin {
+        const BtWin w = wave_first_min(val, std::integral_constant<int, RI>());
+#pragma unroll
+        for (int s = 0; s < RI; s++)
+            if ((unsigned int)(tid + s * NT) == w.i) {
+                payB[wv][0] = dcol[s];
+                payB[wv][1] = xb_s[tid + s * NT];
+#pragma unroll
+                for (int j = 0; j < KR; j++) payB[wv][2 + j] = ureg[s][j];
+            }
+        if (lane == 0) { redMB[wv] = w.m; redIB[wv] = w.i; }
+        __syncthreads();
+        const BtWin f = block_first_min(redMB, redIB);
+        const int ww = (f.i & (NT - 1)) >> 6;
+        dp = payB[ww][0];
+        xp = payB[ww][1];
+        up = &payB[ww][2];
+        return f;
+    };
+    // column q of the current tableau for this thread's rows
+    auto column = [&](int q, const double *vq, double (&dcol)[RI]) {
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            const int i = tid + s * NT;
+            const unsigned int ic = (unsigned int)(i < a.m ? i : a.m - 1);
+            double d = a.T[ic * ldt + (unsigned int)q];
+#pragma unroll
+            for (int j = 0; j < KR; j++) d = __builtin_fma(ureg[s][j], vq[j], d);
+            dcol[s] = i < a.m ? d : 0.0;
+        }
+    };
+    // ratio vector (simplex.go:321-340); rows beyond m carry +Inf
+    auto ratios = [&](const double (&dcol)[RI], double (&mvv)[RI]) {
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            const int i = tid + s * NT;
+            double d = -dcol[s];
+            if (fabs(d) < 1e-13) d = 0;
+            mvv[s] = (d >= 0 || i >= a.m) ? inf : xb_s[i < a.ldu ? i : 0] / fabs(d);
+        }
+    };
+
+    long long tstamp = clock64();
+    auto stamp = [&](int slot) { if (a.pad && tid == 0) { long long now = clock64(); g_bt_prof[slot] += now - tstamp; tstamp = now; } };
+    for (int k = 0; k < a.kmax; k++) {
+        const bool forced = (k == 0 && a.forced_q >= 0);
+        stamp(0);
+        int q, p;
+        double rq = 0, dpv = 1.0, xbp = 0;
+        const double *vq = &payA[0][1], *up = &payB[0][2];
+        bool bland = false;
+        double dcol[RI];
+        if (!forced) {
+            // ---- entering position: first index of min r (simplex.go:247)
+            BtWin fq;
+            {
+                double rv[CJ];
+#pragma unroll
+                for (int s = 0; s < CJ; s++) rv[s] = r_s[tid + s * NT];
+                fq = reduce_cols(rv, rq, vq);
+            }
+            q = (int)fq.i;
+            if (fq.i >= (unsigned int)a.nn) { q = 0; rq = __builtin_nan(""); }  // every r_j is NaN: MinIdx returns 0
+            stamp(1);
+            if (rq >= -a.tol) { status = ST_OPTIMAL; break; }  // simplex.go:248
+            column(q, vq, dcol);
+            if (a.pad) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(2); }
+            BtWin w;
+            {
+                double mvv[RI];
+                ratios(dcol, mvv);
+                w = reduce_rows(mvv, dcol, dpv, xbp, up);
+            }
+            p = (int)w.i;
+            stamp(3);
+            const double mv = w.m;
+            if (mv == inf || w.i >= (unsigned int)a.m) { status = ST_UNBOUNDED; break; }  // simplex.go:328-330
+            if (mv <= 0) {
+                // ---- replaceBland (simplex.go:347-383): candidates in position order with r_i <= -1e-14 after the
+                // 1e-13 rounding of :252-256; the mat.Cond guard of :377 is replaced by |d| >= 1e-13
+                bland = true;
+                blands++;
+                int cand = -1;
+                bool found = false;
+                for (;;) {
+                    double fl[CJ];
+#pragma unroll
+                    for (int s = 0; s < CJ; s++) {
+                        const int j = tid + s * NT;
+                        double rv = r_s[j];
+                        if (fabs(rv) < 1e-13) rv = 0;
+                        fl[s] = (j < a.nn && j > cand && !(rv > -1e-14)) ? 0.0 : inf;
+                    }
+                    double rqc;
+                    const BtWin fc = reduce_cols(fl, rqc, vq);
+                    if (fc.m != 0.0) break;  // candidates exhausted -> ErrBland
+                    cand = (int)fc.i;
+                    column(cand, vq, dcol);
+                    BtWin w2;
+                    {
+                        double mvv[RI];
+                        ratios(dcol, mvv);
+                        w2 = reduce_rows(mvv, dcol, dpv, xbp, up);
+                    }
+                    const double mv2 = w2.m;
+                    if (mv2 == inf || w2.i >= (unsigned int)a.m) { status = ST_UNBOUNDED; break; }  // computeMove inside Bland, :356-360
+                    if (fabs(mv2) > 1e-12) { q = cand; p = (int)w2.i; rq = rqc; found = true; break; }  // :362
+                    double gl[RI];
+                    ratios(dcol, gl);
+#pragma unroll
+                    for (int s = 0; s < RI; s++) {
+                        const int i = tid + s * NT;
+                        gl[s] = (i < a.m && !(gl[s] > 1e-12)) ? 0.0 : inf;
+                    }
+                    __syncthreads();   // two row reductions in a row: everyone is done with the first one's LDS slots
+                    const BtWin gw = reduce_rows(gl, dcol, dpv, xbp, up);
+                    if (gw.m == 0.0) { q = cand; p = (int)gw.i; rq = rqc; found = true; break; }  // :368-379
+                }
+                if (status == ST_UNBOUNDED) break;
+                if (!found) { status = ST_BLAND_FAILED; break; }
+            }
+        } else {
+            // set-up pivot chosen by the host: first pivot of a block, so the block terms are all zero
+            q = a.forced_q; p = a.forced_p; rq = 0;
+            column(q, vq, dcol);   // vq -> the zeros written before the loop
+            double gl[RI];
+#pragma unroll
+            for (int s = 0; s < RI; s++) gl[s] = (tid + s * NT == p) ? 0.0 : inf;
+            reduce_rows(gl, dcol, dpv, xbp, up);
+        }
+        // ---- row p of the current tableau for this thread's columns, reduced costs, block terms
+        const double mult = rq / dpv;
+        const double theta = xbp / dpv;
+        const double rinv = 1.0 / dpv, nrinv = -rinv;
+        double *Vk = a.V + (size_t)k * a.ldt;
+        double *Uk = a.U + (size_t)k * a.ldu;
+#pragma unroll
+        for (int s = 0; s < CJ; s++) {
+            const int j = tid + s * NT;
+            if (j < a.ldt) {
+                double v = a.T[(unsigned int)p * ldt + (unsigned int)j];   // columns nn..ldt of T are zero
+#pragma unroll
+                for (int jj = 0; jj < KR; jj++) v = __builtin_fma(up[jj], vreg[s][jj], v);
+                // reduced costs (positional): r_j - (r_q/d_p) v_j ; the leaving variable takes slot q
+                r_s[j] = (j == q) ? -mult : __builtin_fma(-mult, v, r_s[j]);
+                const double vprime = (j == q) ? dpv + 1.0 : v;
+                Vk[j] = vprime;
+#pragma unroll
+                for (int jj = KR - 1; jj > 0; jj--) vreg[s][jj] = vreg[s][jj - 1];
+                vreg[s][0] = vprime;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            const int i = tid + s * NT;
+            if (i < a.ldu) {
+                const double u = (i == p) ? rinv - 1.0 : dcol[s] * nrinv;   // rows >= m: dcol = 0
+                if (i < a.m) xb_s[i] = (i == p) ? theta : __builtin_fma(-theta, dcol[s], xb_s[i]);
+                Uk[i] = u;
+#pragma unroll
+                for (int jj = KR - 1; jj > 0; jj--) ureg[s][jj] = ureg[s][jj - 1];
+                ureg[s][0] = u;
+            }
+        }
+        if (tid == 0 && !(forced && a.forced_nocommit)) {  // simplex.go:280
+            const int ent = nonbasic_s[q], lea = basic_s[p];
+            basic_s[p] = ent; nonbasic_s[q] = lea;
+            if (a.trace && st->trace_len < a.trace_cap) {
+                DevPivot &tr = a.trace[st->trace_len];
+                tr.phase = a.phase; tr.bland = bland ? 1 : 0; tr.min_idx = q; tr.replace = p; tr.entering = ent; tr.leaving = lea;
+            }
+            st->trace_len += 1;
+            st->pivots += 1;
+        }
+        kd = k + 1;
+        if (a.pad) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(5); if (tid == 0) g_bt_prof[15] += 1; }
+    }
+#pragma unroll
+    for (int s = 0; s < CJ; s++) {
+        const int j = tid + s * NT;
+        if (j < a.ldt) a.r[j] = j < a.nn ? r_s[j] : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < RI; s++) {
+        const int i = tid + s * NT;
+        if (i < a.ldu) a.xb[i] = xb_s[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < a.m; i += NT) a.basic[i] = basic_s[i];
+    for (int j = tid; j < a.nn; j += NT) a.nonbasic[j] = nonbasic_s[j];
+    if (tid == 0) {
+        st->kdone = kd;
+        st->bland_steps += blands;
+        if (status != ST_RUNNING) { st->done = 1; st->status = status; }
+    }
+}
+
 // T[i, j] += sum_{k < kdone} U[k][i] * V[k][j]  — in place, one streaming pass.
 // Workgroup = 4 waves x 128 columns (one double2 per lane) over `rows_per_wg` rows; each lane keeps its V column
 // pair for all k in registers, the u scalars of the row block sit in LDS.
@@ -383,6 +713,13 @@ int bt_reg_k(int m, int ldt) { return bt_cfg(m, ldt).kreg; }
 template <int NT>
 static void bt_launch_nt(const BTArgs &a, const BtCfg &c, bool reg, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
 #define GOMILP_BT_LAUNCH(RI, CJ, KR) hipExtLaunchKernelGGL((k_bt_inner<NT, RI, CJ, KR>), dim3(1), dim3(NT), lds, s, e0, e1, 0, a)
+    if (reg && !getenv("GOMILP_BT_OLD")) {
+        const size_t lds2 = (size_t)(a.ldu + c.cj * NT) * sizeof(double) + (size_t)(a.ldu + a.ldt) * sizeof(int);
+        if (c.ri == 2) { hipExtLaunchKernelGGL((k_bt_inner2<NT, 2, 2, 8>), dim3(1), dim3(NT), lds2, s, e0, e1, 0, a); return; }
+        if constexpr (NT <= 512) {
+            if (c.ri == 4) { hipExtLaunchKernelGGL((k_bt_inner2<NT, 4, 4, 8>), dim3(1), dim3(NT), lds2, s, e0, e1, 0, a); return; }
+        }
+    }
     if (c.ri == 2) { if (reg) GOMILP_BT_LAUNCH(2, 2, 8); else GOMILP_BT_LAUNCH(2, 2, 0); }
     else if (c.ri == 4) { if (reg && NT <= 512) GOMILP_BT_LAUNCH(4, 4, (NT <= 512 ? 8 : 0)); else GOMILP_BT_LAUNCH(4, 4, 0); }
     else { if (reg && NT <= 256) GOMILP_BT_LAUNCH(8, 8, (NT <= 256 ? 8 : 0)); else GOMILP_BT_LAUNCH(8, 8, 0); }

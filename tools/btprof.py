@@ -9,6 +9,6 @@ for m,seed in ((512,3),(2048,2)):
     cx=lp.Context(); rl=cx.upload(c,A,b); rl.solve(0.0)
     buf=(C.c_longlong*16)(); L.gomilp_dbg_bt_prof(buf,1)
     r=rl.solve(0.0); L.gomilp_dbg_bt_prof(buf,0)
-    n=buf[15]; names=['loop-top','argmin r','column','ratio','row-stage','row+update','commit+sync']
+    n=buf[15]; names=['loop-top','argmin r','column','ratio+argmin','-','row+update','-']
     print(m,'pivots',n, {names[i]: round(buf[i]/n/100*1.0,2) for i in range(7)}, 'sum(us @100MHz?)', round(sum(buf[:7])/n/100,2))
     cx.close()
