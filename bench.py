@@ -225,10 +225,11 @@ def main() -> int:
         nsamp = max(ksec[3], 1.0)
         extra = {}
         if pipeline == "blocked":
-            # K pivots per k_bt_inner launch (one workgroup, latency-bound: no HBM roofline applies to it) followed by ONE
-            # streaming launch k_bt_update that reads and writes T = B^-1 A_N once: 16*m*(n-m) bytes, HBM-bound.
+            # K pivots per k_bt_inner2 launch (one workgroup, latency-bound: no HBM roofline applies to it) followed by ONE
+            # streaming launch k_bt_update_tiled that reads and writes T = B^-1 A_N once: 16*m*(n-m) bytes, HBM-bound.
+            # (Shapes whose block terms do not fit in registers run k_bt_inner / k_bt_update on row-major T instead.)
             nblocks = max(ksec[1], 1.0)
-            kernel_name, bytes_update, bytes_moved = "k_bt_update", 16.0 * m * nn, 16.0 * m * nn
+            kernel_name, bytes_update, bytes_moved = ("k_bt_update_tiled" if m <= 2048 and nn <= 2048 else "k_bt_update"), 16.0 * m * nn, 16.0 * m * nn
             t_upd = ksec[2] / nblocks
             t_inner = ksec[0] / nblocks
             extra = {"block_pivots": nsamp / nblocks, "k_bt_inner_us_per_launch": 1e6 * t_inner,

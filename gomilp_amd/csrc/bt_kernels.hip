@@ -332,17 +332,24 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(b >> 32), lane);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// v_min_f64 directly: minnum semantics in hardware (a NaN operand loses); __builtin_fmin would add a v_max_f64 x,x
+// canonicalisation per operand, doubling the instruction count of the reductions
+__device__ __forceinline__ double vmin_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // min over each 16-lane row, result in lane 15 of the row (NaN operands lose: minnum)
 __device__ __forceinline__ double row_min_f64(double x) {
-    x = __builtin_fmin(x, dpp_f64<0x111>(x));
-    x = __builtin_fmin(x, dpp_f64<0x112>(x));
-    x = __builtin_fmin(x, dpp_f64<0x114>(x));
-    x = __builtin_fmin(x, dpp_f64<0x118>(x));
+    x = vmin_f64(x, dpp_f64<0x111>(x));
+    x = vmin_f64(x, dpp_f64<0x112>(x));
+    x = vmin_f64(x, dpp_f64<0x114>(x));
+    x = vmin_f64(x, dpp_f64<0x118>(x));
     return x;
 }
 __device__ __forceinline__ double wave_min_f64(double x) {
     x = row_min_f64(x);
-    return __builtin_fmin(__builtin_fmin(readlane_f64(x, 15), readlane_f64(x, 31)), __builtin_fmin(readlane_f64(x, 47), readlane_f64(x, 63)));
+    return vmin_f64(vmin_f64(readlane_f64(x, 15), readlane_f64(x, 31)), vmin_f64(readlane_f64(x, 47), readlane_f64(x, 63)));
 }
 __device__ __forceinline__ unsigned int row_min_u32(unsigned int x) {
     x = min(x, dpp_u32<0x111>(x));
@@ -352,6 +359,7 @@ __device__ __forceinline__ unsigned int row_min_u32(unsigned int x) {
     return x;
 }
 
+__device__ __forceinline__ unsigned int tile_off(unsigned int i, unsigned int j, unsigned int ldt);
 struct BtWin { double m; unsigned int i; };   // minimum and the first index that attains it (0xFFFFFFFF: none, all NaN)
 
 template <int NT, int RI, int CJ, int KR>
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
         constexpr int N = decltype(nslots)::value;
         double x = val[0];
 #pragma unroll
-        for (int s = 1; s < N; s++) x = __builtin_fmin(x, val[s]);
+        for (int s = 1; s < N; s++) x = vmin_f64(x, val[s]);
         BtWin w;
         w.m = wave_min_f64(x);
         w.i = 0xFFFFFFFFu;
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
         for (int s = 0; s < RI; s++) {
             const int i = tid + s * NT;
             const unsigned int ic = (unsigned int)(i < a.m ? i : a.m - 1);
-            double d = a.T[ic * ldt + (unsigned int)q];
+            double d = a.T[tile_off(ic, (unsigned int)q, ldt)];   // T in 4x4 tiles (k_bt_tile)
 #pragma unroll
             for (int j = 0; j < KR; j++) d = __builtin_fma(ureg[s][j], vq[j], d);
             dcol[s] = i < a.m ? d : 0.0;
@@ -580,7 +588,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
         for (int s = 0; s < CJ; s++) {
             const int j = tid + s * NT;
             if (j < a.ldt) {
-                double v = a.T[(unsigned int)p * ldt + (unsigned int)j];   // columns nn..ldt of T are zero
+                double v = a.T[tile_off((unsigned int)p, (unsigned int)j, ldt)];   // columns nn..ldt of T are zero
 #pragma unroll
                 for (int jj = 0; jj < KR; jj++) v = __builtin_fma(up[jj], vreg[s][jj], v);
                 // reduced costs (positional): r_j - (r_q/d_p) v_j ; the leaving variable takes slot q
@@ -675,6 +683,80 @@ __global__ __launch_bounds__(kBlock) void k_bt_update(BTArgs a, int rows_per_wg)
     }
 }
 
+
+// ---- 4x4-tile layout of T for the register-resident inner kernel ---------------------------------------------------
+// One workgroup reads a whole column (ratio test) and a whole row (reduced costs) of T per pivot.  Row-major T makes
+// the column a gather of m separate 128-byte lines (8 useful bytes each) through ONE CU's L1 — 256 KB of fill traffic
+// per pivot at m = 2048, the largest item of the pivot's critical path.  In 4x4 tiles (one tile = one 128-byte line,
+// tile (I, J) at ((I * ldt/4) + J) * 16, element (i&3)*4 + (j&3)) a column and a row both touch m/4 resp. (n-m)/4
+// lines: 4x less fill for the column, 4x more for the (cheap) row, half in total.  The layout is private to the block
+// loop: k_bt_tile converts on entry and exit (two streaming passes per pivot LOOP, not per pivot).
+__device__ __forceinline__ unsigned int tile_off(unsigned int i, unsigned int j, unsigned int ldt) {
+    return ((i >> 2) * (ldt >> 2) + (j >> 2)) * 16u + ((i & 3u) << 2) + (j & 3u);
+}
+
+// one thread = one 32-byte piece (4 consecutive columns of one row); threads follow the tiled side's memory order
+__global__ __launch_bounds__(256) void k_bt_tile(const double *__restrict__ src, double *__restrict__ dst, int m, int ldt, int to_tiles) {
+    const unsigned int c = blockIdx.x * 256u + threadIdx.x;        // piece index on the tiled side
+    const unsigned int per_tilerow = (unsigned int)ldt;             // (ldt/4 tiles) * 4 pieces
+    const unsigned int I = c / per_tilerow, rem = c % per_tilerow;
+    const unsigned int J = rem >> 2, r = rem & 3u;
+    const unsigned int i = I * 4u + r, j = J * 4u;
+    const unsigned int m4 = ((unsigned int)m + 3u) & ~3u;
+    if (i >= m4) return;
+    const size_t toff = (size_t)c * 4u, roff = (size_t)i * (unsigned int)ldt + j;
+    if (to_tiles) {
+        double2 lo = make_double2(0, 0), hi = make_double2(0, 0);
+        if (i < (unsigned int)m) { lo = *reinterpret_cast<const double2 *>(src + roff); hi = *reinterpret_cast<const double2 *>(src + roff + 2); }
+        *reinterpret_cast<double2 *>(dst + toff) = lo;
+        *reinterpret_cast<double2 *>(dst + toff + 2) = hi;
+    } else if (i < (unsigned int)m) {
+        *reinterpret_cast<double2 *>(dst + roff) = *reinterpret_cast<const double2 *>(src + toff);
+        *reinterpret_cast<double2 *>(dst + roff + 2) = *reinterpret_cast<const double2 *>(src + toff + 2);
+    }
+}
+
+// T += sum_k u_k v_k'^T on the tiled layout.  Thread = one 16-byte half piece (tile column J, row-in-tile r, half h),
+// looping over `tilerows_per_wg` tile rows: consecutive lanes touch consecutive 16 bytes (the access shape of
+// k_bt_update); v_k'[4J+2h], v_k'[4J+2h+1] in registers, u in LDS.
+template <int KMAX>
+__global__ __launch_bounds__(kBlock) void k_bt_update_tiled(BTArgs a, int tilerows_per_wg) {
+    __shared__ double us[KMAX][64];
+    const int kd = a.st->kdone;
+    if (kd <= 0) return;
+    const unsigned int cx = blockIdx.x * kBlock + threadIdx.x;   // half piece within a tile row: 0 .. 2*ldt-1
+    const unsigned int J = cx >> 3, r = (cx >> 1) & 3u, h = cx & 1u;
+    const int I0 = blockIdx.y * tilerows_per_wg;
+    const int m4 = (a.m + 3) & ~3;
+    const int nI = min(tilerows_per_wg, m4 / 4 - I0);
+    for (int idx = threadIdx.x; idx < KMAX * 64; idx += kBlock) {
+        const int k = idx / 64, rr = idx % 64;
+        const int row = I0 * 4 + rr;
+        us[k][rr] = (k < kd && rr < nI * 4 && row < a.m) ? a.U[(size_t)k * a.ldu + row] : 0.0;
+    }
+    const bool inb = cx < 2u * (unsigned int)a.ldt;
+    double2 vv[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        vv[k] = make_double2(0, 0);
+        if (k < kd && inb) vv[k] = *reinterpret_cast<const double2 *>(a.V + (size_t)k * a.ldt + J * 4u + h * 2u);
+    }
+    __syncthreads();
+    if (!inb) return;
+    double2 *cell = reinterpret_cast<double2 *>(a.T) + (size_t)I0 * (unsigned int)a.ldt * 2u + cx;
+    const size_t step = (size_t)a.ldt * 2u;   // double2 per tile row
+    for (int ii = 0; ii < nI; ii++, cell += step) {
+        double2 t = *cell;
+#pragma unroll
+        for (int k = 0; k < KMAX; k++) {
+            const double u = us[k][ii * 4 + r];
+            t.x += u * vv[k].x;
+            t.y += u * vv[k].y;
+        }
+        *cell = t;
+    }
+}
+
 // ---- launch wrappers ---------------------------------------------------------------------------
 
 int bt_max_k() { return kBtMaxK; }
@@ -713,12 +795,13 @@ int bt_reg_k(int m, int ldt) { return bt_cfg(m, ldt).kreg; }
 template <int NT>
 static void bt_launch_nt(const BTArgs &a, const BtCfg &c, bool reg, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
 #define GOMILP_BT_LAUNCH(RI, CJ, KR) hipExtLaunchKernelGGL((k_bt_inner<NT, RI, CJ, KR>), dim3(1), dim3(NT), lds, s, e0, e1, 0, a)
-    if (reg && !getenv("GOMILP_BT_OLD")) {
+    if (a.tiled) {   // register-resident kernel on the tiled layout (the engine converted T: bt_tiled())
         const size_t lds2 = (size_t)(a.ldu + c.cj * NT) * sizeof(double) + (size_t)(a.ldu + a.ldt) * sizeof(int);
         if (c.ri == 2) { hipExtLaunchKernelGGL((k_bt_inner2<NT, 2, 2, 8>), dim3(1), dim3(NT), lds2, s, e0, e1, 0, a); return; }
         if constexpr (NT <= 512) {
             if (c.ri == 4) { hipExtLaunchKernelGGL((k_bt_inner2<NT, 4, 4, 8>), dim3(1), dim3(NT), lds2, s, e0, e1, 0, a); return; }
         }
+        return;   // unreachable: bt_tiled() admits exactly the two shapes above
     }
     if (c.ri == 2) { if (reg) GOMILP_BT_LAUNCH(2, 2, 8); else GOMILP_BT_LAUNCH(2, 2, 0); }
     else if (c.ri == 4) { if (reg && NT <= 512) GOMILP_BT_LAUNCH(4, 4, (NT <= 512 ? 8 : 0)); else GOMILP_BT_LAUNCH(4, 4, 0); }
@@ -739,7 +822,27 @@ void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e
     else if (c.nt == 512) bt_launch_nt<512>(a, c, reg, lds, s, e0, e1);
     else bt_launch_nt<1024>(a, c, reg, lds, s, e0, e1);
 }
+// true when launch_bt_inner picks the register-resident kernel, which works on the tiled layout of T
+bool bt_tiled(int m, int ldt, int kmax) {
+    const BtCfg c = bt_cfg(m, ldt);
+    if (getenv("GOMILP_BT_OLD") || !(c.kreg > 0 && kmax <= c.kreg)) return false;
+    return c.ri == 2 || (c.ri == 4 && c.nt <= 512);
+}
+void launch_bt_tile(const double *src, double *dst, int m, int ldt, bool to_tiles, hipStream_t s) {
+    const size_t pieces = (size_t)((m + 3) / 4) * 4 * (size_t)(ldt / 4);
+    hipLaunchKernelGGL(k_bt_tile, dim3((unsigned int)((pieces + 255) / 256)), dim3(256), 0, s, src, dst, m, ldt, to_tiles ? 1 : 0);
+}
 void launch_bt_update(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    if (a.tiled) {
+        const int gx = (2 * a.ldt + kBlock - 1) / kBlock;
+        const int ntr = (a.m + 3) / 4;
+        int tr = 16;   // tile rows per workgroup (64 rows); aim for >= 512 workgroups
+        while (tr > 2 && gx * ((ntr + tr - 1) / tr) < 512) tr >>= 1;
+        dim3 grid(gx, (ntr + tr - 1) / tr);
+        if (a.kmax <= 8) hipExtLaunchKernelGGL((k_bt_update_tiled<8>), grid, dim3(kBlock), 0, s, e0, e1, 0, a, tr);
+        else hipExtLaunchKernelGGL((k_bt_update_tiled<16>), grid, dim3(kBlock), 0, s, e0, e1, 0, a, tr);
+        return;
+    }
     const int ld2 = a.ldt / 2;
     const int gx = (ld2 + kWavesPerBlock * 64 - 1) / (kWavesPerBlock * 64);
     int rows = 64;

@@ -122,6 +122,7 @@ struct BTArgs {
     int64_t trace_cap;
     int32_t forced_q, forced_p, forced_nocommit;  // first pivot of the block chosen by the host (set-up pivots)
     int32_t pad;
+    int32_t tiled, pad2;  // T is in the 4x4-tile layout of the register-resident inner kernel
 };
 
 // Control block of the compressed LU schedule (lu_compressed.hip): written by the panel kernel of a round, read by the

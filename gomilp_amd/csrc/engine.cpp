@@ -778,10 +778,10 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     int loop_rc = GOMILP_OK;
     if (use_tab) {
         const int ldt = tab_ld(nn_max);
-        if (w.cap_T < (size_t)m * ldt || w.cap_ldt < ldt) {
+        if (w.cap_T < (size_t)(m + 3) * ldt || w.cap_ldt < ldt) {   // + 3 rows: the tiled layout pads m to a multiple of 4
             for (double **pp : {&w.T[0], &w.T[1], &w.R[0], &w.R[1], &w.tscratch, &w.btU, &w.btV}) { if (*pp) hipFree(*pp); *pp = nullptr; }
             if (w.srcpos) hipFree(w.srcpos); w.srcpos = nullptr;
-            const size_t cap = std::max(w.cap_T, (size_t)m * ldt);
+            const size_t cap = std::max(w.cap_T, (size_t)(m + 3) * ldt);
             const int cl = std::max(w.cap_ldt, ldt);
             HIP_TRY(dmalloc(&w.T[0], cap)); HIP_TRY(dmalloc(&w.T[1], cap));
             HIP_TRY(dmalloc(&w.R[0], (size_t)cl)); HIP_TRY(dmalloc(&w.R[1], (size_t)cl));

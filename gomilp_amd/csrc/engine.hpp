@@ -65,6 +65,7 @@ class Engine {
     int solve_tableau(const Problem &P, double tol, std::vector<int32_t> &basic, const std::vector<int32_t> &rho,
                       std::vector<double> &xb, bool feasible, gomilp_lp_stats *st, int *loop_rc,
                       const std::vector<double> *binv_host);
+    void bt_layout(const Problem &P, bool tiled);
     BTArgs make_bt_args(const Problem &P, int phase, double tol, int nn, int kmax);
     int bt_forced_pivot(const Problem &P, int phase, double tol, int nn, int q, int p, int nocommit);
     int run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_lp_stats *st);
@@ -88,6 +89,7 @@ class Engine {
     int ycur_ = 0;  // which y buffer is current
     int grid_ratio_ = 1;
     int tcur_ = 0, rcur_ = 0, ldt_ = 0;
+    bool t_tiled_ = false;   // layout of T[tcur_]: 4x4 tiles (blocked pipeline, register-resident kernel) or row-major
     bool use_bt_ = false;  // blocked tableau (deferred rank-K updates) instead of one launch per pivot  // tableau pipeline: current T / r buffer, row length of T  // workgroups of the last ratio-test kernel (partials to reduce)
     int64_t launches_ = 0;
     double fs_device_ = 0, fs_host_ = 0;
@@ -130,6 +132,8 @@ void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb
 bool bt_supported(int m, int nn);
 int bt_max_k();
 int bt_reg_k(int m, int ldt);
+bool bt_tiled(int m, int ldt, int kmax);
+void launch_bt_tile(const double *src, double *dst, int m, int ldt, bool to_tiles, hipStream_t s);
 void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 void launch_bt_update(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 void launch_transpose_in(const double *A, int64_t lda, int m, int n, double *At, int ld, hipStream_t s);

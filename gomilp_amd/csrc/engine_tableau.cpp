@@ -12,6 +12,7 @@ TabArgs Engine::make_tab_args(const Problem &P, int phase, double tol, int nn) {
     TabArgs a;
     memset(&a, 0, sizeof(a));
     a.m = P.m; a.nn = nn; a.ldt = ldt_; a.phase = phase; a.tol = tol;
+    bt_layout(P, false);
     a.T_cur = w.T[tcur_]; a.T_next = w.T[tcur_ ^ 1];
     a.r_in = w.R[rcur_]; a.r_out = w.R[rcur_ ^ 1];
     a.xb = w.xb; a.dvec = w.dvec; a.move = w.move;
@@ -69,6 +70,7 @@ int Engine::host_bland_tab(const Problem &P, int phase, double tol, int nn, gomi
     for (int i = 0; i < m; i++) { xb[i] = w.h_vec[i]; bas[i] = w.h_idx[i]; }
     for (int i = 0; i < nn; i++) {
         if (r[i] > -1e-14) continue;  // blandNegTol, :352
+        bt_layout(P, false);
         launch_tab_column(w.T[tcur_], ldt_, m, i, w.xb, w.dvec, w.move, stream_);
         launches_++;
         HIP_TRY(hipMemcpyAsync(w.h_vec, w.move, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
@@ -181,10 +183,23 @@ int Engine::run_loop_tab(const Problem &P, int phase, double tol, int nn, gomilp
 
 // ---- blocked tableau (bt_kernels.hip) -----------------------------------------------------------------------
 
+// T[tcur_] lives in 4x4 tiles while the register-resident block kernels run (bt_kernels.hip) and in row-major
+// order for everything else (set-up, column extraction, reduced-cost rebuild, the single-kernel pipeline).  One streaming
+// conversion into the other T buffer per change of layout.
+void Engine::bt_layout(const Problem &P, bool tiled) {
+    if (tiled == t_tiled_) return;
+    Work &w = *w_;
+    launch_bt_tile(w.T[tcur_], w.T[tcur_ ^ 1], P.m, ldt_, tiled, stream_);
+    launches_++;
+    tcur_ ^= 1;
+    t_tiled_ = tiled;
+}
+
 BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int kmax) {
     Work &w = *w_;
     BTArgs a;
     memset(&a, 0, sizeof(a));
+    a.tiled = t_tiled_ ? 1 : 0;
     a.m = P.m; a.nn = nn; a.ldt = ldt_; a.ldu = P.ld; a.phase = phase; a.kmax = kmax; a.tol = tol;
     a.T = w.T[tcur_]; a.U = w.btU; a.V = w.btV; a.r = w.R[rcur_]; a.xb = w.xb;
     a.basic = w.basic; a.nonbasic = w.nonbasic; a.st = w.st;
@@ -200,6 +215,7 @@ int Engine::bt_forced_pivot(const Problem &P, int phase, double tol, int nn, int
     DevState &hs = *w.st_host;
     hs.done = 0; hs.status = ST_RUNNING; hs.kdone = 0;
     sync_state_to_device();
+    bt_layout(P, bt_tiled(P.m, ldt_, 1));
     BTArgs a = make_bt_args(P, phase, tol, nn, 1);
     a.forced_q = q; a.forced_p = p; a.forced_nocommit = nocommit;
     launch_bt_inner(a, stream_, nullptr, nullptr);
@@ -218,6 +234,7 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
     int ret = GOMILP_OK;
     // block size: 8 when the block's rank-1 terms fit in registers (bt_kernels.hip), else 16
     const int K = block_k_ > 0 ? (int)block_k_ : (bt_reg_k(P.m, ldt_) > 0 ? 8 : 16);
+    bt_layout(P, bt_tiled(P.m, ldt_, K));
     const int64_t blocks_per_chunk = std::max<int64_t>(1, chunk_ / K);
     const bool sampling = sample_events_ > 0;
     int64_t block_no = 0;
@@ -293,7 +310,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         nonbasic.clear();
         for (int j = 0; j < ncols; j++) if (!inb[j]) nonbasic.push_back(j);
     };
-    tcur_ = 0; rcur_ = 0;
+    tcur_ = 0; rcur_ = 0; t_tiled_ = false;
     if (!binv_host) HIP_TRY(hipMemcpyAsync(w.rho, rho.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipMemsetAsync(w.xb, 0, (size_t)P.ld * sizeof(double), stream_));
     HIP_TRY(hipMemcpyAsync(w.xb, xb.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, stream_));
@@ -371,6 +388,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
                 for (int jp = 0; jp < nn; jp++) srcpos[jp] = pos_of[asc[jp]];
                 HIP_TRY(hipMemcpyAsync(w.srcpos, srcpos.data(), (size_t)nn * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
                 HIP_TRY(hipStreamSynchronize(stream_));
+                bt_layout(P, false);
                 launch_tab_permute_cols(w.T[tcur_], ldt_, w.T[tcur_ ^ 1], ldt_, m, nn, w.srcpos, stream_);
                 launches_++;
                 tcur_ ^= 1;
@@ -378,6 +396,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
             }
         }
         if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return rc;
+        bt_layout(P, false);
         launch_tab_r(w.T[tcur_], ldt_, m, nn, P.dc1, w.basic, w.nonbasic, w.tscratch, w.R[rcur_], stream_);
         launches_ += 2;
         HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
@@ -408,6 +427,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
             bool exchanged = false;
             for (auto &cv : cand) {
                 const int jp = cv.second;
+                bt_layout(P, false);
                 launch_tab_column(w.T[tcur_], ldt_, m, jp, w.xb, w.dvec, w.move, stream_);
                 launches_++;
                 HIP_TRY(hipMemcpyAsync(w.h_vec, w.dvec, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
@@ -446,6 +466,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         HIP_TRY(hipMemcpyAsync(w.srcpos, srcpos.data(), (size_t)nn2 * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
         const int ldt2 = tab_ld(nn2);
+        bt_layout(P, false);
         launch_tab_permute_cols(w.T[tcur_], ldt_, w.T[tcur_ ^ 1], ldt2, m, nn2, w.srcpos, stream_);
         launches_++;
         tcur_ ^= 1;
@@ -459,6 +480,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         if ((rc = set_up_T(nn)) != GOMILP_OK) return rc;
     }
     // ---- Phase II ----
+    bt_layout(P, false);
     launch_tab_r(w.T[tcur_], ldt_, m, nn, P.dc, w.basic, w.nonbasic, w.tscratch, w.R[rcur_], stream_);
     launches_ += 2;
     *loop_rc = use_bt_ ? run_loop_bt(P, 2, tol, nn, st) : run_loop_tab(P, 2, tol, nn, st);
