@@ -403,6 +403,10 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
     if (tid < KR + 1) payA[0][tid] = 0;   // a host-chosen first pivot reads v'_k[q] = 0 from here
     __syncthreads();
     int kd = 0, status = ST_RUNNING, blands = 0;
+    // thread 0 keeps the pivot / trace counters in registers: a global read-modify-write per pivot would stall its wave
+    // (and, at the next barrier, everybody) for a memory round trip
+    long long trace_len = 0, npiv = 0;
+    if (tid == 0) { trace_len = st->trace_len; npiv = st->pivots; }
 
     // ---- floats.MinIdx over N slots per thread (slot s of thread t is index t + s*NT)
     auto wave_first_min = [&](auto &val, auto nslots) -> BtWin {
@@ -615,12 +619,12 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
         if (tid == 0 && !(forced && a.forced_nocommit)) {  // simplex.go:280
             const int ent = nonbasic_s[q], lea = basic_s[p];
             basic_s[p] = ent; nonbasic_s[q] = lea;
-            if (a.trace && st->trace_len < a.trace_cap) {
-                DevPivot &tr = a.trace[st->trace_len];
+            if (a.trace && trace_len < a.trace_cap) {
+                DevPivot &tr = a.trace[trace_len];
                 tr.phase = a.phase; tr.bland = bland ? 1 : 0; tr.min_idx = q; tr.replace = p; tr.entering = ent; tr.leaving = lea;
             }
-            st->trace_len += 1;
-            st->pivots += 1;
+            trace_len += 1;
+            npiv += 1;
         }
         kd = k + 1;
         if (a.pad) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(5); if (tid == 0) g_bt_prof[15] += 1; }
@@ -639,6 +643,8 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
     for (int i = tid; i < a.m; i += NT) a.basic[i] = basic_s[i];
     for (int j = tid; j < a.nn; j += NT) a.nonbasic[j] = nonbasic_s[j];
     if (tid == 0) {
+        st->trace_len = trace_len;
+        st->pivots = npiv;
         st->kdone = kd;
         st->bland_steps += blands;
         if (status != ST_RUNNING) { st->done = 1; st->status = status; }
@@ -670,7 +676,28 @@ __global__ __launch_bounds__(kBlock) void k_bt_update(BTArgs a, int rows_per_wg)
     }
     __syncthreads();
     if (c2 >= ld2) return;
-    for (int rr = 0; rr < nrows; rr++) {
+    // UNR rows per trip: independent 16-byte loads in flight per lane before the first use (bytes in flight per CU set
+    // the speed of this kernel, see k_bt_update_tiled)
+    constexpr int UNR = KMAX <= 8 ? 8 : 4;
+    int rr = 0;
+    for (; rr + UNR <= nrows; rr += UNR) {
+        double2 *cell = reinterpret_cast<double2 *>(a.T + (size_t)(i0 + rr) * a.ldt) + c2;
+        double2 t[UNR];
+#pragma unroll
+        for (int x = 0; x < UNR; x++) t[x] = cell[(size_t)x * ld2];
+#pragma unroll
+        for (int x = 0; x < UNR; x++) {
+#pragma unroll
+            for (int k = 0; k < KMAX; k++) {
+                const double u = us[k][rr + x];
+                t[x].x += u * vv[k].x;
+                t[x].y += u * vv[k].y;
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < UNR; x++) cell[(size_t)x * ld2] = t[x];
+    }
+    for (; rr < nrows; rr++) {
         double2 *cell = reinterpret_cast<double2 *>(a.T + (size_t)(i0 + rr) * a.ldt) + c2;
         double2 t = *cell;
 #pragma unroll
@@ -745,7 +772,27 @@ __global__ __launch_bounds__(kBlock) void k_bt_update_tiled(BTArgs a, int tilero
     if (!inb) return;
     double2 *cell = reinterpret_cast<double2 *>(a.T) + (size_t)I0 * (unsigned int)a.ldt * 2u + cx;
     const size_t step = (size_t)a.ldt * 2u;   // double2 per tile row
-    for (int ii = 0; ii < nI; ii++, cell += step) {
+    // UNR tile rows per trip: UNR independent 16-byte loads in flight per lane before the first use (the kernel runs out
+    // of the Infinity Cache at m = 2048: bytes in flight per CU, not issue rate, set its speed)
+    constexpr int UNR = 8;
+    int ii = 0;
+    for (; ii + UNR <= nI; ii += UNR, cell += UNR * step) {
+        double2 t[UNR];
+#pragma unroll
+        for (int x = 0; x < UNR; x++) t[x] = cell[x * step];
+#pragma unroll
+        for (int x = 0; x < UNR; x++) {
+#pragma unroll
+            for (int k = 0; k < KMAX; k++) {
+                const double u = us[k][(ii + x) * 4 + r];
+                t[x].x += u * vv[k].x;
+                t[x].y += u * vv[k].y;
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < UNR; x++) cell[x * step] = t[x];
+    }
+    for (; ii < nI; ii++, cell += step) {
         double2 t = *cell;
 #pragma unroll
         for (int k = 0; k < KMAX; k++) {
@@ -837,7 +884,8 @@ void launch_bt_update(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t 
         const int gx = (2 * a.ldt + kBlock - 1) / kBlock;
         const int ntr = (a.m + 3) / 4;
         int tr = 16;   // tile rows per workgroup (64 rows); aim for >= 512 workgroups
-        while (tr > 2 && gx * ((ntr + tr - 1) / tr) < 512) tr >>= 1;
+        if (const char *e = getenv("GOMILP_BT_TR")) tr = atoi(e);
+        while (tr > 4 && gx * ((ntr + tr - 1) / tr) < 512) tr >>= 1;
         dim3 grid(gx, (ntr + tr - 1) / tr);
         if (a.kmax <= 8) hipExtLaunchKernelGGL((k_bt_update_tiled<8>), grid, dim3(kBlock), 0, s, e0, e1, 0, a, tr);
         else hipExtLaunchKernelGGL((k_bt_update_tiled<16>), grid, dim3(kBlock), 0, s, e0, e1, 0, a, tr);
