@@ -152,6 +152,7 @@ struct LUArgs {
     const int32_t *unit_row;    // per column: row of the 1 when the column of ab is a unit vector, else -1 (nullable)
     int32_t *dense_flag;        // per step: 1 when the step did arithmetic (0 = unit-column fast path); nullable
     LUCtl *ctl;                 // compressed schedule only
+    double *Lp, *Up;            // compressed schedule only: compact panels of the running round (32 x ldw each)
 };
 
 }  // namespace gomilp

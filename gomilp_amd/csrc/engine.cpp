@@ -79,6 +79,7 @@ int Engine::ensure_work(int m, int ncols) {
     HIP_TRY(dmalloc(&w.lpos, (size_t)nm)); HIP_TRY(dmalloc(&w.rowstep, (size_t)nm)); HIP_TRY(dmalloc(&w.rho, (size_t)nm));
     HIP_TRY(dmalloc(&w.unitrow, (size_t)nm)); HIP_TRY(dmalloc(&w.denseflag, (size_t)nm)); HIP_TRY(dmalloc(&w.dlist, (size_t)nm));
     HIP_TRY(dmalloc(&w.ludiag, (size_t)nm)); HIP_TRY(dmalloc(&w.Wd, (size_t)nm * nld));
+    HIP_TRY(dmalloc(&w.luLp, (size_t)32 * nld)); HIP_TRY(dmalloc(&w.luUp, (size_t)32 * nld));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_W), (size_t)nm * nld * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_vec), (size_t)std::max(nld, nc) * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_idx), (size_t)std::max(nm, nc) * sizeof(int32_t), hipHostMallocDefault));
@@ -552,7 +553,10 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     const double tf0 = now_s();
     const int m = P.m, ldw = P.ld;
     int nonunit = 0;
-    launch_gather_w(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
+    const bool compressed = lu_blocked_ >= 2 && lu_compressed_supported(m);
+    // the compressed schedule keeps L/U column-major (lu_compressed.hip), the other two row-major
+    if (compressed) launch_luc_gather(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
+    else launch_gather_w(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
     // unit columns of ab (from the column statistics of the upload): the blocked LU skips their elimination steps
     HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -571,10 +575,9 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     for (int t = 0; t < 2; t++) { a.pk[t] = w.lpk[t]; a.pl[t] = w.lpl[t]; a.pr[t] = w.lpr[t]; }
     a.st = w.st;
     a.unit_row = w.unitrow;
-    const bool compressed = lu_blocked_ >= 2 && lu_compressed_supported(m);
     const bool blocked = compressed || (lu_blocked_ && lu_blocked_supported(m));
     a.dense_flag = blocked ? w.denseflag : nullptr;
-    a.ctl = w.luctl;
+    a.ctl = w.luctl; a.Lp = w.luLp; a.Up = w.luUp;
     w.st_host->lu_singular = 0;
     sync_state_to_device();
     lu_rounds_ = 0;
@@ -620,7 +623,8 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     if (nd) HIP_TRY(hipMemcpyAsync(w.dlist, dl.data(), (size_t)nd * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     double *Wd = w.Wd;
-    launch_lu_pack(a, w.dlist, nd, Wd, w.ludiag, stream_);
+    if (compressed) launch_luc_pack(a, w.dlist, nd, Wd, w.ludiag, stream_);
+    else launch_lu_pack(a, w.dlist, nd, Wd, w.ludiag, stream_);
     launches_++;
     if (nd) HIP_TRY(hipMemcpyAsync(w.h_W, Wd, (size_t)m * nd * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(w.h_vec, w.ludiag, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));

@@ -157,6 +157,8 @@ bool lu_compressed_supported(int m);
 int lu_compressed_nb(int m);
 void launch_luc_init(const LUArgs &a, hipStream_t s);
 int launch_luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t s);
+void launch_luc_gather(const double *At, int ld, int m, const int32_t *basic, double *W, int ldw, hipStream_t s);
+void launch_luc_pack(const LUArgs &a, const int32_t *dlist, int nd, double *Wd, double *diag, hipStream_t s);
 void launch_lu_pack(const LUArgs &a, const int32_t *dlist, int nd, double *Wd, double *diag, hipStream_t s);
 
 }  // namespace gomilp

@@ -74,6 +74,7 @@ struct Engine::Work {
     int32_t *unitrow = nullptr;  // final solve: unit-column rows per basis position
     int32_t *denseflag = nullptr, *dlist = nullptr;  // final solve: steps that did arithmetic / their compact list
     double *ludiag = nullptr;   // diagonal of U by physical row
+    double *luLp = nullptr, *luUp = nullptr;  // compressed LU: compact multiplier / U-row panels of the running round
     double *Wd = nullptr;       // packed dense columns of L\\U for the host solves (m x nd)
     size_t cap_T = 0;  // doubles per T buffer
     int cap_ldt = 0;
@@ -92,7 +93,7 @@ struct Engine::Work {
 
     void release() {
         for (auto &p : binv) { if (p) hipFree(p); p = nullptr; }
-        for (double **p : {&xb, &yb[0], &yb[1], &dvec, &move, &rvec, &yscratch, &W, &ludiag, &Wd}) { if (*p) hipFree(*p); *p = nullptr; }
+        for (double **p : {&xb, &yb[0], &yb[1], &dvec, &move, &rvec, &yscratch, &W, &ludiag, &Wd, &luLp, &luUp}) { if (*p) hipFree(*p); *p = nullptr; }
         for (int32_t **p : {&basic, &nonbasic, &lpos, &rowstep, &rho, &unitrow, &denseflag, &dlist}) { if (*p) hipFree(*p); *p = nullptr; }
         if (h_W) hipHostFree(h_W); h_W = nullptr;
         if (h_vec) hipHostFree(h_vec); h_vec = nullptr;

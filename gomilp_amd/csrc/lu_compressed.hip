@@ -36,6 +36,10 @@ struct CPanelRow {
     bool act;
 };
 
+// Storage of this schedule: W is COLUMN-major (Wc[k*ldw + R] = element (R, k)): the panel's column loads and its
+// per-step multiplier stores are contiguous over the threads' rows (row-major W made both m-line scatters through
+// one CU), and the basis gather is a plain copy of rows of At.  The round's multipliers and finished U rows also
+// go to two compact panels, Lp[s][R] = -l and Up[s][j] = u, which is all the trailing update reads.
 template <int T, int RPT, int NB>
 __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__ pivrow) {
     constexpr int NW = T / 64;
@@ -51,6 +55,7 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
     LUCtl *ctl = a.ctl;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m = a.m;
+    const size_t ldw = (size_t)a.ldw;
     const int k0 = ctl->k_next;
     if (k0 >= m) {
         if (tid == 0) ctl->nsteps = 0;
@@ -92,9 +97,9 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
         row.R = tid + r * T;
         row.act = (row.R < m) && s_active[row.R < m ? row.R : 0];
         row.lp = 0;
-        const double *src = a.W + (size_t)(row.act ? row.R : 0) * a.ldw;
+        const double *src = a.W + (row.act ? row.R : 0);
 #pragma unroll
-        for (int c = 0; c < NB; c++) row.v[c] = (row.act && c < ncols) ? src[s_cols[c]] : 0.0;
+        for (int c = 0; c < NB; c++) row.v[c] = (row.act && c < ncols) ? src[(size_t)s_cols[c < ncols ? c : 0] * ldw] : 0.0;
     };
     GOMILP_FOR_ROWS(load_row);
     if (tid < NB) ctl->cols[tid] = tid < ncols ? s_cols[tid] : -1;
@@ -125,10 +130,10 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
             if (!row.act || s_active[row.R]) return;
             const int kt = s_lpos[row.R];
             a.rowstep[row.R] = kt; pivrow[kt] = row.R;
-            double *dst = a.W + (size_t)row.R * a.ldw;
+            double *dst = a.W + row.R;
 #pragma unroll
             for (int c = 0; c < NB; c++)
-                if (s + c < ncols) dst[s_cols[s + c]] = row.v[c];
+                if (s + c < ncols) dst[(size_t)s_cols[s + c] * ldw] = row.v[c];
             row.act = false;
         };
         GOMILP_FOR_ROWS(retire);
@@ -151,11 +156,11 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
         auto publish = [&](CPanelRow<NB> &row, int) {
             if (!row.act || row.lp != jp) return;
             const int P = row.R;
-            double *dst = a.W + (size_t)P * a.ldw;
+            double *dst = a.W + P;
 #pragma unroll
             for (int cc = 0; cc < NB; cc++) {
                 pr[cc] = row.v[cc];
-                if (s + cc < ncols) dst[s_cols[s + cc]] = row.v[cc];
+                if (s + cc < ncols) dst[(size_t)s_cols[s + cc] * ldw] = row.v[cc];
             }
             row.act = false;
             s_active[P] = 0;
@@ -172,11 +177,17 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
         const bool singular = (piv == 0);  // dgetf2.go:48-49: no scaling, the rank-1 update is a no-op
         if (singular && tid == 0) a.st->lu_singular = 1;
         const double rinv = 1.0 / piv;
+        double *wcol = a.W + (size_t)k * ldw;      // column k of L\U
+        double *lcol = a.Lp + (size_t)s * ldw;     // compact panel: -l (0 for rows that are not active)
         auto elim = [&](CPanelRow<NB> &row, int) {
-            if (!row.act) return;
+            if (!row.act) {
+                if (row.R < a.ldw) lcol[row.R] = 0.0;
+                return;
+            }
             const double l = singular ? row.v[0] : __dmul_rn(row.v[0], rinv);
-            a.W[(size_t)row.R * a.ldw + k] = l;
+            wcol[row.R] = l;
             const double nl = -l;
+            lcol[row.R] = singular ? 0.0 : nl;
             const bool skip = singular;   // Dger (dgetf2.go:60-66) does not skip zero multipliers
 #pragma unroll
             for (int cc = 1; cc < NB; cc++) row.v[cc - 1] = skip ? row.v[cc] : __dadd_rn(__dmul_rn(nl, pr[cc]), row.v[cc]);
@@ -195,115 +206,111 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
 }
 
 // dense pivot rows of the round, columns j >= k1:  u_s = a[P_s] + sum_{t<s} (-l[P_s][t]) * u_t  (ascending t, the
-// Dtrsm of dgetrf.go:57-60).  Register columns of the panel (ctl->cols) are final already: the panel wrote them.
+// Dtrsm of dgetrf.go:57-60) into the compact panel Up; the trailing kernel writes them back into W together with all
+// other rows.  Register columns of the panel (ctl->cols) are final already: the panel wrote them.
 template <int NB>
 __global__ __launch_bounds__(256) void k_luc_usolve(LUArgs a) {
     const LUCtl *ctl = a.ctl;
     const int ns = ctl->nsteps, k1 = ctl->k1;
-    if (ns == 0 || k1 + (int)blockIdx.x * 256 >= a.m) return;
+    const int j0 = k1 + (int)blockIdx.x * 64;
+    if (ns == 0 || j0 >= a.m) return;
     __shared__ double Ln[NB][NB + 1];
+    __shared__ double X[NB][64 + 1];
     __shared__ int Ps[NB], Cs[NB];
-    if (threadIdx.x < NB) {
-        Ps[threadIdx.x] = threadIdx.x < ns ? ctl->prow[threadIdx.x] : 0;
-        Cs[threadIdx.x] = threadIdx.x < ctl->ncols ? ctl->cols[threadIdx.x] : -1;
+    const int tid = threadIdx.x;
+    const size_t ldw = (size_t)a.ldw;
+    if (tid < NB) {
+        Ps[tid] = tid < ns ? ctl->prow[tid] : 0;
+        Cs[tid] = tid < ctl->ncols ? ctl->cols[tid] : -1;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
+    for (int idx = tid; idx < NB * NB; idx += 256) {
         const int s = idx / NB, t = idx % NB;
-        Ln[s][t] = (s < ns && t < s) ? -a.W[(size_t)Ps[s] * a.ldw + Cs[t]] : 0.0;
+        Ln[s][t] = (s < ns && t < s) ? a.Lp[(size_t)t * ldw + Ps[s]] : 0.0;
+    }
+    for (int idx = tid; idx < NB * 64; idx += 256) {
+        const int s = idx / 64, c = idx % 64;
+        const int j = j0 + c;
+        X[s][c] = (s < ns && j < a.m) ? a.W[(size_t)j * ldw + Ps[s]] : 0.0;
     }
     __syncthreads();
-    const int j = k1 + blockIdx.x * 256 + threadIdx.x;
-    if (j >= a.m) return;
+    const int j = j0 + tid;
+    if (tid >= 64 || j >= a.m) return;
+    bool inlist = false;
 #pragma unroll
-    for (int t = 0; t < NB; t++)
-        if (Cs[t] == j) return;
+    for (int t = 0; t < NB; t++) inlist |= (Cs[t] == j);
     double u[NB];
 #pragma unroll
     for (int s = 0; s < NB; s++) {
         if (s < ns) {
-            double *cell = a.W + (size_t)Ps[s] * a.ldw + j;
-            double x = *cell;
+            double x = X[s][tid];
+            if (!inlist) {
 #pragma unroll
-            for (int t = 0; t < s; t++) {
-                const double l = Ln[s][t];
-                x = (l != 0) ? __dadd_rn(__dmul_rn(l, u[t]), x) : x;
+                for (int t = 0; t < s; t++) {
+                    const double l = Ln[s][t];
+                    x = (l != 0) ? __dadd_rn(__dmul_rn(l, u[t]), x) : x;
+                }
             }
             u[s] = x;
-            *cell = x;
+            a.Up[(size_t)s * ldw + j] = x;
         } else {
             u[s] = 0;
         }
     }
 }
 
-// every other row, columns j >= k1: a[R][j] += sum_s (-l[R][s]) * u_s[j] over the round's dense steps in ascending s
-// (the Dgemm of dgetrf.go:62-66).  Rows still active take all steps; a row retired by a bookkeeping step of the round
-// takes the steps before its own and already holds final values in the panel's register columns.
+// every row that took part in the round, columns j >= k1: a[R][j] += sum_s Lp[s][R] * Up[s][j] in ascending s (the
+// Dgemm of dgetrf.go:62-66; zero multipliers skipped).  Lp is zero from the step at which a row left the active set,
+// so rows still active take all steps, a row retired by a bookkeeping step takes the steps before it and the pivot row
+// of dense step s takes steps < s — which IS its U-solve recurrence.  Rows that left during the round already hold
+// final values in the panel's register columns (retire / publish wrote them).
 template <int NB>
 __global__ __launch_bounds__(256) void k_luc_trail(LUArgs a) {
     const LUCtl *ctl = a.ctl;
     const int ns = ctl->nsteps, k0 = ctl->k0, k1 = ctl->k1;
     const int j0 = k1 + blockIdx.x * 64;
     if (ns == 0 || j0 >= a.m) return;
-    __shared__ double Ls[64][NB + 1];
+    __shared__ double Ls[NB][64];
     __shared__ double Us[NB][64];
-    __shared__ int pre[64];
-    __shared__ unsigned char retired[64], inlist[64];
-    __shared__ int Ss[NB], Ps[NB], Cs[NB];
+    __shared__ unsigned char rowcls[64], inlist[64];
+    __shared__ int Cs[NB];
     const int tid = threadIdx.x;
     const int R0 = blockIdx.y * 64;
-    if (tid < NB) {
-        Ss[tid] = tid < ns ? ctl->steps[tid] : 0x7fffffff;
-        Ps[tid] = tid < ns ? ctl->prow[tid] : 0;
-        Cs[tid] = tid < ctl->ncols ? ctl->cols[tid] : -1;
-    }
+    const size_t ldw = (size_t)a.ldw;
+    if (tid < NB) Cs[tid] = tid < ctl->ncols ? ctl->cols[tid] : -1;
     __syncthreads();
-    int p = 0;
+    int cls = 0;
     if (tid < 64) {
         const int R = R0 + tid;
-        bool ret = false;
         if (R < a.m) {
             const int rs = a.rowstep[R];
-            if (rs < 0) {
-                p = ns;
-            } else if (rs >= k0) {
-                int cnt = 0;
-                bool dense = false;
-                for (int s = 0; s < ns; s++) { cnt += (Ss[s] < rs) ? 1 : 0; dense |= (Ss[s] == rs); }
-                if (!dense) { p = cnt; ret = true; }
-            }
+            cls = rs < 0 ? 1 : (rs >= k0 ? 2 : 0);   // 1 active, 2 left during this round, 0 finished earlier
         }
-        pre[tid] = p;
-        retired[tid] = ret ? 1 : 0;
+        rowcls[tid] = (unsigned char)cls;
     } else if (tid < 128) {
         const int j = j0 + (tid - 64);
         bool il = false;
         for (int t = 0; t < NB; t++) il |= (Cs[t] == j);
         inlist[tid - 64] = il ? 1 : 0;
     }
-    if (!__syncthreads_or(p > 0)) return;
-    for (int idx = tid; idx < 64 * NB; idx += 256) {
-        const int r = idx / NB, s = idx % NB;
-        Ls[r][s] = (s < pre[r]) ? -a.W[(size_t)(R0 + r) * a.ldw + Ss[s]] : 0.0;
-    }
+    if (!__syncthreads_or(cls > 0)) return;
     for (int idx = tid; idx < NB * 64; idx += 256) {
         const int s = idx / 64, c = idx % 64;
-        const int j = j0 + c;
-        Us[s][c] = (s < ns && j < a.m) ? a.W[(size_t)Ps[s] * a.ldw + j] : 0.0;
+        Ls[s][c] = (s < ns && R0 + c < a.m) ? a.Lp[(size_t)s * ldw + R0 + c] : 0.0;
+        Us[s][c] = (s < ns && j0 + c < a.m) ? a.Up[(size_t)s * ldw + j0 + c] : 0.0;
     }
     __syncthreads();
-    const int ty = tid >> 4, tx = tid & 15;
-    double acc[4][4];
+    const int tx = tid & 15, ty = tid >> 4;   // rows tx*4.., columns ty*4..: consecutive lanes walk down a column
+    double acc[4][4];   // [cc][rr]
     bool live[4][4];
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-        const int r = ty * 4 + rr;
+    for (int cc = 0; cc < 4; cc++) {
+        const int c = ty * 4 + cc;
 #pragma unroll
-        for (int cc = 0; cc < 4; cc++) {
-            const int c = tx * 4 + cc;
-            live[rr][cc] = pre[r] > 0 && (j0 + c) < a.m && !(retired[r] && inlist[c]);
-            acc[rr][cc] = live[rr][cc] ? a.W[(size_t)(R0 + r) * a.ldw + j0 + c] : 0.0;
+        for (int rr = 0; rr < 4; rr++) {
+            const int r = tx * 4 + rr;
+            live[cc][rr] = rowcls[r] > 0 && (j0 + c) < a.m && !(rowcls[r] == 2 && inlist[c]);
+            acc[cc][rr] = live[cc][rr] ? a.W[(size_t)(j0 + c) * ldw + R0 + r] : 0.0;
         }
     }
 #pragma unroll
@@ -311,23 +318,23 @@ __global__ __launch_bounds__(256) void k_luc_trail(LUArgs a) {
         if (s < ns) {
             double l[4], u[4];
 #pragma unroll
-            for (int rr = 0; rr < 4; rr++) l[rr] = Ls[ty * 4 + rr][s];
+            for (int rr = 0; rr < 4; rr++) l[rr] = Ls[s][tx * 4 + rr];
 #pragma unroll
-            for (int cc = 0; cc < 4; cc++) u[cc] = Us[s][tx * 4 + cc];
+            for (int cc = 0; cc < 4; cc++) u[cc] = Us[s][ty * 4 + cc];
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
                 const bool nz = l[rr] != 0;
 #pragma unroll
-                for (int cc = 0; cc < 4; cc++) acc[rr][cc] = nz ? __dadd_rn(__dmul_rn(l[rr], u[cc]), acc[rr][cc]) : acc[rr][cc];
+                for (int cc = 0; cc < 4; cc++) acc[cc][rr] = nz ? __dadd_rn(__dmul_rn(l[rr], u[cc]), acc[cc][rr]) : acc[cc][rr];
             }
         }
     }
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-        const int r = ty * 4 + rr;
+    for (int cc = 0; cc < 4; cc++) {
+        const int c = ty * 4 + cc;
 #pragma unroll
-        for (int cc = 0; cc < 4; cc++)
-            if (live[rr][cc]) a.W[(size_t)(R0 + r) * a.ldw + j0 + tx * 4 + cc] = acc[rr][cc];
+        for (int rr = 0; rr < 4; rr++)
+            if (live[cc][rr]) a.W[(size_t)(j0 + c) * ldw + R0 + tx * 4 + rr] = acc[cc][rr];
     }
 }
 
@@ -343,12 +350,43 @@ __global__ void k_luc_init(LUArgs a) {
     }
 }
 
+// Wc[k][R] = At[basic[k]][R]: the basis, column-major (rows of At are columns of A)
+__global__ __launch_bounds__(256) void k_luc_gather(const double *__restrict__ At, int ld, int m, const int32_t *__restrict__ basic,
+                                                    double *__restrict__ W, int ldw) {
+    const int k = blockIdx.x;
+    const double *src = At + (size_t)basic[k] * ld;
+    double *dst = W + (size_t)k * ldw;
+    for (int R = threadIdx.x; R < ldw; R += 256) dst[R] = R < m ? src[R] : 0.0;
+}
+
+// Wd[R*nd + t] = W(R, dlist[t]) (32x32 tiles through LDS: both sides coalesced) and diag[R] = W(R, lpos[R])
+__global__ __launch_bounds__(256) void k_luc_pack(LUArgs a, const int32_t *__restrict__ dlist, int nd, double *__restrict__ Wd,
+                                                  double *__restrict__ diag) {
+    __shared__ double tile[32][33];
+    const int t0 = blockIdx.x * 32, R0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const size_t ldw = (size_t)a.ldw;
+    for (int tt = ty; tt < 32; tt += 8) {
+        const int t = t0 + tt, R = R0 + tx;
+        tile[tt][tx] = (t < nd && R < a.m) ? a.W[(size_t)dlist[t] * ldw + R] : 0.0;
+    }
+    __syncthreads();
+    for (int rr = ty; rr < 32; rr += 8) {
+        const int R = R0 + rr, t = t0 + tx;
+        if (R < a.m && t < nd) Wd[(size_t)R * nd + t] = tile[tx][rr];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 32) {
+        const int R = R0 + threadIdx.x;
+        if (R < a.m) diag[R] = a.W[(size_t)a.lpos[R] * ldw + R];
+    }
+}
+
 template <int T, int RPT, int NB>
 static void luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t s) {
     const int m = a.m;
     for (int r = 0; r < nrounds; r++) {
         hipLaunchKernelGGL((k_luc_panel<T, RPT, NB>), dim3(1), dim3(T), 0, s, a, pivrow);
-        hipLaunchKernelGGL((k_luc_usolve<NB>), dim3((m + 255) / 256), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_luc_usolve<NB>), dim3((m + 63) / 64), dim3(256), 0, s, a);
         hipLaunchKernelGGL((k_luc_trail<NB>), dim3((m + 63) / 64, (m + 63) / 64), dim3(256), 0, s, a);
     }
 }
@@ -362,6 +400,13 @@ int lu_compressed_nb(int m) { const int c = luc_cfg(m); return c <= 1 ? 32 : (c 
 
 void launch_luc_init(const LUArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(k_luc_init, dim3((a.m + 255) / 256), dim3(256), 0, s, a);
+}
+void launch_luc_gather(const double *At, int ld, int m, const int32_t *basic, double *W, int ldw, hipStream_t s) {
+    hipLaunchKernelGGL(k_luc_gather, dim3(m), dim3(256), 0, s, At, ld, m, basic, W, ldw);
+}
+void launch_luc_pack(const LUArgs &a, const int32_t *dlist, int nd, double *Wd, double *diag, hipStream_t s) {
+    dim3 grid((nd + 31) / 32 > 0 ? (nd + 31) / 32 : 1, (a.m + 31) / 32);
+    hipLaunchKernelGGL(k_luc_pack, grid, dim3(256), 0, s, a, dlist, nd, Wd, diag);
 }
 
 // enqueue `nrounds` rounds; returns the number of kernel launches
