@@ -320,45 +320,6 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
 //  * one division per pivot for the rank-1 term (u_i = d_i * (-1/d_p)) and fused multiply-adds for the block
 //    corrections: these are the engine's own running quantities, not values the reference defines bit by bit
 //    (the returned x comes from the gonum-order solve of the final basis).
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const unsigned int lo = dpp_u32<CTRL>((unsigned int)b), hi = dpp_u32<CTRL>((unsigned int)(b >> 32));
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)b, lane);
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(b >> 32), lane);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-// v_min_f64 directly: minnum semantics in hardware (a NaN operand loses); __builtin_fmin would add a v_max_f64 x,x
-// canonicalisation per operand, doubling the instruction count of the reductions
-__device__ __forceinline__ double vmin_f64(double a, double b) {
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// min over each 16-lane row, result in lane 15 of the row (NaN operands lose: minnum)
-__device__ __forceinline__ double row_min_f64(double x) {
-    x = vmin_f64(x, dpp_f64<0x111>(x));
-    x = vmin_f64(x, dpp_f64<0x112>(x));
-    x = vmin_f64(x, dpp_f64<0x114>(x));
-    x = vmin_f64(x, dpp_f64<0x118>(x));
-    return x;
-}
-__device__ __forceinline__ double wave_min_f64(double x) {
-    x = row_min_f64(x);
-    return vmin_f64(vmin_f64(readlane_f64(x, 15), readlane_f64(x, 31)), vmin_f64(readlane_f64(x, 47), readlane_f64(x, 63)));
-}
-__device__ __forceinline__ unsigned int row_min_u32(unsigned int x) {
-    x = min(x, dpp_u32<0x111>(x));
-    x = min(x, dpp_u32<0x112>(x));
-    x = min(x, dpp_u32<0x114>(x));
-    x = min(x, dpp_u32<0x118>(x));
-    return x;
-}
-
 __device__ __forceinline__ unsigned int tile_off(unsigned int i, unsigned int j, unsigned int ldt);
 struct BtWin { double m; unsigned int i; };   // minimum and the first index that attains it (0xFFFFFFFF: none, all NaN)
 

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
     __shared__ int s_unit[MAXM];    // unit_row per column
     __shared__ unsigned char s_active[MAXM];
     __shared__ double prow[2][NB];
-    __shared__ BtCand sm2[2 * 16];
+    __shared__ double redM[2][16];
+    __shared__ unsigned int redL[2][16];
     __shared__ int s_cols[NB];
     __shared__ int s_ncols, s_stop;
     LUCtl *ctl = a.ctl;
@@ -140,18 +141,32 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
         if (kstop < limit || s >= ncols) { k1 = kstop; break; }
         const int k = limit;
         // ---- dense step k: pivot = first max |a_ik| in logical row order (idamax over the permuted column)
-        BtCand c;
-        c.k = ~0ull; c.i = 0xFFFFFFFFu;
+        // idamax without (key, index) candidates: the minimum of -|a_ik| by v_min_f64 over DPP row shifts, then the
+        // smallest logical position among the rows that attain it (u32 min) — first maximum in LAPACK row order
+        double xm = __builtin_inf();
         auto cand = [&](CPanelRow<NB> &row, int) {
             if (!row.act) return;
             row.lp = s_lpos[row.R];
-            BtCand b;
-            b.k = ordkey(-fabs(row.v[0])); b.i = (unsigned int)row.lp;
-            bt_take(c, b);
+            xm = vmin_f64(xm, -fabs(row.v[0]));
         };
         GOMILP_FOR_ROWS(cand);
-        bt_block_argmin<NW>(c, sm2 + 16 * (s & 1));
-        const int jp = (int)c.i;
+        const double wm = wave_min_f64(xm);
+        unsigned int lk = 0xFFFFFFFFu;
+        auto cand2 = [&](CPanelRow<NB> &row, int) {
+            if (row.act && -fabs(row.v[0]) == wm) lk = min(lk, (unsigned int)row.lp);
+        };
+        GOMILP_FOR_ROWS(cand2);
+        lk = row_min_u32(lk);
+        lk = min(min((unsigned int)__builtin_amdgcn_readlane((int)lk, 15), (unsigned int)__builtin_amdgcn_readlane((int)lk, 31)),
+                 min((unsigned int)__builtin_amdgcn_readlane((int)lk, 47), (unsigned int)__builtin_amdgcn_readlane((int)lk, 63)));
+        double *rm = redM[s & 1];
+        unsigned int *rl = redL[s & 1];
+        if (lane == 0) { rm[w] = wm; rl[w] = lk; }
+        __syncthreads();
+        const double bx = lane < NW ? rm[lane] : __builtin_inf();
+        const double bm = readlane_f64(row_min_f64(bx), 15);
+        const unsigned int bk = (lane < NW && bx == bm) ? rl[lane] : 0xFFFFFFFFu;
+        const int jp = (int)(unsigned int)__builtin_amdgcn_readlane((int)row_min_u32(bk), 15);
         double *pr = prow[s & 1];
         auto publish = [&](CPanelRow<NB> &row, int) {
             if (!row.act || row.lp != jp) return;
@@ -277,7 +292,25 @@ __global__ __launch_bounds__(256) void k_luc_trail(LUArgs a) {
     const int tid = threadIdx.x;
     const int R0 = blockIdx.y * 64;
     const size_t ldw = (size_t)a.ldw;
+    // the tile's cells first: their loads overlap the staging of the panels (this kernel is a chain of dependent
+    // memory round trips, not bandwidth)
+    const int tx = tid & 15, ty = tid >> 4;   // rows tx*4.., columns ty*4..: consecutive lanes walk down a column
+    double acc[4][4];   // [cc][rr]
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) {
+        const int c = ty * 4 + cc;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int r = tx * 4 + rr;
+            acc[cc][rr] = ((j0 + c) < a.m && (R0 + r) < a.m) ? a.W[(size_t)(j0 + c) * ldw + R0 + r] : 0.0;
+        }
+    }
     if (tid < NB) Cs[tid] = tid < ctl->ncols ? ctl->cols[tid] : -1;
+    for (int idx = tid; idx < NB * 64; idx += 256) {
+        const int s = idx / 64, c = idx % 64;
+        Ls[s][c] = (s < ns && R0 + c < a.m) ? a.Lp[(size_t)s * ldw + R0 + c] : 0.0;
+        Us[s][c] = (s < ns && j0 + c < a.m) ? a.Up[(size_t)s * ldw + j0 + c] : 0.0;
+    }
     __syncthreads();
     int cls = 0;
     if (tid < 64) {
@@ -294,14 +327,6 @@ __global__ __launch_bounds__(256) void k_luc_trail(LUArgs a) {
         inlist[tid - 64] = il ? 1 : 0;
     }
     if (!__syncthreads_or(cls > 0)) return;
-    for (int idx = tid; idx < NB * 64; idx += 256) {
-        const int s = idx / 64, c = idx % 64;
-        Ls[s][c] = (s < ns && R0 + c < a.m) ? a.Lp[(size_t)s * ldw + R0 + c] : 0.0;
-        Us[s][c] = (s < ns && j0 + c < a.m) ? a.Up[(size_t)s * ldw + j0 + c] : 0.0;
-    }
-    __syncthreads();
-    const int tx = tid & 15, ty = tid >> 4;   // rows tx*4.., columns ty*4..: consecutive lanes walk down a column
-    double acc[4][4];   // [cc][rr]
     bool live[4][4];
 #pragma unroll
     for (int cc = 0; cc < 4; cc++) {
@@ -310,7 +335,6 @@ __global__ __launch_bounds__(256) void k_luc_trail(LUArgs a) {
         for (int rr = 0; rr < 4; rr++) {
             const int r = tx * 4 + rr;
             live[cc][rr] = rowcls[r] > 0 && (j0 + c) < a.m && !(rowcls[r] == 2 && inlist[c]);
-            acc[cc][rr] = live[cc][rr] ? a.W[(size_t)(j0 + c) * ldw + R0 + r] : 0.0;
         }
     }
 #pragma unroll
