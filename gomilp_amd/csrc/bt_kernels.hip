@@ -327,10 +327,11 @@ template <int NT, int RI, int CJ, int KR>
 __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double sh2[];
-    double *xb_s = sh2;              // ldu    x_B and r: every thread touches only its own rows / columns (no barrier
-    double *r_s = sh2 + a.ldu;       // CJ*NT  needed); kept out of the register file, which the block terms fill
-    int *basic_s = reinterpret_cast<int *>(sh2 + a.ldu + CJ * NT);  // m   only thread 0 touches the lists inside the loop
-    int *nonbasic_s = basic_s + a.ldu;                    // nn
+    // fixed offsets (not a.ldu / a.ldt): every slot address is 8*tid + a compile-time constant, one VGPR for all of them
+    double *xb_s = sh2;              // RI*NT  x_B and r: every thread touches only its own rows / columns (no barrier
+    double *r_s = sh2 + RI * NT;     // CJ*NT  needed); kept out of the register file, which the block terms fill
+    int *basic_s = reinterpret_cast<int *>(sh2 + RI * NT + CJ * NT);  // RI*NT  only thread 0 touches the lists in the loop
+    int *nonbasic_s = basic_s + RI * NT;                              // CJ*NT
     __shared__ double redMA[16], redMB[16];
     __shared__ unsigned int redIA[16], redIB[16];
     __shared__ double payA[16][KR + 1];  // per wave: r_q, v'_k[q]
@@ -344,11 +345,13 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
     }
     const double inf = __builtin_inf();
     const unsigned int ldt = (unsigned int)a.ldt;
+    const char *Tb = reinterpret_cast<const char *>(a.T);   // byte offsets in 32 bits: saddr + voffset addressing
+    auto ldT = [&](unsigned int elem) -> double { return *reinterpret_cast<const double *>(Tb + (elem << 3)); };
     double ureg[RI][KR], vreg[CJ][KR];
 #pragma unroll
     for (int s = 0; s < RI; s++) {
         const int i = tid + s * NT;
-        if (i < a.ldu) xb_s[i] = i < a.m ? a.xb[i] : 0.0;
+        xb_s[i] = i < a.m ? a.xb[i] : 0.0;
 #pragma unroll
         for (int j = 0; j < KR; j++) ureg[s][j] = 0;
     }
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
         for (int s = 0; s < RI; s++) {
             const int i = tid + s * NT;
             const unsigned int ic = (unsigned int)(i < a.m ? i : a.m - 1);
-            double d = a.T[tile_off(ic, (unsigned int)q, ldt)];   // T in 4x4 tiles (k_bt_tile)
+            double d = ldT(tile_off(ic, (unsigned int)q, ldt));   // T in 4x4 tiles (k_bt_tile)
 #pragma unroll
             for (int j = 0; j < KR; j++) d = __builtin_fma(ureg[s][j], vq[j], d);
             dcol[s] = i < a.m ? d : 0.0;
@@ -451,15 +454,12 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
             const int i = tid + s * NT;
             double d = -dcol[s];
             if (fabs(d) < 1e-13) d = 0;
-            mvv[s] = (d >= 0 || i >= a.m) ? inf : xb_s[i < a.ldu ? i : 0] / fabs(d);
+            mvv[s] = (d >= 0 || i >= a.m) ? inf : xb_s[i] / fabs(d);
         }
     };
 
-    long long tstamp = clock64();
-    auto stamp = [&](int slot) { if (a.pad && tid == 0) { long long now = clock64(); g_bt_prof[slot] += now - tstamp; tstamp = now; } };
     for (int k = 0; k < a.kmax; k++) {
         const bool forced = (k == 0 && a.forced_q >= 0);
-        stamp(0);
         int q, p;
         double rq = 0, dpv = 1.0, xbp = 0;
         const double *vq = &payA[0][1], *up = &payB[0][2];
@@ -476,10 +476,8 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
             }
             q = (int)fq.i;
             if (fq.i >= (unsigned int)a.nn) { q = 0; rq = __builtin_nan(""); }  // every r_j is NaN: MinIdx returns 0
-            stamp(1);
             if (rq >= -a.tol) { status = ST_OPTIMAL; break; }  // simplex.go:248
             column(q, vq, dcol);
-            if (a.pad) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(2); }
             BtWin w;
             {
                 double mvv[RI];
@@ -487,7 +485,6 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
                 w = reduce_rows(mvv, dcol, dpv, xbp, up);
             }
             p = (int)w.i;
-            stamp(3);
             const double mv = w.m;
             if (mv == inf || w.i >= (unsigned int)a.m) { status = ST_UNBOUNDED; break; }  // simplex.go:328-330
             if (mv <= 0) {
@@ -547,19 +544,19 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
         const double mult = rq / dpv;
         const double theta = xbp / dpv;
         const double rinv = 1.0 / dpv, nrinv = -rinv;
-        double *Vk = a.V + (size_t)k * a.ldt;
-        double *Uk = a.U + (size_t)k * a.ldu;
+        char *Vk = reinterpret_cast<char *>(a.V + (size_t)k * a.ldt);
+        char *Uk = reinterpret_cast<char *>(a.U + (size_t)k * a.ldu);
 #pragma unroll
         for (int s = 0; s < CJ; s++) {
             const int j = tid + s * NT;
             if (j < a.ldt) {
-                double v = a.T[tile_off((unsigned int)p, (unsigned int)j, ldt)];   // columns nn..ldt of T are zero
+                double v = ldT(tile_off((unsigned int)p, (unsigned int)j, ldt));   // columns nn..ldt of T are zero
 #pragma unroll
                 for (int jj = 0; jj < KR; jj++) v = __builtin_fma(up[jj], vreg[s][jj], v);
                 // reduced costs (positional): r_j - (r_q/d_p) v_j ; the leaving variable takes slot q
                 r_s[j] = (j == q) ? -mult : __builtin_fma(-mult, v, r_s[j]);
                 const double vprime = (j == q) ? dpv + 1.0 : v;
-                Vk[j] = vprime;
+                *reinterpret_cast<double *>(Vk + ((unsigned int)j << 3)) = vprime;
 #pragma unroll
                 for (int jj = KR - 1; jj > 0; jj--) vreg[s][jj] = vreg[s][jj - 1];
                 vreg[s][0] = vprime;
@@ -571,7 +568,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
             if (i < a.ldu) {
                 const double u = (i == p) ? rinv - 1.0 : dcol[s] * nrinv;   // rows >= m: dcol = 0
                 if (i < a.m) xb_s[i] = (i == p) ? theta : __builtin_fma(-theta, dcol[s], xb_s[i]);
-                Uk[i] = u;
+                *reinterpret_cast<double *>(Uk + ((unsigned int)i << 3)) = u;
 #pragma unroll
                 for (int jj = KR - 1; jj > 0; jj--) ureg[s][jj] = ureg[s][jj - 1];
                 ureg[s][0] = u;
@@ -588,7 +585,6 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
             npiv += 1;
         }
         kd = k + 1;
-        if (a.pad) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(5); if (tid == 0) g_bt_prof[15] += 1; }
     }
 #pragma unroll
     for (int s = 0; s < CJ; s++) {
@@ -804,7 +800,7 @@ template <int NT>
 static void bt_launch_nt(const BTArgs &a, const BtCfg &c, bool reg, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
 #define GOMILP_BT_LAUNCH(RI, CJ, KR) hipExtLaunchKernelGGL((k_bt_inner<NT, RI, CJ, KR>), dim3(1), dim3(NT), lds, s, e0, e1, 0, a)
     if (a.tiled) {   // register-resident kernel on the tiled layout (the engine converted T: bt_tiled())
-        const size_t lds2 = (size_t)(a.ldu + c.cj * NT) * sizeof(double) + (size_t)(a.ldu + a.ldt) * sizeof(int);
+        const size_t lds2 = (size_t)(c.ri + c.cj) * NT * (sizeof(double) + sizeof(int));
         if (c.ri == 2) { hipExtLaunchKernelGGL((k_bt_inner2<NT, 2, 2, 8>), dim3(1), dim3(NT), lds2, s, e0, e1, 0, a); return; }
         if constexpr (NT <= 512) {
             if (c.ri == 4) { hipExtLaunchKernelGGL((k_bt_inner2<NT, 4, 4, 8>), dim3(1), dim3(NT), lds2, s, e0, e1, 0, a); return; }
