@@ -9,9 +9,10 @@ value = simplex pivots per second, whole job (all ranks' pivots / max-over-ranks
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload M|C2|C4|C3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_update: rank-1 update of B^-1) against
-the HBM roof with HIP-event timings sampled inside the timed region; `cpu_baseline` times the CPU oracle
-(the reference algorithm: 3 fresh LU per pivot) on a bounded sample of the same workload on the host cores.
+Rank 0 prints ONE JSON line.  `roofline` prices the HBM-streaming kernel of the pipeline that ran (default: the rank-8
+update of the tableau, k_bt_update_tiled) against the HBM roof with HIP-event timings of sampled launches inside the
+timed region; `roofline.detail` gives the latency-bound single-workgroup kernel beside it; `cpu_baseline` times the
+CPU oracle (the reference algorithm: 3 fresh LU per pivot) on a bounded sample of the same workload on the host cores.
 """
 from __future__ import annotations
 
@@ -249,12 +250,15 @@ def main() -> int:
         # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), collected
         # with rocprofv3 --pmc in separate passes on the same command and committed under profiles/
         traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            if pmc.get("kernel") == kernel_name and args.workload == "M":
-                traffic = pmc["traffic_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        if args.workload == "M":
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):   # newest tag last
+                try:
+                    pmc = json.load(open(path))
+                except Exception:
+                    continue
+                if pmc.get("kernel") == kernel_name:
+                    traffic = pmc["traffic_bytes_per_launch"]
         out = {
             "metric": "simplex pivots/sec on %dx%d fp64 dense LP" % (m, n),
             "value": value,
