@@ -339,31 +339,48 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
     DevState *st = a.st;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
-    if (st->done) {
-        if (tid == 0) st->kdone = 0;
-        return;
-    }
+    // prologue: every load is issued before the first one is waited for (the `done` test used to add a full memory
+    // round trip in front of the state loads of every launch)
+    const int done = __hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double inf = __builtin_inf();
     const unsigned int ldt = (unsigned int)a.ldt;
     const char *Tb = reinterpret_cast<const char *>(a.T);   // byte offsets in 32 bits: saddr + voffset addressing
     auto ldT = [&](unsigned int elem) -> double { return *reinterpret_cast<const double *>(Tb + (elem << 3)); };
+    double x0[RI], r0[CJ];
+    int b0[RI], n0[CJ];
+#pragma unroll
+    for (int s = 0; s < RI; s++) {
+        const int i = tid + s * NT;
+        x0[s] = i < a.m ? a.xb[i] : 0.0;
+        b0[s] = i < a.m ? a.basic[i] : 0;
+    }
+#pragma unroll
+    for (int s = 0; s < CJ; s++) {
+        const int j = tid + s * NT;
+        r0[s] = j < a.nn ? a.r[j] : inf;   // padding never wins an argmin
+        n0[s] = j < a.nn ? a.nonbasic[j] : 0;
+    }
+    if (done) {
+        if (tid == 0) st->kdone = 0;
+        return;
+    }
     double ureg[RI][KR], vreg[CJ][KR];
 #pragma unroll
     for (int s = 0; s < RI; s++) {
         const int i = tid + s * NT;
-        xb_s[i] = i < a.m ? a.xb[i] : 0.0;
+        xb_s[i] = x0[s];
+        basic_s[i] = b0[s];
 #pragma unroll
         for (int j = 0; j < KR; j++) ureg[s][j] = 0;
     }
 #pragma unroll
     for (int s = 0; s < CJ; s++) {
         const int j = tid + s * NT;
-        r_s[j] = j < a.nn ? a.r[j] : inf;   // padding never wins an argmin
+        r_s[j] = r0[s];
+        nonbasic_s[j] = n0[s];
 #pragma unroll
         for (int j2 = 0; j2 < KR; j2++) vreg[s][j2] = 0;
     }
-    for (int i = tid; i < a.m; i += NT) basic_s[i] = a.basic[i];
-    for (int j = tid; j < a.nn; j += NT) nonbasic_s[j] = a.nonbasic[j];
     if (tid < KR + 1) payA[0][tid] = 0;   // a host-chosen first pivot reads v'_k[q] = 0 from here
     __syncthreads();
     int kd = 0, status = ST_RUNNING, blands = 0;
@@ -706,8 +723,7 @@ __global__ __launch_bounds__(256) void k_bt_tile(const double *__restrict__ src,
 template <int KMAX>
 __global__ __launch_bounds__(kBlock) void k_bt_update_tiled(BTArgs a, int tilerows_per_wg) {
     __shared__ double us[KMAX][64];
-    const int kd = a.st->kdone;
-    if (kd <= 0) return;
+    const int kd = a.st->kdone;   // tested below, after the loads that do not depend on it are in flight
     const unsigned int cx = blockIdx.x * kBlock + threadIdx.x;   // half piece within a tile row: 0 .. 2*ldt-1
     const unsigned int J = cx >> 3, r = (cx >> 1) & 3u, h = cx & 1u;
     const int I0 = blockIdx.y * tilerows_per_wg;
@@ -716,15 +732,20 @@ __global__ __launch_bounds__(kBlock) void k_bt_update_tiled(BTArgs a, int tilero
     for (int idx = threadIdx.x; idx < KMAX * 64; idx += kBlock) {
         const int k = idx / 64, rr = idx % 64;
         const int row = I0 * 4 + rr;
-        us[k][rr] = (k < kd && rr < nI * 4 && row < a.m) ? a.U[(size_t)k * a.ldu + row] : 0.0;
+        const double uval = (k < a.kmax && rr < nI * 4 && row < a.m) ? a.U[(size_t)k * a.ldu + row] : 0.0;
+        us[k][rr] = k < kd ? uval : 0.0;   // rows of U beyond the pivots of this block are stale
     }
     const bool inb = cx < 2u * (unsigned int)a.ldt;
     double2 vv[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
         vv[k] = make_double2(0, 0);
-        if (k < kd && inb) vv[k] = *reinterpret_cast<const double2 *>(a.V + (size_t)k * a.ldt + J * 4u + h * 2u);
+        if (k < a.kmax && inb) vv[k] = *reinterpret_cast<const double2 *>(a.V + (size_t)k * a.ldt + J * 4u + h * 2u);
     }
+    if (kd <= 0) return;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        if (k >= kd) vv[k] = make_double2(0, 0);   // rows of V beyond the pivots of this block are stale
     __syncthreads();
     if (!inb) return;
     double2 *cell = reinterpret_cast<double2 *>(a.T) + (size_t)I0 * (unsigned int)a.ldt * 2u + cx;
