@@ -41,7 +41,7 @@ def main() -> int:
     ap.add_argument("--chunk", type=int, default=64)
     ap.add_argument("--refresh", type=int, default=0)
     ap.add_argument("--frontier-vars", type=int, default=8, help="C5: 2^k children from the k highest fractional integer vars (0 = skip)")
-    ap.add_argument("--workers", type=int, default=8, help="engine contexts (HIP streams) per GPU for the frontier")
+    ap.add_argument("--workers", type=int, default=16, help="engine contexts (HIP streams) per GPU for the frontier")
     ap.add_argument("--frontier-cpu-children", type=int, default=8, help="children timed on the CPU oracle")
     ap.add_argument("--concurrent", type=int, default=4, help="extra figure: independent 2048x4096 LPs solved concurrently on one GPU (0 = skip)")
     ap.add_argument("--milp-nodes", type=int, default=127, help="C3: node budget of the host B&B over GPU relaxations (0 = skip)")

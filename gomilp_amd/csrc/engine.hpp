@@ -127,6 +127,7 @@ void launch_tab_permute_cols(const double *Tin, int ld_in, double *Tout, int ld_
 int tab_r_chunks(int m);
 void launch_tab_r(const double *T, int ldt, int m, int nn, const double *cost, const int32_t *basic, const int32_t *nonbasic,
                   double *scratch, double *r, hipStream_t s);
+void launch_tab_row_colmax(const double *T, int ldt, int m, int nn, int row, double *out, hipStream_t s);
 void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb, double *dvec, double *move, hipStream_t s);
 // bt_kernels.hip
 bool bt_supported(int m, int nn);

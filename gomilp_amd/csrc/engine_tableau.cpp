@@ -425,8 +425,16 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
             for (int jp = 0; jp < nn; jp++) if (nonbasic[jp] < n) cand.emplace_back(nonbasic[jp], jp);
             std::sort(cand.begin(), cand.end());
             bool exchanged = false;
+            // pivot elements T[added][jp] and column maxima of every candidate in one pass (tscratch holds 64 rows of ldt)
+            bt_layout(P, false);
+            launch_tab_row_colmax(w.T[tcur_], ldt_, m, nn, added, w.tscratch, stream_);
+            launches_++;
+            std::vector<double> rowmax((size_t)2 * ldt_);
+            HIP_TRY(hipMemcpyAsync(rowmax.data(), w.tscratch, rowmax.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipStreamSynchronize(stream_));
             for (auto &cv : cand) {
                 const int jp = cv.second;
+                if (!(fabs(rowmax[jp]) > 1e-9 * std::max(1.0, rowmax[(size_t)ldt_ + jp]))) continue;   // same test as below
                 bt_layout(P, false);
                 launch_tab_column(w.T[tcur_], ldt_, m, jp, w.xb, w.dvec, w.move, stream_);
                 launches_++;

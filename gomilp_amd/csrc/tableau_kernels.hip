@@ -319,6 +319,21 @@ void launch_tab_r(const double *T, int ldt, int m, int nn, const double *cost, c
     hipLaunchKernelGGL(k_tab_r_partial, grid, dim3(kBlock), 0, s, T, ldt, m, nn, cost, basic, scratch, rpc);
     hipLaunchKernelGGL(k_tab_r_reduce, dim3((ldt + 255) / 256), dim3(256), 0, s, scratch, ldt, nn, nchunks, cost, nonbasic, r);
 }
+// out[jp] = T[row][jp] and out[ldt + jp] = max_i |T[i][jp]| for every nonbasic position: what the exchange of a
+// zero-level artificial (simplex.go:581-606) needs to rank ALL candidate columns in one pass instead of one
+// column fetch + host round trip per candidate
+__global__ void k_tab_row_colmax(const double *__restrict__ T, int ldt, int m, int nn, int row, double *__restrict__ out) {
+    const int jp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (jp >= nn) return;
+    double mx = 0;
+    for (int i = 0; i < m; i++) mx = fmax(mx, fabs(T[(size_t)i * ldt + jp]));
+    out[jp] = T[(size_t)row * ldt + jp];
+    out[ldt + jp] = mx;
+}
+void launch_tab_row_colmax(const double *T, int ldt, int m, int nn, int row, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_row_colmax, dim3((nn + 255) / 256), dim3(256), 0, s, T, ldt, m, nn, row, out);
+}
+
 void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb, double *dvec, double *move, hipStream_t s) {
     hipLaunchKernelGGL(k_tab_column, dim3((m + 255) / 256), dim3(256), 0, s, T, ldt, m, jp, xb, dvec, move);
 }
