@@ -645,27 +645,101 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     if (*singular) return GOMILP_OK;
     // Dlaswp: b in logical row order
     for (int i = 0; i < m; i++) x[i] = P.hb[phys[i]];
-    // Dtrsm(Left, Lower, NoTrans, Unit): ascending k, zero multipliers skipped, (-l)*b_k + b_i
-    for (int i = 0; i < m; i++) {
+    // The two Dtrsm of Dgetrs, per row in gonum's order: ascending k, zero multipliers skipped, b_i = (-a_ik)*b_k + b_i
+    // as a rounded multiply and a rounded add (level3double.go:75-118).  Only the nd columns whose elimination step did
+    // arithmetic carry off-diagonal entries, so a row depends on the solution at those "dense" positions only: they are
+    // solved first, one after the other; every other row is then independent of the rest and four of them run
+    // interleaved (each row is one chain of dependent rounded additions: a single chain leaves the FPU idle).
+    std::vector<double> xd(nd);
+    std::vector<char> isd(m, 0);
+    for (int t = 0; t < nd; t++) isd[dl[t]] = 1;
+    std::vector<int> nl;   // logical positions that are not dense, ascending
+    nl.reserve(m - nd);
+    for (int i = 0; i < m; i++) if (!isd[i]) nl.push_back(i);
+    auto term = [](double bi, double va, double xk) { return va != 0 ? (-va) * xk + bi : bi; };
+    // ---- Dtrsm(Left, Lower, NoTrans, Unit)
+    for (int s2 = 0; s2 < nd; s2++) {
+        const int i = dl[s2];
         const double *row = w.h_W + (size_t)phys[i] * nd;
         double bi = x[i];
-        for (int t = 0; t < nd && dl[t] < i; t++) {
-            const double va = row[t];
-            if (va != 0) bi = (-va) * x[dl[t]] + bi;
-        }
-        x[i] = bi;
+        for (int t = 0; t < s2; t++) bi = term(bi, row[t], xd[t]);
+        x[i] = bi; xd[s2] = bi;
     }
-    // Dtrsm(Left, Upper, NoTrans, NonUnit): rows from the bottom, ascending k, then * (1/u_ii)
-    for (int i = m - 1; i >= 0; i--) {
+    {
+        size_t g = 0;
+        int cnt = 0;   // dense positions below the current row
+        for (; g + 4 <= nl.size(); g += 4) {
+            int c[4];
+            const double *row[4];
+            double acc[4];
+            for (int r = 0; r < 4; r++) {
+                const int i = nl[g + r];
+                while (cnt < nd && dl[cnt] < i) cnt++;
+                c[r] = cnt; row[r] = w.h_W + (size_t)phys[i] * nd; acc[r] = x[i];
+            }
+            const int c0 = c[0];   // c[0] <= c[1] <= c[2] <= c[3]
+            for (int t = 0; t < c0; t++) {
+                const double xk = xd[t];
+                acc[0] = term(acc[0], row[0][t], xk); acc[1] = term(acc[1], row[1][t], xk);
+                acc[2] = term(acc[2], row[2][t], xk); acc[3] = term(acc[3], row[3][t], xk);
+            }
+            for (int r = 1; r < 4; r++)
+                for (int t = c0; t < c[r]; t++) acc[r] = term(acc[r], row[r][t], xd[t]);
+            for (int r = 0; r < 4; r++) x[nl[g + r]] = acc[r];
+        }
+        for (; g < nl.size(); g++) {
+            const int i = nl[g];
+            while (cnt < nd && dl[cnt] < i) cnt++;
+            const double *row = w.h_W + (size_t)phys[i] * nd;
+            double bi = x[i];
+            for (int t = 0; t < cnt; t++) bi = term(bi, row[t], xd[t]);
+            x[i] = bi;
+        }
+    }
+    // ---- Dtrsm(Left, Upper, NoTrans, NonUnit): rows from the bottom, ascending k within a row, then * (1/u_ii)
+    for (int s2 = nd - 1; s2 >= 0; s2--) {
+        const int i = dl[s2];
         const double *row = w.h_W + (size_t)phys[i] * nd;
         double bi = x[i];
-        int t0 = (int)(std::upper_bound(dl.begin(), dl.end(), i) - dl.begin());
-        for (int t = t0; t < nd; t++) {
-            const double va = row[t];
-            if (va != 0) bi = (-va) * x[dl[t]] + bi;
-        }
+        for (int t = s2 + 1; t < nd; t++) bi = term(bi, row[t], xd[t]);
         const double tinv = 1 / diag[phys[i]];
-        x[i] = bi * tinv;
+        x[i] = bi * tinv; xd[s2] = x[i];
+    }
+    {
+        size_t g = 0;
+        int first = 0;   // first dense position above the current row
+        for (; g + 4 <= nl.size(); g += 4) {
+            int f[4];
+            const double *row[4];
+            double acc[4];
+            for (int r = 0; r < 4; r++) {
+                const int i = nl[g + r];
+                while (first < nd && dl[first] < i) first++;
+                f[r] = first; row[r] = w.h_W + (size_t)phys[i] * nd; acc[r] = x[i];
+            }
+            const int f3 = f[3];   // f[0] <= f[1] <= f[2] <= f[3]: the leading terms of rows 0..2 come first, in order
+            for (int r = 0; r < 3; r++)
+                for (int t = f[r]; t < f3; t++) acc[r] = term(acc[r], row[r][t], xd[t]);
+            for (int t = f3; t < nd; t++) {
+                const double xk = xd[t];
+                acc[0] = term(acc[0], row[0][t], xk); acc[1] = term(acc[1], row[1][t], xk);
+                acc[2] = term(acc[2], row[2][t], xk); acc[3] = term(acc[3], row[3][t], xk);
+            }
+            for (int r = 0; r < 4; r++) {
+                const int i = nl[g + r];
+                const double tinv = 1 / diag[phys[i]];
+                x[i] = acc[r] * tinv;
+            }
+        }
+        for (; g < nl.size(); g++) {
+            const int i = nl[g];
+            while (first < nd && dl[first] < i) first++;
+            const double *row = w.h_W + (size_t)phys[i] * nd;
+            double bi = x[i];
+            for (int t = first; t < nd; t++) bi = term(bi, row[t], xd[t]);
+            const double tinv = 1 / diag[phys[i]];
+            x[i] = bi * tinv;
+        }
     }
     fs_host_ += now_s() - tf1;
     return GOMILP_OK;
