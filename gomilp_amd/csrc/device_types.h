@@ -131,12 +131,14 @@ struct LUCtl {
     int32_t k_next;     // first elimination step not performed yet
     int32_t k0, k1;     // steps [k0, k1) were performed by the last round
     int32_t nsteps;     // how many of them did arithmetic ("dense" steps)
-    int32_t ncols;      // columns the panel held in registers at its start (>= nsteps)
+    int32_t ndrop;      // register columns the panel dropped un-eliminated (a newly dense column took their slot)
     int32_t rounds;     // rounds that did work
     int32_t pad[2];
     int32_t steps[32];  // step (= column) index of each dense step, ascending
     int32_t prow[32];   // its pivot row
-    int32_t cols[32];   // the register columns of the panel, ascending (cols[0..nsteps) == steps)
+    // dropped column d was in the register list for the rows that left the active set at steps [dropin, dropout):
+    // those rows hold final values in it (the panel wrote them), every other row still holds the original
+    int32_t dropcol[32], dropin[32], dropout[32];
 };
 
 // Arguments of the gonum-order LU kernels (final basis solve).

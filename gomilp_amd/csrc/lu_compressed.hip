@@ -11,14 +11,15 @@
 //   k_luc_panel   ONE workgroup: registers hold the next NB columns that are KNOWN to be dense (non-unit, or unit with
 //                 a used row), wherever they are; between two of them a single thread replays the run of bookkeeping
 //                 steps on LDS-resident index maps (lpos / rowat / active).  A unit column that BECOMES dense inside
-//                 the round (a dense step took its row) is not in registers: the round ends in front of it ("cut") and
-//                 the not yet eliminated register columns are dropped — W still holds their untouched originals.
+//                 the round (a dense step took its row: the column is -l of that step) is inserted into the register
+//                 list at its sorted position; when the list is full its last column is dropped un-eliminated (W
+//                 still holds its original; LUCtl records for which retired rows the panel already wrote it).
 //   k_luc_usolve  finishes the dense pivot rows right of the round (columns >= k1),
 //   k_luc_trail   applies the round's dense steps to every other row right of the round: all of them for rows that
 //                 are still active, the steps before its own for a row retired by a bookkeeping step of the round.
 // Rounds are data dependent, so the kernels take their step range from a device control block (LUCtl) and the host
 // enqueues rounds in batches until k_next == m.
-// m = 2048 metric basis: 2048 steps, 384 dense -> ~30 rounds instead of 128 panels.
+// m = 2048 metric basis: 2048 steps, 384 dense -> 24 rounds instead of 128 panels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -44,15 +45,19 @@ template <int T, int RPT, int NB>
 __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__ pivrow) {
     constexpr int NW = T / 64;
     constexpr int MAXM = T * RPT;
-    __shared__ int s_lpos[MAXM];    // logical position of physical row R
-    __shared__ int s_rowat[MAXM];   // physical row at logical position
-    __shared__ int s_unit[MAXM];    // unit_row per column
+    typedef unsigned short idx_t;            // m <= 4096
+    constexpr idx_t NONE = 0xFFFF;
+    __shared__ idx_t s_lpos[MAXM];    // logical position of physical row R
+    __shared__ idx_t s_rowat[MAXM];   // physical row at logical position
+    __shared__ idx_t s_unit[MAXM];    // unit_row per column (NONE: not a unit column)
+    __shared__ idx_t s_ucol[MAXM];    // inverse: the unit column of a row (NONE: none)
     __shared__ unsigned char s_active[MAXM];
     __shared__ double prow[2][NB];
     __shared__ double redM[2][16];
     __shared__ unsigned int redL[2][16];
-    __shared__ int s_cols[NB];
-    __shared__ int s_ncols, s_stop;
+    __shared__ int s_cols[2][NB];     // register columns, ascending; double buffered across insertions
+    __shared__ int s_in[2][NB];       // thread 0 only: dense step after which a column joined the list (-1: round start)
+    __shared__ int s_ncols, s_stop, s_limit, s_ins;
     LUCtl *ctl = a.ctl;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m = a.m;
@@ -64,12 +69,17 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
     }
     for (int R = tid; R < MAXM; R += T) {
         const bool in = R < m;
-        s_lpos[R] = in ? a.lpos[R] : R;
+        s_lpos[R] = (idx_t)(in ? a.lpos[R] : R);
         s_active[R] = (in && a.rowstep[R] < 0) ? 1 : 0;
-        s_unit[R] = (in && a.unit_row) ? a.unit_row[R] : -1;
+        const int ur = (in && a.unit_row) ? a.unit_row[R] : -1;
+        s_unit[R] = ur < 0 ? NONE : (idx_t)ur;
+        s_ucol[R] = NONE;
     }
     __syncthreads();
-    for (int R = tid; R < m; R += T) s_rowat[s_lpos[R]] = R;
+    for (int R = tid; R < m; R += T) {
+        s_rowat[s_lpos[R]] = (idx_t)R;
+        if (s_unit[R] != NONE) s_ucol[s_unit[R]] = (idx_t)R;   // column R is the unit vector of row s_unit[R]
+    }
     if (w == 0) {
         // the first NB columns >= k0 that are dense for sure
         int n = 0;
@@ -77,18 +87,20 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
             const int k = base + lane;
             bool dense = false;
             if (k < m) {
-                const int ur = s_unit[k];
-                dense = ur < 0 || !s_active[ur];
+                const idx_t ur = s_unit[k];
+                dense = ur == NONE || !s_active[ur];
             }
             const unsigned long long mask = __ballot(dense);
             const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-            if (dense && n + rank < NB) s_cols[n + rank] = k;
+            if (dense && n + rank < NB) s_cols[0][n + rank] = k;
             n += __popcll(mask);
         }
         if (lane == 0) s_ncols = n < NB ? n : NB;
+        if (lane < NB) s_in[0][lane] = -1;
     }
     __syncthreads();
-    const int ncols = s_ncols;
+    int ncols = s_ncols;
+    int lsel = 0;   // which copy of s_cols is current (uniform)
     CPanelRow<NB> rows[RPT];
 #define GOMILP_FOR_ROWS(F)                              \
     do {                                                \
@@ -100,32 +112,32 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
         row.lp = 0;
         const double *src = a.W + (row.act ? row.R : 0);
 #pragma unroll
-        for (int c = 0; c < NB; c++) row.v[c] = (row.act && c < ncols) ? src[(size_t)s_cols[c < ncols ? c : 0] * ldw] : 0.0;
+        for (int c = 0; c < NB; c++) row.v[c] = (row.act && c < ncols) ? src[(size_t)s_cols[0][c < ncols ? c : 0] * ldw] : 0.0;
     };
     GOMILP_FOR_ROWS(load_row);
-    if (tid < NB) ctl->cols[tid] = tid < ncols ? s_cols[tid] : -1;
     __syncthreads();   // every thread has taken its rows' `act` from s_active before thread 0's first run clears entries
-    int kcur = k0, s = 0, k1 = m;
+    int kcur = k0, s = 0, k1 = m, ndrop = 0;
 #pragma unroll 1
     for (;;) {
-        const int limit = (s < ncols) ? s_cols[s] : m;
         if (tid == 0) {
             // run of bookkeeping steps [kcur, limit): Idamax finds the 1 in row ur, dlaswp exchanges logical
             // positions k and lpos[ur]; nothing else happens (the step's multipliers are exactly 0)
+            const int limit = (s < ncols) ? s_cols[lsel][s] : m;
             int k = kcur;
             while (k < limit) {
-                const int ur = s_unit[k];
-                if (ur < 0 || !s_active[ur]) break;
-                const int jp = s_lpos[ur], Q = s_rowat[k];
+                const idx_t ur = s_unit[k];
+                if (ur == NONE || !s_active[ur]) break;
+                const idx_t jp = s_lpos[ur], Q = s_rowat[k];
                 s_lpos[Q] = jp; s_rowat[jp] = Q;
-                s_lpos[ur] = k; s_rowat[k] = ur;
+                s_lpos[ur] = (idx_t)k; s_rowat[k] = ur;
                 s_active[ur] = 0;
                 k++;
             }
-            s_stop = k;
+            s_stop = k; s_limit = limit;
         }
         __syncthreads();
-        const int kstop = s_stop;
+        const int kstop = s_stop, limit = s_limit;
+        const int *cols = s_cols[lsel];
         // rows retired by the run become U rows: their entries in the register columns are final
         auto retire = [&](CPanelRow<NB> &row, int) {
             if (!row.act || s_active[row.R]) return;
@@ -134,15 +146,15 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
             double *dst = a.W + row.R;
 #pragma unroll
             for (int c = 0; c < NB; c++)
-                if (s + c < ncols) dst[(size_t)s_cols[s + c] * ldw] = row.v[c];
+                if (s + c < ncols) dst[(size_t)cols[s + c] * ldw] = row.v[c];
             row.act = false;
         };
         GOMILP_FOR_ROWS(retire);
         if (kstop < limit || s >= ncols) { k1 = kstop; break; }
         const int k = limit;
-        // ---- dense step k: pivot = first max |a_ik| in logical row order (idamax over the permuted column)
-        // idamax without (key, index) candidates: the minimum of -|a_ik| by v_min_f64 over DPP row shifts, then the
-        // smallest logical position among the rows that attain it (u32 min) — first maximum in LAPACK row order
+        // ---- dense step k.  idamax without (key, index) candidates: the minimum of -|a_ik| by v_min_f64 over DPP row
+        // shifts, then the smallest logical position among the rows that attain it (u32 min): first maximum in
+        // LAPACK row order
         double xm = __builtin_inf();
         auto cand = [&](CPanelRow<NB> &row, int) {
             if (!row.act) return;
@@ -175,16 +187,19 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
 #pragma unroll
             for (int cc = 0; cc < NB; cc++) {
                 pr[cc] = row.v[cc];
-                if (s + cc < ncols) dst[(size_t)s_cols[s + cc] * ldw] = row.v[cc];
+                if (s + cc < ncols) dst[(size_t)cols[s + cc] * ldw] = row.v[cc];
             }
             row.act = false;
             s_active[P] = 0;
             a.rowstep[P] = k; pivrow[k] = P;
             if (a.dense_flag) a.dense_flag[k] = 1;
             ctl->steps[s] = k; ctl->prow[s] = P;
-            const int Q = s_rowat[k];   // dlaswp.go: the row at logical k moves to jp
-            s_lpos[Q] = jp; s_rowat[jp] = Q;
-            s_lpos[P] = k; s_rowat[k] = P;
+            const idx_t Q = s_rowat[k];   // dlaswp.go: the row at logical k moves to jp
+            s_lpos[Q] = (idx_t)jp; s_rowat[jp] = Q;
+            s_lpos[P] = (idx_t)k; s_rowat[k] = (idx_t)P;
+            // taking row P makes the unit column of P (if it is still to come) dense from this step on
+            const idx_t uc = s_ucol[P];
+            s_ins = (uc != NONE && (int)uc > k) ? (int)uc : -1;
         };
         GOMILP_FOR_ROWS(publish);
         __syncthreads();
@@ -192,6 +207,22 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
         const bool singular = (piv == 0);  // dgetf2.go:48-49: no scaling, the rank-1 update is a no-op
         if (singular && tid == 0) a.st->lu_singular = 1;
         const double rinv = 1.0 / piv;
+        // ---- the column that just became dense joins the register list (sorted position `pos` behind the columns
+        // still to come) instead of ending the round in front of it; with a full list the last column is dropped
+        // (W still holds its original: the trailing kernels redo it, except for the rows retired while it was listed)
+        const int k2 = s_ins;
+        const int rest = ncols - (s + 1);   // columns behind the current one
+        bool doins = false;
+        int pos = 0;
+        if (k2 >= 0) {
+            // one LDS read per lane + a ballot instead of a serial scan of the list
+            const int cv = (lane < rest) ? cols[s + 1 + lane] : 0x7fffffff;   // NB <= 32 < 64 lanes
+            const unsigned long long below = __ballot(cv < k2);
+            const int lastv = rest > 0 ? cols[ncols - 1] : -1;
+            doins = (ncols < NB) || (k2 < lastv);
+            pos = doins ? __popcll(below) : 0;
+        }
+        const bool dropping = doins && ncols == NB;
         double *wcol = a.W + (size_t)k * ldw;      // column k of L\U
         double *lcol = a.Lp + (size_t)s * ldw;     // compact panel: -l (0 for rows that are not active)
         auto elim = [&](CPanelRow<NB> &row, int) {
@@ -204,17 +235,52 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
             const double nl = -l;
             lcol[row.R] = singular ? 0.0 : nl;
             const bool skip = singular;   // Dger (dgetf2.go:60-66) does not skip zero multipliers
+            if (!doins) {   // plain shift (uniform branch)
 #pragma unroll
-            for (int cc = 1; cc < NB; cc++) row.v[cc - 1] = skip ? row.v[cc] : __dadd_rn(__dmul_rn(nl, pr[cc]), row.v[cc]);
-            row.v[NB - 1] = 0.0;
+                for (int cc = 1; cc < NB; cc++) row.v[cc - 1] = skip ? row.v[cc] : __dadd_rn(__dmul_rn(nl, pr[cc]), row.v[cc]);
+                row.v[NB - 1] = 0.0;
+                return;
+            }
+            typename CPanelRow<NB>::vec old = row.v;   // old[c], c >= 1: column c after this step's update
+#pragma unroll
+            for (int cc = 1; cc < NB; cc++) old[cc] = skip ? row.v[cc] : __dadd_rn(__dmul_rn(nl, pr[cc]), row.v[cc]);
+            // e_P column: 0 + (-l)*1 for the active rows
+            const double vnew = skip ? 0.0 : __dadd_rn(__dmul_rn(nl, 1.0), 0.0);
+#pragma unroll
+            for (int cc = 0; cc < NB; cc++) {
+                const double shifted = cc + 1 < NB ? old[cc + 1 < NB ? cc + 1 : 0] : 0.0;
+                const double stay = cc >= 1 ? old[cc >= 1 ? cc : 1] : 0.0;
+                row.v[cc] = (cc > pos) ? stay : ((cc == pos) ? vnew : shifted);
+            }
         };
         GOMILP_FOR_ROWS(elim);
+        if (doins) {
+            if (tid == 0) {
+                // new list in the other copy: entries up to and including s unchanged, then the rest with k2 at s+1+pos
+                int *nc = s_cols[lsel ^ 1], *ni = s_in[lsel ^ 1];
+                const int *oi = s_in[lsel];
+                for (int c = 0; c <= s; c++) { nc[c] = cols[c]; ni[c] = oi[c]; }
+                int src = s + 1;
+                for (int c = s + 1; c < NB; c++) {
+                    if (c == s + 1 + pos) { nc[c] = k2; ni[c] = k; }
+                    else if (src < ncols) { nc[c] = cols[src]; ni[c] = oi[src]; src++; }
+                }
+                if (dropping) {
+                    ctl->dropcol[ndrop] = cols[ncols - 1];
+                    ctl->dropin[ndrop] = oi[ncols - 1];
+                    ctl->dropout[ndrop] = k + 1;
+                }
+            }
+            if (dropping) ndrop++;
+            else ncols++;
+            lsel ^= 1;
+        }
         s++;
         kcur = k + 1;
     }
     for (int R = tid; R < m; R += T) a.lpos[R] = s_lpos[R];
     if (tid == 0) {
-        ctl->k0 = k0; ctl->k1 = k1; ctl->k_next = k1; ctl->nsteps = s; ctl->ncols = ncols;
+        ctl->k0 = k0; ctl->k1 = k1; ctl->k_next = k1; ctl->nsteps = s; ctl->ndrop = ndrop;
         ctl->rounds += 1;
     }
 #undef GOMILP_FOR_ROWS
@@ -222,7 +288,7 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
 
 // dense pivot rows of the round, columns j >= k1:  u_s = a[P_s] + sum_{t<s} (-l[P_s][t]) * u_t  (ascending t, the
 // Dtrsm of dgetrf.go:57-60) into the compact panel Up; the trailing kernel writes them back into W together with all
-// other rows.  Register columns of the panel (ctl->cols) are final already: the panel wrote them.
+// other rows.  In a column the panel dropped, a pivot row that left while the column was listed is final already.
 template <int NB>
 __global__ __launch_bounds__(256) void k_luc_usolve(LUArgs a) {
     const LUCtl *ctl = a.ctl;
@@ -231,12 +297,16 @@ __global__ __launch_bounds__(256) void k_luc_usolve(LUArgs a) {
     if (ns == 0 || j0 >= a.m) return;
     __shared__ double Ln[NB][NB + 1];
     __shared__ double X[NB][64 + 1];
-    __shared__ int Ps[NB], Cs[NB];
+    __shared__ int Ps[NB], Ss[NB], Dc[NB], Di[NB], Do[NB];
     const int tid = threadIdx.x;
     const size_t ldw = (size_t)a.ldw;
+    const int nd = ctl->ndrop;
     if (tid < NB) {
         Ps[tid] = tid < ns ? ctl->prow[tid] : 0;
-        Cs[tid] = tid < ctl->ncols ? ctl->cols[tid] : -1;
+        Ss[tid] = tid < ns ? ctl->steps[tid] : 0x7fffffff;
+        Dc[tid] = tid < nd ? ctl->dropcol[tid] : -1;
+        Di[tid] = tid < nd ? ctl->dropin[tid] : 0;
+        Do[tid] = tid < nd ? ctl->dropout[tid] : 0;
     }
     __syncthreads();
     for (int idx = tid; idx < NB * NB; idx += 256) {
@@ -251,15 +321,15 @@ __global__ __launch_bounds__(256) void k_luc_usolve(LUArgs a) {
     __syncthreads();
     const int j = j0 + tid;
     if (tid >= 64 || j >= a.m) return;
-    bool inlist = false;
-#pragma unroll
-    for (int t = 0; t < NB; t++) inlist |= (Cs[t] == j);
+    int din = 0, dout = 0;   // window of steps whose pivot rows are final in this column (empty: not a dropped column)
+    for (int t = 0; t < nd; t++)
+        if (Dc[t] == j) { din = Di[t]; dout = Do[t]; }
     double u[NB];
 #pragma unroll
     for (int s = 0; s < NB; s++) {
         if (s < ns) {
             double x = X[s][tid];
-            if (!inlist) {
+            if (!(Ss[s] >= din && Ss[s] < dout)) {
 #pragma unroll
                 for (int t = 0; t < s; t++) {
                     const double l = Ln[s][t];
@@ -277,8 +347,8 @@ __global__ __launch_bounds__(256) void k_luc_usolve(LUArgs a) {
 // every row that took part in the round, columns j >= k1: a[R][j] += sum_s Lp[s][R] * Up[s][j] in ascending s (the
 // Dgemm of dgetrf.go:62-66; zero multipliers skipped).  Lp is zero from the step at which a row left the active set,
 // so rows still active take all steps, a row retired by a bookkeeping step takes the steps before it and the pivot row
-// of dense step s takes steps < s — which IS its U-solve recurrence.  Rows that left during the round already hold
-// final values in the panel's register columns (retire / publish wrote them).
+// of dense step s takes steps < s — which IS its U-solve recurrence.  In a column the panel dropped, the rows that left
+// while it was listed hold final values already (retire / publish wrote them).
 template <int NB>
 __global__ __launch_bounds__(256) void k_luc_trail(LUArgs a) {
     const LUCtl *ctl = a.ctl;
@@ -287,8 +357,9 @@ __global__ __launch_bounds__(256) void k_luc_trail(LUArgs a) {
     if (ns == 0 || j0 >= a.m) return;
     __shared__ double Ls[NB][64];
     __shared__ double Us[NB][64];
-    __shared__ unsigned char rowcls[64], inlist[64];
-    __shared__ int Cs[NB];
+    __shared__ unsigned char rowcls[64];
+    __shared__ int rstep[64], cdin[64], cdout[64];
+    __shared__ int Dc[NB], Di[NB], Do[NB];
     const int tid = threadIdx.x;
     const int R0 = blockIdx.y * 64;
     const size_t ldw = (size_t)a.ldw;
@@ -305,7 +376,12 @@ __global__ __launch_bounds__(256) void k_luc_trail(LUArgs a) {
             acc[cc][rr] = ((j0 + c) < a.m && (R0 + r) < a.m) ? a.W[(size_t)(j0 + c) * ldw + R0 + r] : 0.0;
         }
     }
-    if (tid < NB) Cs[tid] = tid < ctl->ncols ? ctl->cols[tid] : -1;
+    const int nd = ctl->ndrop;
+    if (tid < NB) {
+        Dc[tid] = tid < nd ? ctl->dropcol[tid] : -1;
+        Di[tid] = tid < nd ? ctl->dropin[tid] : 0;
+        Do[tid] = tid < nd ? ctl->dropout[tid] : 0;
+    }
     for (int idx = tid; idx < NB * 64; idx += 256) {
         const int s = idx / 64, c = idx % 64;
         Ls[s][c] = (s < ns && R0 + c < a.m) ? a.Lp[(size_t)s * ldw + R0 + c] : 0.0;
@@ -315,16 +391,19 @@ __global__ __launch_bounds__(256) void k_luc_trail(LUArgs a) {
     int cls = 0;
     if (tid < 64) {
         const int R = R0 + tid;
+        int rs = -1;
         if (R < a.m) {
-            const int rs = a.rowstep[R];
+            rs = a.rowstep[R];
             cls = rs < 0 ? 1 : (rs >= k0 ? 2 : 0);   // 1 active, 2 left during this round, 0 finished earlier
         }
         rowcls[tid] = (unsigned char)cls;
+        rstep[tid] = rs;
     } else if (tid < 128) {
         const int j = j0 + (tid - 64);
-        bool il = false;
-        for (int t = 0; t < NB; t++) il |= (Cs[t] == j);
-        inlist[tid - 64] = il ? 1 : 0;
+        int din = 0, dout = 0;   // rows that left at steps [din, dout) are final in this column
+        for (int t = 0; t < nd; t++)
+            if (Dc[t] == j) { din = Di[t]; dout = Do[t]; }
+        cdin[tid - 64] = din; cdout[tid - 64] = dout;
     }
     if (!__syncthreads_or(cls > 0)) return;
     bool live[4][4];
@@ -334,7 +413,7 @@ __global__ __launch_bounds__(256) void k_luc_trail(LUArgs a) {
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
             const int r = tx * 4 + rr;
-            live[cc][rr] = rowcls[r] > 0 && (j0 + c) < a.m && !(rowcls[r] == 2 && inlist[c]);
+            live[cc][rr] = rowcls[r] > 0 && (j0 + c) < a.m && !(rowcls[r] == 2 && rstep[r] >= cdin[c] && rstep[r] < cdout[c]);
         }
     }
 #pragma unroll
@@ -370,7 +449,7 @@ __global__ void k_luc_init(LUArgs a) {
     }
     if (R == 0) {
         LUCtl *c = a.ctl;
-        c->k_next = 0; c->k0 = 0; c->k1 = 0; c->nsteps = 0; c->ncols = 0; c->rounds = 0;
+        c->k_next = 0; c->k0 = 0; c->k1 = 0; c->nsteps = 0; c->ndrop = 0; c->rounds = 0;
     }
 }
 
