@@ -238,43 +238,72 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
     const int64_t blocks_per_chunk = std::max<int64_t>(1, chunk_ / K);
     const bool sampling = sample_events_ > 0;
     int64_t block_no = 0;
-    for (;;) {
-        const int64_t before = hs.pivots;
-        size_t nsamp = 0;
+    // Chunks are pipelined: chunk c+1 is enqueued BEFORE the host waits for the state of chunk c, so the GPU never idles
+    // for a host round trip; the price is one chunk of no-op launches after the device has set `done`.
+    if (!w.pipe_state[0]) {
+        for (int t = 0; t < 2; t++) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.pipe_state[t]), sizeof(DevState), hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&w.pipe_ev[t], hipEventDisableTiming));
+        }
+    }
+    struct ChunkInfo { int64_t before_pred; size_t samp0, nsamp; };
+    ChunkInfo info[2];
+    size_t samp_total = 0;
+    auto enqueue_chunk = [&](int slot, int64_t before_pred) -> int {
+        info[slot].before_pred = before_pred;
+        info[slot].samp0 = samp_total;
+        info[slot].nsamp = 0;
         for (int64_t bkk = 0; bkk < blocks_per_chunk; bkk++, block_no++) {
             int kmax = K;
-            if (max_pivots_ > 0) kmax = (int)std::max<int64_t>(1, std::min<int64_t>(K, max_pivots_ - before - bkk * K));
+            if (max_pivots_ > 0) kmax = (int)std::max<int64_t>(1, std::min<int64_t>(K, max_pivots_ - before_pred - bkk * K));
             BTArgs a = make_bt_args(P, phase, tol, nn, kmax);
             a.kmax = K;  // the update kernel is instantiated for the configured block size
             BTArgs ai = a; ai.kmax = kmax;
             const bool sample = sampling && (block_no % std::max<int64_t>(1, sample_events_ / K) == 0);
             hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
             if (sample) {
-                while (w.sample_ev.size() < (nsamp + 1) * 6) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); w.sample_ev.push_back(ev); }
-                for (int k = 0; k < 4; k++) e[k] = w.sample_ev[nsamp * 6 + k];
-                nsamp++;
+                while (w.sample_ev.size() < (samp_total + 1) * 6) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); w.sample_ev.push_back(ev); }
+                for (int k = 0; k < 4; k++) e[k] = w.sample_ev[samp_total * 6 + k];
+                samp_total++; info[slot].nsamp++;
             }
             launch_bt_inner(ai, stream_, e[0], e[1]);
             launch_bt_update(a, stream_, e[2], e[3]);
             launches_ += 2;
         }
-        HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(hipMemcpyAsync(w.pipe_state[slot], w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipEventRecord(w.pipe_ev[slot], stream_));
+        return GOMILP_OK;
+    };
+    int cur = 0;
+    int64_t pred = 0;   // pivots if every enqueued block ran in full
+    { int rc0 = enqueue_chunk(0, 0); if (rc0 != GOMILP_OK) return rc0; }
+    pred = blocks_per_chunk * K;
+    int64_t seen = 0;   // pivots at the end of the previous inspected chunk
+    for (;;) {
+        // keep one chunk in flight behind the one whose state is awaited (not past a pivot budget)
+        const bool more = !(max_pivots_ > 0 && pred >= max_pivots_);
+        if (more) { int rc1 = enqueue_chunk(cur ^ 1, pred); if (rc1 != GOMILP_OK) return rc1; pred += blocks_per_chunk * K; }
+        HIP_TRY(hipEventSynchronize(w.pipe_ev[cur]));
         HIP_TRY(hipGetLastError());
-        const int64_t executed = hs.pivots - before;
-        if (st && nsamp && executed == blocks_per_chunk * K) {  // only chunks made of full blocks are samples
-            for (size_t s = 0; s < nsamp; s++) {
+        hs = *w.pipe_state[cur];
+        const int64_t executed = hs.pivots - seen;
+        const ChunkInfo &ci = info[cur];
+        if (st && ci.nsamp && executed == blocks_per_chunk * K) {  // only chunks made of full blocks are samples
+            for (size_t s2 = ci.samp0; s2 < ci.samp0 + ci.nsamp; s2++) {
                 float ms0 = 0, ms1 = 0;
-                if (hipEventElapsedTime(&ms0, w.sample_ev[s * 6], w.sample_ev[s * 6 + 1]) != hipSuccess) continue;
-                if (hipEventElapsedTime(&ms1, w.sample_ev[s * 6 + 2], w.sample_ev[s * 6 + 3]) != hipSuccess) continue;
+                if (hipEventElapsedTime(&ms0, w.sample_ev[s2 * 6], w.sample_ev[s2 * 6 + 1]) != hipSuccess) continue;
+                if (hipEventElapsedTime(&ms1, w.sample_ev[s2 * 6 + 2], w.sample_ev[s2 * 6 + 3]) != hipSuccess) continue;
                 st->pivot_kernel_seconds[0] += ms0 * 1e-3;  // inner kernel: K pivots
                 st->pivot_kernel_seconds[2] += ms1 * 1e-3;  // rank-K update
                 st->pivot_kernel_seconds[1] += 1.0;         // sampled blocks
                 st->pivot_kernel_seconds[3] += (double)K;   // sampled pivots
             }
         }
+        seen = hs.pivots;
         if (!hs.done) {
             if (max_pivots_ > 0 && hs.pivots >= max_pivots_) { ret = GOMILP_ERR_UNSUPPORTED; break; }
+            if (!more) { ret = GOMILP_ERR_UNSUPPORTED; break; }
+            cur ^= 1;
             continue;
         }
         if (hs.status == ST_OPTIMAL) break;

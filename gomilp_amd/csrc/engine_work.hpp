@@ -89,6 +89,8 @@ struct Engine::Work {
     char *child_stage = nullptr;  // pinned staging block of upload_child
     size_t child_stage_cap = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    DevState *pipe_state[2] = {nullptr, nullptr};   // pinned: state after each of the two chunks in flight (blocked pipeline)
+    hipEvent_t pipe_ev[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> sample_ev;  // pairs around sampled kernels
 
     void release() {
