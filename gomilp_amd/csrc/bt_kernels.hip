@@ -464,14 +464,23 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
             dcol[s] = i < a.m ? d : 0.0;
         }
     };
-    // ratio vector (simplex.go:321-340); rows beyond m carry +Inf
+    // ratio vector (simplex.go:321-340); rows beyond m carry +Inf.  Branch-free: the quotient is formed for every row
+    // and discarded where the reference does not divide (x/0 is harmless here), so the division chains of a thread's
+    // rows interleave instead of running one after the other inside exec-masked branches
     auto ratios = [&](const double (&dcol)[RI], double (&mvv)[RI]) {
+        double quot[RI], dn[RI];
 #pragma unroll
         for (int s = 0; s < RI; s++) {
             const int i = tid + s * NT;
             double d = -dcol[s];
             if (fabs(d) < 1e-13) d = 0;
-            mvv[s] = (d >= 0 || i >= a.m) ? inf : xb_s[i] / fabs(d);
+            dn[s] = d;
+            quot[s] = xb_s[i] / fabs(d);
+        }
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            const int i = tid + s * NT;
+            mvv[s] = (dn[s] >= 0 || i >= a.m) ? inf : quot[s];
         }
     };
 
