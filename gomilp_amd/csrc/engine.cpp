@@ -778,7 +778,6 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
         return finish(P.verify_status);
     }
     const int m = P.m, n = P.n;
-    if (initial_basic) return finish(GOMILP_ERR_UNSUPPORTED);  // GoMILP always passes nil (subproblem.go:154,172)
     int rc = ensure_work(m, n + 1);
     if (rc != GOMILP_OK) return finish(rc);
     Work &w = *w_;
@@ -807,7 +806,16 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     // unit vectors (always true for GoMILP's [.. | I] standard forms, subproblem.go:81-139); cond == 1 there.
     std::vector<int32_t> basic(m), rho(m);
     bool unit_basis = true;
-    {
+    if (initial_basic) {
+        // supplied basis (simplex.go:147-160; GoMILP itself always passes nil): the caller hands over m entries; an index
+        // out of range panics in extractColumns, a singular or infeasible set panics in initializeFromBasic (:447-471)
+        unit_basis = false;
+        for (int pos = 0; pos < m; pos++) {
+            const int64_t j = initial_basic[pos];
+            if (j < 0 || j >= n) return finish(GOMILP_ERR_PANIC);
+            basic[pos] = (int32_t)j;
+        }
+    } else {
         std::vector<char> used(m, 0);
         for (int pos = 0; pos < m; pos++) {
             const int j = n - 1 - pos;
@@ -825,9 +833,12 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     } else {
         // general case (engine_general.cpp): host search over a kept copy of A, small problems on the tableau pipelines
         if (P.hA.empty() || !use_tab || m > 512) return finish(GOMILP_ERR_UNSUPPORTED);
-        rc = general_find_linearly_independent(P.hA, m, n, basic);
-        if (rc != GOMILP_OK) return finish(rc);  // ErrSingular, simplex.go:495-497
-        if (!general_basis_inverse(P.hA, m, n, basic, n, std::vector<double>(), binv_host)) return finish(GOMILP_ERR_SINGULAR);
+        if (!initial_basic) {
+            rc = general_find_linearly_independent(P.hA, m, n, basic);
+            if (rc != GOMILP_OK) return finish(rc);  // ErrSingular, simplex.go:495-497
+        }
+        if (!general_basis_inverse(P.hA, m, n, basic, n, std::vector<double>(), binv_host))
+            return finish(initial_basic ? GOMILP_ERR_PANIC : GOMILP_ERR_SINGULAR);
         // xb = ab^-1 b with the reference's own arithmetic (gonum-order LU on the device): the feasibility test of
         // simplex.go:459-469 then sees the same bits
         if ((rc = upload_index_lists(basic, {})) != GOMILP_OK) return finish(rc);
@@ -835,6 +846,7 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
         if ((rc = final_solve(P, n, xb_exact, &sing)) != GOMILP_OK) return finish(rc);
         if (sing) { feasible = false; }  // "singular" also sends the reference to Phase I (simplex.go:504-507), xb stays zero
         else { xb = xb_exact; for (int pos = 0; pos < m; pos++) if (xb[pos] < -1e-13) feasible = false; }
+        if (initial_basic && !feasible) return finish(GOMILP_ERR_PANIC);  // initializeFromBasic errors panic (:156-158)
     }
     cur_ = 0;
     if (unit_basis && !use_tab) {

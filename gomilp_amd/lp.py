@@ -211,15 +211,18 @@ class ResidentLP:
             raise RuntimeError("gomilp_lp_upload_child failed: %s" % STATUS_NAMES.get(-pid, -pid))
         return ResidentLP(self.ctx, pid, self.m + K, self.n + K)
 
-    def solve(self, tol: float = 0.0, trace: bool = False) -> LPResult:
+    def solve(self, tol: float = 0.0, trace: bool = False, initial_basic=None) -> LPResult:
         L = lib()
+        ib = None if initial_basic is None else np.ascontiguousarray(initial_basic, dtype=np.int64)
+        if ib is not None and ib.shape != (self.m,):
+            raise ValueError("lp: incorrect number of initial vectors")   # simplex.go:149-151 panics
         x = np.zeros(self.n)
         basis = np.zeros(self.m, dtype=np.int64)
         z = C.c_double(math.nan)
         has_x = C.c_int32(0)
         st = Stats()
         self.ctx.set("trace", 1 if trace else 0)
-        rc = L.gomilp_lp_solve_resident(self.ctx._h, self.pid, float(tol), None, C.byref(z), _dp(x), C.byref(has_x),
+        rc = L.gomilp_lp_solve_resident(self.ctx._h, self.pid, float(tol), _ip(ib) if ib is not None else None, C.byref(z), _dp(x), C.byref(has_x),
                                         _ip(basis), C.byref(st))
         piv = []
         if trace:

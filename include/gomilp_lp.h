@@ -83,6 +83,9 @@ typedef struct gomilp_pivot {
  * opt_x (length n, caller-owned) is written only when *has_x = 1 (the reference returns nil x on
  * most errors); a mid-loop failure returns the error AND the current point, like the reference.
  * basis_out (nullable, length m) receives the final basicIdxs in positional order.
+ * initial_basic (nullable, exactly m entries; GoMILP passes nil): a supplied feasible basis skips Phase I
+ * (simplex.go:147-160); an index out of range, a singular or an infeasible set return GOMILP_ERR_PANIC (the
+ * reference panics); supported for m <= 512 (GOMILP_ERR_UNSUPPORTED above), like any non-slack starting basis.
  * ---------------------------------------------------------------------------------------- */
 int gomilp_lp_simplex(const double *c, const double *A, int64_t lda, const double *b, int64_t m, int64_t n,
                       double tol, const int64_t *initial_basic, double *opt_f, double *opt_x, int32_t *has_x,

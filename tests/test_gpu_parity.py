@@ -356,3 +356,26 @@ def test_bnb_driver_reference_goldens():
             assert np.array_equal(res.x, arr(kat["want_x"])), kat["id"]
             if kat["want_z"] is not None:
                 assert res.z == kat["want_z"], kat["id"]
+
+
+@pytest.mark.parametrize("m,seed,after", [(40, 5, 0), (40, 5, 7), (96, 2, 25), (200, 3, 60)])
+def test_supplied_initial_basis(ctx, m, seed, after):
+    """initialBasic != nil (simplex.go:147-160): Phase I is skipped, the pivots continue from the supplied vertex.
+    The basis after `after` pivots of a plain solve is feasible by construction."""
+    c, A, b = synth.dense_lp_standard_form(m, seed)
+    n = A.shape[1]
+    plain = O.simplex(c, A, b, 0.0, None, fast_initial_basis=True, trace=True)
+    basic = [n - 1 - pos for pos in range(m)]          # slack basis in findLinearlyIndependent's scan order
+    for p in plain.pivots[:after]:
+        basic[p[3]] = p[4]                               # (phase, bland, min_idx, replace, entering, leaving)
+    o = O.simplex(c, A, b, 0.0, basic, trace=True)
+    rl = ctx.upload(c, A, b)
+    g = rl.solve(0.0, trace=True, initial_basic=basic)
+    assert g.status == o.status == lp.OK
+    assert _same_trace(g.pivots, o.pivots)
+    assert np.array_equal(g.basis, o.basis) and np.array_equal(g.x, o.x) and g.z == o.z
+    # an infeasible vertex and a singular set panic in the reference (initializeFromBasic)
+    bad = list(basic)
+    bad[0] = bad[1]
+    assert rl.solve(0.0, initial_basic=bad).status == lp.ERR_PANIC == O.simplex(c, A, b, 0.0, bad).status
+    rl.free()
