@@ -304,9 +304,32 @@ int Engine::refresh_xb_y(const Problem &P, const double *cost) {
 
 int Engine::upload_index_lists(const std::vector<int32_t> &basic, const std::vector<int32_t> &nonbasic) {
     Work &w = *w_;
-    if (!basic.empty()) HIP_TRY(hipMemcpyAsync(w.basic, basic.data(), basic.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-    if (!nonbasic.empty()) HIP_TRY(hipMemcpyAsync(w.nonbasic, nonbasic.data(), nonbasic.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));  // the vectors are pageable host memory
+    // through a pinned staging block (two slots, each guarded by an event) instead of a stream sync per call: the
+    // callers' vectors are pageable and may die right after the call
+    const size_t need = basic.size() + nonbasic.size();
+    if (w.idx_stage_cap < need) {
+        for (int t = 0; t < 2; t++) {
+            if (w.idx_stage[t]) { if (w.idx_stage_ev[t]) hipEventSynchronize(w.idx_stage_ev[t]); hipHostFree(w.idx_stage[t]); w.idx_stage[t] = nullptr; }
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.idx_stage[t]), need * 2 * sizeof(int32_t), hipHostMallocDefault));
+            if (!w.idx_stage_ev[t]) HIP_TRY(hipEventCreateWithFlags(&w.idx_stage_ev[t], hipEventDisableTiming));
+        }
+        w.idx_stage_cap = need * 2;
+        w.idx_stage_used[0] = w.idx_stage_used[1] = false;
+    }
+    const int slot = w.idx_stage_next;
+    w.idx_stage_next ^= 1;
+    if (w.idx_stage_used[slot]) HIP_TRY(hipEventSynchronize(w.idx_stage_ev[slot]));
+    int32_t *stg = w.idx_stage[slot];
+    if (!basic.empty()) {
+        memcpy(stg, basic.data(), basic.size() * sizeof(int32_t));
+        HIP_TRY(hipMemcpyAsync(w.basic, stg, basic.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    }
+    if (!nonbasic.empty()) {
+        memcpy(stg + basic.size(), nonbasic.data(), nonbasic.size() * sizeof(int32_t));
+        HIP_TRY(hipMemcpyAsync(w.nonbasic, stg + basic.size(), nonbasic.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    }
+    HIP_TRY(hipEventRecord(w.idx_stage_ev[slot], stream_));
+    w.idx_stage_used[slot] = true;
     return GOMILP_OK;
 }
 

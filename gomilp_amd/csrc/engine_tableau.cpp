@@ -281,8 +281,11 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
     int64_t seen = 0;   // pivots at the end of the previous inspected chunk
     for (;;) {
         // keep one chunk in flight behind the one whose state is awaited (not past a pivot budget)
+        // (not behind the very first chunk: short loops — B&B children — usually end inside it, and the speculative
+        // chunk would be pure no-op launches)
         const bool more = !(max_pivots_ > 0 && pred >= max_pivots_);
-        if (more) { int rc1 = enqueue_chunk(cur ^ 1, pred); if (rc1 != GOMILP_OK) return rc1; pred += blocks_per_chunk * K; }
+        const bool speculate = more && seen > 0;
+        if (speculate) { int rc1 = enqueue_chunk(cur ^ 1, pred); if (rc1 != GOMILP_OK) return rc1; pred += blocks_per_chunk * K; }
         HIP_TRY(hipEventSynchronize(w.pipe_ev[cur]));
         HIP_TRY(hipGetLastError());
         hs = *w.pipe_state[cur];
@@ -303,6 +306,7 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
         if (!hs.done) {
             if (max_pivots_ > 0 && hs.pivots >= max_pivots_) { ret = GOMILP_ERR_UNSUPPORTED; break; }
             if (!more) { ret = GOMILP_ERR_UNSUPPORTED; break; }
+            if (!speculate) { int rc1 = enqueue_chunk(cur ^ 1, pred); if (rc1 != GOMILP_OK) return rc1; pred += blocks_per_chunk * K; }
             cur ^= 1;
             continue;
         }
@@ -435,11 +439,12 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         if (rc == GOMILP_ERR_DEVICE) return rc;
         if (rc != GOMILP_OK) { st->wrapped_status = rc; return GOMILP_ERR_PHASE1_WRAPPED; }  // :557-559
         HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipMemcpyAsync(w.h_idx + m, w.nonbasic, (size_t)nn * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));  // m + nn <= n + 1
         HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
         int added = -1;
         for (int i = 0; i < m; i++) { basic[i] = w.h_idx[i]; xb[i] = w.h_vec[i]; if (basic[i] == n) added = i; }
-        HIP_TRY(hipMemcpy(nonbasic.data(), w.nonbasic, (size_t)nn * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int jp = 0; jp < nn; jp++) nonbasic[jp] = w.h_idx[m + jp];
         double xart = added >= 0 ? xb[added] : 0.0;
         if (added >= 0 && fabs(xart) > 1e-13 && fabs(xart) < 1e-11) {
             std::vector<double> xe;

@@ -86,6 +86,11 @@ struct Engine::Work {
     double *h_W = nullptr;  // pinned, cap_m * cap_ld
     double *h_vec = nullptr;  // pinned, max(cap_ld, cap_cols)
     int32_t *h_idx = nullptr; // pinned, max(cap_m, cap_cols)
+    int32_t *idx_stage[2] = {nullptr, nullptr};   // pinned staging of upload_index_lists (two slots)
+    hipEvent_t idx_stage_ev[2] = {nullptr, nullptr};
+    bool idx_stage_used[2] = {false, false};
+    size_t idx_stage_cap = 0;
+    int idx_stage_next = 0;
     char *child_stage = nullptr;  // pinned staging block of upload_child
     size_t child_stage_cap = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
