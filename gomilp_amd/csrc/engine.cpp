@@ -245,12 +245,11 @@ int64_t Engine::upload_child(int64_t root, int K, const int32_t *var, const doub
         P->nnz[n0 + k] = 1; P->lastrow[n0 + k] = m0 + k; P->allone[n0 + k] = 1;
     }
     P->verify_status = R.verify_status;  // bnb rows and their slack columns are never empty
+    // the host copy of [[A0, 0], [G#, I]] is only needed when a solve starts from a non-slack basis: built on demand
     P->hA.clear();
-    if (!R.hA.empty() && (size_t)m * n <= ((size_t)1 << 22)) {  // [[A0, 0], [G#, I]]
-        P->hA.assign((size_t)m * n, 0.0);
-        for (int i = 0; i < m0; i++) memcpy(&P->hA[(size_t)i * n], &R.hA[(size_t)i * n0], sizeof(double) * (size_t)n0);
-        for (int k = 0; k < K; k++) { P->hA[(size_t)(m0 + k) * n + var[k]] = sign[k]; P->hA[(size_t)(m0 + k) * n + n0 + k] = 1.0; }
-    }
+    P->root = root;
+    P->kvar.assign(var, var + K);
+    P->ksign.assign(sign, sign + K);
     P->seconds_upload = now_s() - t0;
     for (size_t i = 0; i < problems_.size(); i++)
         if (!problems_[i]) { problems_[i] = std::move(P); return (int64_t)i; }
@@ -300,6 +299,20 @@ int Engine::refresh_xb_y(const Problem &P, const double *cost) {
     launch_y_from_binv(w.binv[cur_], P.ld, P.m, cost, w.basic, w.yscratch, w.yb[ycur_], stream_);
     launches_ += 3;
     return GOMILP_OK;
+}
+
+// host copy of A for the general-basis path; children derive it from their root (subproblem.go:81-139)
+bool Engine::ensure_host_A(const Problem &P) {
+    if (!P.hA.empty()) return true;
+    if (!P.is_child || P.root < 0 || (size_t)P.root >= problems_.size() || !problems_[P.root]) return false;
+    const Problem &R = *problems_[P.root];
+    if (!ensure_host_A(R)) return false;
+    const int m = P.m, n = P.n, m0 = R.m, n0 = R.n, K = (int)P.kvar.size();
+    if ((size_t)m * n > ((size_t)1 << 22)) return false;
+    P.hA.assign((size_t)m * n, 0.0);
+    for (int i = 0; i < m0; i++) memcpy(&P.hA[(size_t)i * n], &R.hA[(size_t)i * n0], sizeof(double) * (size_t)n0);
+    for (int k = 0; k < K; k++) { P.hA[(size_t)(m0 + k) * n + P.kvar[k]] = P.ksign[k]; P.hA[(size_t)(m0 + k) * n + n0 + k] = 1.0; }
+    return true;
 }
 
 int Engine::upload_index_lists(const std::vector<int32_t> &basic, const std::vector<int32_t> &nonbasic) {
@@ -855,7 +868,7 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
         for (int pos = 0; pos < m; pos++) { xb[pos] = P.hb[rho[pos]]; if (xb[pos] < -1e-13) feasible = false; }
     } else {
         // general case (engine_general.cpp): host search over a kept copy of A, small problems on the tableau pipelines
-        if (P.hA.empty() || !use_tab || m > 512) return finish(GOMILP_ERR_UNSUPPORTED);
+        if (!use_tab || m > 512 || !ensure_host_A(P)) return finish(GOMILP_ERR_UNSUPPORTED);
         if (!initial_basic) {
             rc = general_find_linearly_independent(P.hA, m, n, basic);
             if (rc != GOMILP_OK) return finish(rc);  // ErrSingular, simplex.go:495-497

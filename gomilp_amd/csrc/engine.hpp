@@ -23,7 +23,8 @@ struct Problem {
     double *dc1 = nullptr;    // n+1 : Phase-I cost e_n
     double *db = nullptr;     // ld  : b, zero padded
     std::vector<double> hb, hc;
-    std::vector<double> hA;   // host copy of A (row-major m x n), kept for small problems: general initial basis (S7)
+    mutable std::vector<double> hA;   // host copy of A (row-major m x n), kept for small problems: general initial basis (S7);
+                                      // a child builds it from its root only when a solve needs it (ensure_host_A)
     std::vector<int32_t> nnz, lastrow, allone;  // per column of A
     int verify_status = GOMILP_OK;              // verifyInputs, simplex.go:385-439
     double seconds_upload = 0;
@@ -34,6 +35,9 @@ struct Problem {
     int32_t *dvar = nullptr;                    // child: branched variables / signs on the device
     double *dsign = nullptr;
     int cap_k = 0;
+    int64_t root = -1;                          // child: the problem it was assembled from, its branching rows
+    std::vector<int32_t> kvar;
+    std::vector<double> ksign;
 };
 
 class Engine {
@@ -73,6 +77,7 @@ class Engine {
     int host_bland(const Problem &P, LPArgs &a, gomilp_lp_stats *st);
     int refresh_xb_y(const Problem &P, const double *cost);
     int final_solve(const Problem &P, int ncols_rows, std::vector<double> &xb_exact, bool *singular);
+    bool ensure_host_A(const Problem &P);
     int upload_index_lists(const std::vector<int32_t> &basic, const std::vector<int32_t> &nonbasic);
     void sync_state_to_device();
 
