@@ -299,6 +299,22 @@ def main() -> int:
                 "sample": "first %d Phase-II pivots of the same %dx%d LP from the slack basis (reference algorithm: "
                           "3 fresh LU + cond estimate per pivot, gonum order); unit-column initial-basis fast path; "
                           "%.1f s wall" % (ro.pivots_phase2, m, n, tcb)}
+            # a size where both engines finish the whole solve: the truncated sample above is not an artefact
+            c256, A256, b256 = synth.dense_lp_standard_form(256, 7)
+            O.set_threads(1)   # 256 OpenMP threads on 256x256 panels only add fork/join time
+            t1 = time.perf_counter()
+            r256 = O.simplex(c256, A256, b256, 0.0, None, fast_initial_basis=True)
+            t_cpu = time.perf_counter() - t1
+            p256 = ctx.upload(c256, A256, b256)
+            p256.solve(0.0)
+            t1 = time.perf_counter()
+            g256 = p256.solve(0.0)
+            t_gpu = time.perf_counter() - t1
+            p256.free()
+            npv = r256.pivots_phase1 + r256.pivots_phase2
+            out["cpu_baseline"]["full_solve_256x512"] = {
+                "pivots": int(npv), "cpu_cores": 1, "cpu_seconds": t_cpu, "cpu_pivots_per_s": npv / t_cpu, "gpu_seconds": t_gpu,
+                "gpu_pivots_per_s": npv / t_gpu, "same_x_bits": bool(g256.status == 0 and r256.x is not None and np.array_equal(g256.x, r256.x))}
         if frontier_out is not None:
             if not args.no_cpu_baseline and args.frontier_cpu_children > 0:
                 from concurrent.futures import ThreadPoolExecutor
