@@ -119,21 +119,33 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
     int kcur = k0, s = 0, k1 = m, ndrop = 0;
 #pragma unroll 1
     for (;;) {
-        if (tid == 0) {
+        if (w == 0) {
             // run of bookkeeping steps [kcur, limit): Idamax finds the 1 in row ur, dlaswp exchanges logical
-            // positions k and lpos[ur]; nothing else happens (the step's multipliers are exactly 0)
+            // positions k and lpos[ur]; nothing else happens (the step's multipliers are exactly 0).  Wave 0 classifies
+            // 64 columns at a time (a bookkeeping step only retires its own unit row, so the test of one column does
+            // not depend on the steps before it); lane 0 then replays the interchanges, which do depend on each other,
+            // with the unit rows handed over by v_readlane instead of dependent LDS reads.
             const int limit = (s < ncols) ? s_cols[lsel][s] : m;
             int k = kcur;
-            while (k < limit) {
-                const idx_t ur = s_unit[k];
-                if (ur == NONE || !s_active[ur]) break;
-                const idx_t jp = s_lpos[ur], Q = s_rowat[k];
-                s_lpos[Q] = jp; s_rowat[jp] = Q;
-                s_lpos[ur] = (idx_t)k; s_rowat[k] = ur;
-                s_active[ur] = 0;
-                k++;
+            for (;;) {
+                const int kk = k + lane;
+                const idx_t ur = kk < limit ? s_unit[kk] : NONE;
+                const bool triv = ur != NONE && s_active[ur];
+                const unsigned long long nt = __ballot(!triv);
+                const int cnt = nt ? (int)__builtin_ctzll(nt) : 64;
+                for (int j = 0; j < cnt; j++) {
+                    const int urj = __builtin_amdgcn_readlane((int)ur, j);
+                    if (lane == 0) {
+                        const idx_t jp = s_lpos[urj], Q = s_rowat[k + j];
+                        s_lpos[Q] = jp; s_rowat[jp] = Q;
+                        s_lpos[urj] = (idx_t)(k + j); s_rowat[k + j] = (idx_t)urj;
+                        s_active[urj] = 0;
+                    }
+                }
+                k += cnt;
+                if (cnt < 64) break;   // the limit or a step that needs arithmetic
             }
-            s_stop = k; s_limit = limit;
+            if (lane == 0) { s_stop = k; s_limit = limit; }
         }
         __syncthreads();
         const int kstop = s_stop, limit = s_limit;
@@ -183,13 +195,10 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
         auto publish = [&](CPanelRow<NB> &row, int) {
             if (!row.act || row.lp != jp) return;
             const int P = row.R;
-            double *dst = a.W + P;
 #pragma unroll
-            for (int cc = 0; cc < NB; cc++) {
-                pr[cc] = row.v[cc];
-                if (s + cc < ncols) dst[(size_t)cols[s + cc] * ldw] = row.v[cc];
-            }
+            for (int cc = 0; cc < NB; cc++) pr[cc] = row.v[cc];
             row.act = false;
+            row.lp = -2 - P;   // marks the owner: its U entries go to W after the barrier, off everybody's critical path
             s_active[P] = 0;
             a.rowstep[P] = k; pivrow[k] = P;
             if (a.dense_flag) a.dense_flag[k] = 1;
@@ -203,6 +212,15 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
         };
         GOMILP_FOR_ROWS(publish);
         __syncthreads();
+        auto publish_w = [&](CPanelRow<NB> &row, int) {
+            if (row.act || row.lp != -2 - row.R) return;
+            row.lp = 0;
+            double *dst = a.W + row.R;
+#pragma unroll
+            for (int cc = 0; cc < NB; cc++)
+                if (s + cc < ncols) dst[(size_t)cols[s + cc] * ldw] = row.v[cc];
+        };
+        GOMILP_FOR_ROWS(publish_w);
         const double piv = pr[0];
         const bool singular = (piv == 0);  // dgetf2.go:48-49: no scaling, the rank-1 update is a no-op
         if (singular && tid == 0) a.st->lu_singular = 1;
@@ -235,15 +253,16 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
             const double nl = -l;
             lcol[row.R] = singular ? 0.0 : nl;
             const bool skip = singular;   // Dger (dgetf2.go:60-66) does not skip zero multipliers
+            // only the columns still listed behind the current one carry data (uniform tests: scalar branches)
             if (!doins) {   // plain shift (uniform branch)
 #pragma unroll
-                for (int cc = 1; cc < NB; cc++) row.v[cc - 1] = skip ? row.v[cc] : __dadd_rn(__dmul_rn(nl, pr[cc]), row.v[cc]);
+                for (int cc = 1; cc < NB; cc++) row.v[cc - 1] = (skip || cc > rest) ? row.v[cc] : __dadd_rn(__dmul_rn(nl, pr[cc]), row.v[cc]);
                 row.v[NB - 1] = 0.0;
                 return;
             }
             typename CPanelRow<NB>::vec old = row.v;   // old[c], c >= 1: column c after this step's update
 #pragma unroll
-            for (int cc = 1; cc < NB; cc++) old[cc] = skip ? row.v[cc] : __dadd_rn(__dmul_rn(nl, pr[cc]), row.v[cc]);
+            for (int cc = 1; cc < NB; cc++) old[cc] = (skip || cc > rest) ? row.v[cc] : __dadd_rn(__dmul_rn(nl, pr[cc]), row.v[cc]);
             // e_P column: 0 + (-l)*1 for the active rows
             const double vnew = skip ? 0.0 : __dadd_rn(__dmul_rn(nl, 1.0), 0.0);
 #pragma unroll
