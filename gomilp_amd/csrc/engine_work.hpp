@@ -123,6 +123,16 @@ struct Engine::Work {
         for (auto &e : ev) { if (e) hipEventDestroy(e); e = nullptr; }
         for (auto &e : sample_ev) hipEventDestroy(e);
         sample_ev.clear();
+        for (int t = 0; t < 2; t++) {
+            if (pipe_state[t]) hipHostFree(pipe_state[t]); pipe_state[t] = nullptr;
+            if (pipe_ev[t]) hipEventDestroy(pipe_ev[t]); pipe_ev[t] = nullptr;
+            if (idx_stage[t]) hipHostFree(idx_stage[t]); idx_stage[t] = nullptr;
+            if (idx_stage_ev[t]) hipEventDestroy(idx_stage_ev[t]); idx_stage_ev[t] = nullptr;
+            idx_stage_used[t] = false;
+        }
+        idx_stage_cap = 0;
+        if (luctl) hipFree(luctl); luctl = nullptr;
+        if (luctl_host) hipHostFree(luctl_host); luctl_host = nullptr;
     }
 };
 
