@@ -192,7 +192,7 @@ def main() -> int:
             dist.all_reduce(tft, op=dist.ReduceOp.MAX)
             dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         frontier_out = {
-            "workload": "C5: %d children of the %dx%d root (seed %d), %d bnb rows each, sharded child i -> rank i %% %d"
+            "workload": "C5: %d children of the %dx%d root (seed %d), %d bnb rows each, dealt round-robin over a fixed shuffle to %d rank(s)"
                         % (len(children), m5, 2 * m5, seed5, args.frontier_vars, world),
             "relaxations_per_s": len(children) / float(tft[0]), "wave_seconds": float(tft[0]), "n_gpus": world,
             "workers_per_gpu": args.workers, "pivots": int(agg[0]), "phase1_runs": int(agg[1]), "bland_steps": int(agg[2]),
@@ -288,7 +288,7 @@ def main() -> int:
             "breakdown": {"pivot_loop_s": loop_s, "final_solve_s": final_s, "final_device_s": final_dev, "final_host_s": final_host, "wall_s": dt, "drift_xb": last.stats["drift_xb"],
                           "z": last.z},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
             from oracle import oracle as O   # the checker, timed as the CPU baseline (never the product path)
             cores = max(1, min(args.cpu_threads, os.cpu_count() or 1))
             O.set_threads(cores)
@@ -318,7 +318,7 @@ def main() -> int:
                 "pivots": int(npv), "cpu_cores": 1, "cpu_seconds": t_cpu, "cpu_pivots_per_s": npv / t_cpu, "gpu_seconds": t_gpu,
                 "gpu_pivots_per_s": npv / t_gpu, "same_x_bits": bool(g256.status == 0 and r256.x is not None and np.array_equal(g256.x, r256.x))}
         if frontier_out is not None:
-            if not args.no_cpu_baseline and args.frontier_cpu_children > 0:
+            if not args.no_cpu_baseline and world == 1 and args.frontier_cpu_children > 0:
                 from concurrent.futures import ThreadPoolExecutor
                 from oracle import oracle as O
                 O.set_threads(1)
