@@ -66,8 +66,10 @@ int Engine::ensure_work(int m, int ncols) {
     }
     const int ld = (m + 1) & ~1;
     if (m <= w.cap_m && ncols <= w.cap_cols) return GOMILP_OK;
-    const int nm = std::max(m, w.cap_m), nc = std::max(ncols, w.cap_cols);
-    const int nld = std::max(ld, w.cap_ld);
+    // head-room: B&B children grow by one row and one column per level; without it every level would release and
+    // re-allocate the whole work set (hipFree synchronises the device, pinned allocations are slow)
+    const int nm = std::max(m + 32 + m / 16, w.cap_m), nc = std::max(ncols + 64 + ncols / 16, w.cap_cols);
+    const int nld = std::max((nm + 1) & ~1, w.cap_ld);
     w.release();
     for (auto &p : w.binv) HIP_TRY(dmalloc(&p, (size_t)nm * nld));
     HIP_TRY(dmalloc(&w.W, (size_t)nm * nld));
@@ -83,6 +85,17 @@ int Engine::ensure_work(int m, int ncols) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_W), (size_t)nm * nld * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_vec), (size_t)std::max(nld, nc) * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_idx), (size_t)std::max(nm, nc) * sizeof(int32_t), hipHostMallocDefault));
+    {
+        const size_t cap = std::max<size_t>(4096, sizeof(double) * ((size_t)std::max(nld, nc) + 64));
+        for (int t = 0; t < Work::kStageSlots; t++) {
+            if (w.stage_cap[t] >= cap) continue;
+            if (w.stage_inflight) { hipStreamSynchronize(stream_); w.stage_inflight = 0; }
+            if (w.stage_buf[t]) hipHostFree(w.stage_buf[t]);
+            w.stage_buf[t] = nullptr; w.stage_cap[t] = 0;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.stage_buf[t]), cap, hipHostMallocDefault));
+            w.stage_cap[t] = cap;
+        }
+    }
     w.cap_m = nm; w.cap_ld = nld; w.cap_cols = nc;
     return GOMILP_OK;
 }
@@ -135,7 +148,7 @@ int64_t Engine::upload(const double *c, const double *A, int64_t lda, const doub
     launch_col_stats(P->dAt, ld, m, n, dstats, dstats + n, dstats + 2 * n, dstats + 3 * n, stream_);
     std::vector<int32_t> hs((size_t)3 * n + m);
     UP_TRY(hipMemcpyAsync(hs.data(), dstats, hs.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    UP_TRY(hipStreamSynchronize(stream_));
+    UP_TRY(sync_stream());
     UP_TRY(hipGetLastError());
 #undef UP_TRY
     hipFree(dA); dA = nullptr;
@@ -233,7 +246,7 @@ int64_t Engine::upload_child(int64_t root, int K, const int32_t *var, const doub
     UP_TRY(hipMemcpyAsync(P->dc, sc, ((size_t)n + 1) * sizeof(double), hipMemcpyHostToDevice, stream_));
     UP_TRY(hipMemcpyAsync(P->dc1, sc1, ((size_t)n + 1) * sizeof(double), hipMemcpyHostToDevice, stream_));
     launch_child_assemble(R.dAt, R.ld, m0, n0, P->dAt, ld, K, P->dvar, P->dsign, stream_);
-    UP_TRY(hipStreamSynchronize(stream_));  // the staging block is reused by the next child
+    UP_TRY(sync_stream());  // the staging block is reused by the next child
     UP_TRY(hipGetLastError());
 #undef UP_TRY
     // column statistics follow from the root's: a branched column gains one entry per constraint on it
@@ -290,7 +303,8 @@ LPArgs Engine::make_args(const Problem &P, int phase, double tol, int nn, const 
 }
 
 void Engine::sync_state_to_device() {
-    hipMemcpyAsync(w_->st, w_->st_host, sizeof(DevState), hipMemcpyHostToDevice, stream_);
+    // a snapshot through the staging ring: the host copy may be rewritten before the stream reaches this upload
+    stage_upload(w_->st, w_->st_host, sizeof(DevState));
 }
 
 int Engine::refresh_xb_y(const Problem &P, const double *cost) {
@@ -315,35 +329,40 @@ bool Engine::ensure_host_A(const Problem &P) {
     return true;
 }
 
+// Small host -> device upload from pageable / short-lived memory without a stream sync of its own: the copy is enqueued
+// from a slot of a pinned ring.  A slot may be rewritten only after the stream has been fully synchronised since its
+// last use: sync_stream() — the engine's only way to wait for the stream — resets the count, and the ring forces a
+// sync itself when it would wrap around without one (no per-upload event: with many worker streams the queue
+// packets, not the host, are the bottleneck).
+hipError_t Engine::sync_stream() {
+    const hipError_t e = hipStreamSynchronize(stream_);
+    w_->stage_inflight = 0;
+    return e;
+}
+
+int Engine::stage_upload(void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return GOMILP_OK;
+    Work &w = *w_;
+    if (w.stage_inflight >= Work::kStageSlots) HIP_TRY(sync_stream());
+    const int slot = w.stage_next;
+    if (w.stage_cap[slot] < bytes) {
+        // slots are sized once per work-buffer generation (ensure_work); an oversized request takes the plain path
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream_));
+        HIP_TRY(sync_stream());
+        return GOMILP_OK;
+    }
+    w.stage_next = (slot + 1) % Work::kStageSlots;
+    w.stage_inflight++;
+    memcpy(w.stage_buf[slot], src, bytes);
+    HIP_TRY(hipMemcpyAsync(dst, w.stage_buf[slot], bytes, hipMemcpyHostToDevice, stream_));
+    return GOMILP_OK;
+}
+
 int Engine::upload_index_lists(const std::vector<int32_t> &basic, const std::vector<int32_t> &nonbasic) {
     Work &w = *w_;
-    // through a pinned staging block (two slots, each guarded by an event) instead of a stream sync per call: the
-    // callers' vectors are pageable and may die right after the call
-    const size_t need = basic.size() + nonbasic.size();
-    if (w.idx_stage_cap < need) {
-        for (int t = 0; t < 2; t++) {
-            if (w.idx_stage[t]) { if (w.idx_stage_ev[t]) hipEventSynchronize(w.idx_stage_ev[t]); hipHostFree(w.idx_stage[t]); w.idx_stage[t] = nullptr; }
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.idx_stage[t]), need * 2 * sizeof(int32_t), hipHostMallocDefault));
-            if (!w.idx_stage_ev[t]) HIP_TRY(hipEventCreateWithFlags(&w.idx_stage_ev[t], hipEventDisableTiming));
-        }
-        w.idx_stage_cap = need * 2;
-        w.idx_stage_used[0] = w.idx_stage_used[1] = false;
-    }
-    const int slot = w.idx_stage_next;
-    w.idx_stage_next ^= 1;
-    if (w.idx_stage_used[slot]) HIP_TRY(hipEventSynchronize(w.idx_stage_ev[slot]));
-    int32_t *stg = w.idx_stage[slot];
-    if (!basic.empty()) {
-        memcpy(stg, basic.data(), basic.size() * sizeof(int32_t));
-        HIP_TRY(hipMemcpyAsync(w.basic, stg, basic.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-    }
-    if (!nonbasic.empty()) {
-        memcpy(stg + basic.size(), nonbasic.data(), nonbasic.size() * sizeof(int32_t));
-        HIP_TRY(hipMemcpyAsync(w.nonbasic, stg + basic.size(), nonbasic.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-    }
-    HIP_TRY(hipEventRecord(w.idx_stage_ev[slot], stream_));
-    w.idx_stage_used[slot] = true;
-    return GOMILP_OK;
+    int rc = stage_upload(w.basic, basic.data(), basic.size() * sizeof(int32_t));
+    if (rc != GOMILP_OK) return rc;
+    return stage_upload(w.nonbasic, nonbasic.data(), nonbasic.size() * sizeof(int32_t));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -356,7 +375,7 @@ int Engine::host_bland(const Problem &P, LPArgs &a, gomilp_lp_stats *st) {
     const int m = P.m, nn = a.nn;
     std::vector<double> r(nn), move(m);
     HIP_TRY(hipMemcpyAsync(w.h_vec, w.rvec, (size_t)nn * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(sync_stream());
     for (int j = 0; j < nn; j++) { r[j] = w.h_vec[j]; if (fabs(r[j]) < 1e-13) r[j] = 0; }  // rRoundTol, :252-256
     for (int i = 0; i < nn; i++) {
         if (r[i] > -1e-14) continue;  // blandNegTol, :352
@@ -365,7 +384,7 @@ int Engine::host_bland(const Problem &P, LPArgs &a, gomilp_lp_stats *st) {
         launch_ftran(a, 0, i, -1, stream_);
         launches_++;
         HIP_TRY(hipMemcpyAsync(w.h_vec, w.move, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(sync_stream());
         for (int k = 0; k < m; k++) move[k] = w.h_vec[k];
         int64_t replace = min_idx(move.data(), m);
         if (move[replace] == std::numeric_limits<double>::infinity()) return GOMILP_ERR_UNBOUNDED;  // computeMove :328
@@ -444,7 +463,7 @@ int Engine::run_loop(const Problem &P, int phase, double tol, int nn, const doub
             launches_ += 3;
         }
         HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(sync_stream());
         HIP_TRY(hipGetLastError());
         const int64_t executed = hs.pivots - before;
         cur_ = (int)((cur_ + executed) & 1);
@@ -467,7 +486,7 @@ int Engine::run_loop(const Problem &P, int phase, double tol, int nn, const doub
             if (rc != GOMILP_OK) { ret = rc; break; }
             // resume: the update kernel of the Bland step has been enqueued; read the state back after it
             HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
-            HIP_TRY(hipStreamSynchronize(stream_));
+            HIP_TRY(sync_stream());
             hs.done = 0; hs.status = ST_RUNNING;
             sync_state_to_device();
             continue;
@@ -531,7 +550,7 @@ int Engine::run_loop_fused(const Problem &P, int phase, double tol, int nn, cons
             launches_ += 2;
         }
         HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(sync_stream());
         HIP_TRY(hipGetLastError());
         const int64_t executed = hs.pivots - before;
         since_refresh += executed;
@@ -559,7 +578,7 @@ int Engine::run_loop_fused(const Problem &P, int phase, double tol, int nn, cons
             int rc = host_bland(P, a, st);
             if (rc != GOMILP_OK) { ret = rc; break; }
             HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
-            HIP_TRY(hipStreamSynchronize(stream_));
+            HIP_TRY(sync_stream());
             hs.done = 0; hs.status = ST_RUNNING;
             sync_state_to_device();
             c0 = cur_; y0 = ycur_; seg_start = hs.pivots; tseg = 0;
@@ -595,7 +614,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     else launch_gather_w(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
     // unit columns of ab (from the column statistics of the upload): the blocked LU skips their elimination steps
     HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(sync_stream());
     {
         std::vector<int32_t> ur(m);
         for (int pos = 0; pos < m; pos++) {
@@ -603,8 +622,8 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
             ur[pos] = (j < P.n && P.nnz[j] == 1 && P.allone[j]) ? P.lastrow[j] : -1;
             if (ur[pos] < 0) nonunit++;
         }
-        HIP_TRY(hipMemcpyAsync(w.unitrow, ur.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        int rcu = stage_upload(w.unitrow, ur.data(), (size_t)m * sizeof(int32_t));
+        if (rcu != GOMILP_OK) return rcu;
     }
     LUArgs a;
     a.W = w.W; a.ldw = ldw; a.m = m; a.lpos = w.lpos; a.rowstep = w.rowstep;
@@ -627,7 +646,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
         for (;;) {
             launches_ += launch_luc_rounds(a, w.rho, batch, stream_);
             HIP_TRY(hipMemcpyAsync(w.luctl_host, w.luctl, sizeof(LUCtl), hipMemcpyDeviceToHost, stream_));
-            HIP_TRY(hipStreamSynchronize(stream_));
+            HIP_TRY(sync_stream());
             if (w.luctl_host->k_next >= m) break;
             batch = std::max(4, (int)(((int64_t)(m - w.luctl_host->k_next) * w.luctl_host->rounds) / std::max(1, w.luctl_host->k_next)) + 2);
             if (batch > 64) batch = 64;
@@ -641,7 +660,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     std::vector<int32_t> dl;
     if (blocked) {
         HIP_TRY(hipMemcpyAsync(w.h_idx, w.denseflag, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(sync_stream());
         for (int k = 0; k < m; k++) if (w.h_idx[k]) dl.push_back(k);
     } else {
         for (int k = 0; k < m; k++) dl.push_back(k);
@@ -656,8 +675,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     }
     const int nd = (int)dl.size();
     lu_dense_ = nd;
-    if (nd) HIP_TRY(hipMemcpyAsync(w.dlist, dl.data(), (size_t)nd * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    { int rcd = stage_upload(w.dlist, dl.data(), (size_t)nd * sizeof(int32_t)); if (rcd != GOMILP_OK) return rcd; }
     double *Wd = w.Wd;
     if (compressed) launch_luc_pack(a, w.dlist, nd, Wd, w.ludiag, stream_);
     else launch_lu_pack(a, w.dlist, nd, Wd, w.ludiag, stream_);
@@ -666,7 +684,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     HIP_TRY(hipMemcpyAsync(w.h_vec, w.ludiag, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(w.h_idx, w.lpos, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(sync_stream());
     HIP_TRY(hipGetLastError());
     const double tf1 = now_s();
     fs_device_ += tf1 - tf0;
@@ -887,15 +905,14 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     cur_ = 0;
     if (unit_basis && !use_tab) {
         HIP_TRY(hipMemsetAsync(w.binv[0], 0, (size_t)m * P.ld * sizeof(double), stream_));
-        HIP_TRY(hipMemcpyAsync(w.rho, rho.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        if ((rc = stage_upload(w.rho, rho.data(), (size_t)m * sizeof(int32_t))) != GOMILP_OK) return finish(rc);
         launch_set_binv_perm(w.binv[0], P.ld, m, w.rho, stream_);
     }
     HIP_TRY(hipMemsetAsync(w.xb, 0, (size_t)P.ld * sizeof(double), stream_));
     ycur_ = 0;
     HIP_TRY(hipMemsetAsync(w.yb[0], 0, (size_t)P.ld * sizeof(double), stream_));
     HIP_TRY(hipMemsetAsync(w.yb[1], 0, (size_t)P.ld * sizeof(double), stream_));
-    HIP_TRY(hipMemcpyAsync(w.xb, xb.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    if ((rc = stage_upload(w.xb, xb.data(), (size_t)m * sizeof(double))) != GOMILP_OK) return finish(rc);
 
     // pipeline choice: the explicit tableau moves 16*m*(n-m) bytes per pivot in one launch, the revised form
     // 8*[m(n-m) + 2m^2] in two: the tableau wins while n - m < 2m
@@ -907,7 +924,7 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
         if (w.cap_T < (size_t)(m + 3) * ldt || w.cap_ldt < ldt) {   // + 3 rows: the tiled layout pads m to a multiple of 4
             for (double **pp : {&w.T[0], &w.T[1], &w.R[0], &w.R[1], &w.tscratch, &w.btU, &w.btV}) { if (*pp) hipFree(*pp); *pp = nullptr; }
             if (w.srcpos) hipFree(w.srcpos); w.srcpos = nullptr;
-            const size_t cap = std::max(w.cap_T, (size_t)(m + 3) * ldt);
+            const size_t cap = std::max(w.cap_T, (size_t)(m + 3 + 32 + m / 16) * ldt);   // head-room for deeper children
             const int cl = std::max(w.cap_ldt, ldt);
             HIP_TRY(dmalloc(&w.T[0], cap)); HIP_TRY(dmalloc(&w.T[1], cap));
             HIP_TRY(dmalloc(&w.R[0], (size_t)cl)); HIP_TRY(dmalloc(&w.R[1], (size_t)cl));
@@ -940,7 +957,7 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
         for (int k = 0; k < m; k++) if (art[k] != 0) { art_zero = false; break; }
         if (art_zero) { st->wrapped_status = GOMILP_ERR_ZERO_COLUMN; return finish(GOMILP_ERR_PHASE1_WRAPPED); }  // verifyInputs of the recursive call
         HIP_TRY(hipMemcpyAsync(P.dAt + (size_t)n * P.ld, art.data(), (size_t)P.ld * sizeof(double), hipMemcpyHostToDevice, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(sync_stream());
         // basis := slack basis with position minidx replaced by the artificial: one forced pivot builds its inverse
         w.st_host->done = 0; w.st_host->status = ST_RUNNING; w.st_host->pivots = 0; w.st_host->max_pivots = 0; w.st_host->rq = 0;
         sync_state_to_device();
@@ -956,14 +973,14 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
         if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return finish(rc);
         refresh_xb_y(P, P.dc1);  // xb = ab^-1 b (initializeFromBasic of the recursive call), y = ab^-T cb
         HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(sync_stream());
         for (int i = 0; i < m; i++) if (w.h_vec[i] < -1e-13) return finish(GOMILP_ERR_PANIC);  // simplex.go:155-158
         rc = run_loop(P, 1, 1e-10, (int)nonbasic.size(), P.dc1, st);
         if (rc == GOMILP_ERR_DEVICE) return finish(rc);
         if (rc != GOMILP_OK) { st->wrapped_status = rc; return finish(GOMILP_ERR_PHASE1_WRAPPED); }  // :557-559
         HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(sync_stream());
         int added = -1;
         for (int i = 0; i < m; i++) { basic[i] = w.h_idx[i]; xb[i] = w.h_vec[i]; if (basic[i] == n) added = i; }
         double xart = added >= 0 ? xb[added] : 0.0;
@@ -987,7 +1004,7 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
                 launch_ftran(a, 0, -1, j, stream_);
                 launches_++;
                 HIP_TRY(hipMemcpyAsync(w.h_vec, w.dvec, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-                HIP_TRY(hipStreamSynchronize(stream_));
+                HIP_TRY(sync_stream());
                 double dmax = 0;
                 for (int i = 0; i < m; i++) dmax = std::max(dmax, fabs(w.h_vec[i]));
                 const double dpv = w.h_vec[added];
@@ -1026,7 +1043,7 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     // ---- epilogue (simplex.go:296-301): x_B from a fresh gonum-order solve on the final basis ----
     HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(sync_stream());
     for (int i = 0; i < m; i++) { basic[i] = w.h_idx[i]; xb[i] = w.h_vec[i]; }
     const double t1 = now_s();
     if ((rc = final_solve(P, n, xb_exact, &singular)) != GOMILP_OK) return finish(rc);
@@ -1047,7 +1064,7 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     if (basis_out) for (int i = 0; i < m; i++) basis_out[i] = basic[i];
     if (trace_on_) {
         HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(sync_stream());
         last_trace_total_ = w.st_host->trace_len;
         const int64_t cnt = std::min<int64_t>(last_trace_total_, w.trace_cap);
         std::vector<DevPivot> tmp((size_t)cnt);

@@ -78,6 +78,8 @@ class Engine {
     int refresh_xb_y(const Problem &P, const double *cost);
     int final_solve(const Problem &P, int ncols_rows, std::vector<double> &xb_exact, bool *singular);
     bool ensure_host_A(const Problem &P);
+    int stage_upload(void *dst, const void *src, size_t bytes);
+    hipError_t sync_stream();
     int upload_index_lists(const std::vector<int32_t> &basic, const std::vector<int32_t> &nonbasic);
     void sync_state_to_device();
 

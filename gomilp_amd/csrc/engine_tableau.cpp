@@ -44,7 +44,7 @@ int Engine::tab_forced_pivot(const Problem &P, int phase, double tol, int nn, in
     HIP_TRY(hipMemcpyAsync(w.pb_ratio, &part.b, sizeof(part.b), hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipMemcpyAsync(w.pd_ratio, &part.d, sizeof(part.d), hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipMemcpyAsync(w.px_ratio, &part.x, sizeof(part.x), hipMemcpyHostToDevice, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));  // `part` lives on this stack frame
+    HIP_TRY(sync_stream());  // `part` lives on this stack frame
     TabArgs a = make_tab_args(P, phase, tol, nn);
     grid_ratio_ = launch_tableau_pivot(a, flags | 1 | 2, 1, t, stream_, nullptr, nullptr);
     launches_++;
@@ -61,12 +61,12 @@ int Engine::host_bland_tab(const Problem &P, int phase, double tol, int nn, gomi
     std::vector<double> r(nn), move(m), xb(m), dv(m);
     std::vector<int32_t> bas(m);
     HIP_TRY(hipMemcpyAsync(w.h_vec, w.R[rcur_], (size_t)nn * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(sync_stream());
     std::vector<double> rraw(w.h_vec, w.h_vec + nn);
     for (int j = 0; j < nn; j++) { r[j] = rraw[j]; if (fabs(r[j]) < 1e-13) r[j] = 0; }  // rRoundTol, :252-256
     HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(sync_stream());
     for (int i = 0; i < m; i++) { xb[i] = w.h_vec[i]; bas[i] = w.h_idx[i]; }
     for (int i = 0; i < nn; i++) {
         if (r[i] > -1e-14) continue;  // blandNegTol, :352
@@ -74,10 +74,10 @@ int Engine::host_bland_tab(const Problem &P, int phase, double tol, int nn, gomi
         launch_tab_column(w.T[tcur_], ldt_, m, i, w.xb, w.dvec, w.move, stream_);
         launches_++;
         HIP_TRY(hipMemcpyAsync(w.h_vec, w.move, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(sync_stream());
         for (int k = 0; k < m; k++) move[k] = w.h_vec[k];
         HIP_TRY(hipMemcpyAsync(w.h_vec, w.dvec, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(sync_stream());
         for (int k = 0; k < m; k++) dv[k] = w.h_vec[k];
         int64_t replace = min_idx(move.data(), m);
         if (move[replace] == std::numeric_limits<double>::infinity()) return GOMILP_ERR_UNBOUNDED;  // computeMove :328
@@ -138,7 +138,7 @@ int Engine::run_loop_tab(const Problem &P, int phase, double tol, int nn, gomilp
             if (pending) applied++;
         }
         HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(sync_stream());
         HIP_TRY(hipGetLastError());
         const int64_t executed = hs.pivots - before;
         if (st) {
@@ -344,10 +344,8 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         for (int j = 0; j < ncols; j++) if (!inb[j]) nonbasic.push_back(j);
     };
     tcur_ = 0; rcur_ = 0; t_tiled_ = false;
-    if (!binv_host) HIP_TRY(hipMemcpyAsync(w.rho, rho.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-    HIP_TRY(hipMemsetAsync(w.xb, 0, (size_t)P.ld * sizeof(double), stream_));
-    HIP_TRY(hipMemcpyAsync(w.xb, xb.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    if (!binv_host && (rc = stage_upload(w.rho, rho.data(), (size_t)m * sizeof(int32_t))) != GOMILP_OK) return rc;
+    // (x_B itself was uploaded by Engine::solve)
     std::vector<double> art(P.ld, 0.0);  // Phase-I artificial column (simplex.go:533-542)
     auto set_up_T = [&](int nn) -> int {  // T = B^-1 A_N
         ldt_ = tab_ld(nn);
@@ -371,7 +369,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         }
         // same stream as everything else (a null-stream copy is not ordered against the non-blocking stream)
         HIP_TRY(hipMemcpyAsync(w.T[0], Th.data(), Th.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));  // Th is a local
+        HIP_TRY(sync_stream());  // Th is a local
         return GOMILP_OK;
     };
     int nn;
@@ -391,8 +389,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         bool art_zero = true;
         for (int k = 0; k < m; k++) if (art[k] != 0) { art_zero = false; break; }
         if (art_zero) { st->wrapped_status = GOMILP_ERR_ZERO_COLUMN; return GOMILP_ERR_PHASE1_WRAPPED; }
-        HIP_TRY(hipMemcpyAsync(P.dAt + (size_t)n * P.ld, art.data(), (size_t)P.ld * sizeof(double), hipMemcpyHostToDevice, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        if ((rc = stage_upload(P.dAt + (size_t)n * P.ld, art.data(), (size_t)P.ld * sizeof(double))) != GOMILP_OK) return rc;
         // tableau over the n+1-m columns that are nonbasic w.r.t. the slack basis (the artificial is the last one),
         // then one forced pivot brings the artificial into position minidx (the basis of simplex.go:551)
         build_nonbasic(n + 1);
@@ -419,8 +416,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
                 std::vector<int32_t> pos_of(n + 1, -1), srcpos(nn);
                 for (int jp = 0; jp < nn; jp++) pos_of[nonbasic[jp]] = jp;
                 for (int jp = 0; jp < nn; jp++) srcpos[jp] = pos_of[asc[jp]];
-                HIP_TRY(hipMemcpyAsync(w.srcpos, srcpos.data(), (size_t)nn * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-                HIP_TRY(hipStreamSynchronize(stream_));
+                if ((rc = stage_upload(w.srcpos, srcpos.data(), (size_t)nn * sizeof(int32_t))) != GOMILP_OK) return rc;
                 bt_layout(P, false);
                 launch_tab_permute_cols(w.T[tcur_], ldt_, w.T[tcur_ ^ 1], ldt_, m, nn, w.srcpos, stream_);
                 launches_++;
@@ -433,7 +429,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         launch_tab_r(w.T[tcur_], ldt_, m, nn, P.dc1, w.basic, w.nonbasic, w.tscratch, w.R[rcur_], stream_);
         launches_ += 2;
         HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(sync_stream());
         for (int i = 0; i < m; i++) if (w.h_vec[i] < -1e-13) return GOMILP_ERR_PANIC;  // simplex.go:155-158
         rc = use_bt_ ? run_loop_bt(P, 1, 1e-10, nn, st) : run_loop_tab(P, 1, 1e-10, nn, st);
         if (rc == GOMILP_ERR_DEVICE) return rc;
@@ -441,7 +437,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipMemcpyAsync(w.h_idx + m, w.nonbasic, (size_t)nn * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));  // m + nn <= n + 1
         HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(sync_stream());
         int added = -1;
         for (int i = 0; i < m; i++) { basic[i] = w.h_idx[i]; xb[i] = w.h_vec[i]; if (basic[i] == n) added = i; }
         for (int jp = 0; jp < nn; jp++) nonbasic[jp] = w.h_idx[m + jp];
@@ -465,7 +461,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
             launches_++;
             std::vector<double> rowmax((size_t)2 * ldt_);
             HIP_TRY(hipMemcpyAsync(rowmax.data(), w.tscratch, rowmax.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
-            HIP_TRY(hipStreamSynchronize(stream_));
+            HIP_TRY(sync_stream());
             for (auto &cv : cand) {
                 const int jp = cv.second;
                 if (!(fabs(rowmax[jp]) > 1e-9 * std::max(1.0, rowmax[(size_t)ldt_ + jp]))) continue;   // same test as below
@@ -473,7 +469,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
                 launch_tab_column(w.T[tcur_], ldt_, m, jp, w.xb, w.dvec, w.move, stream_);
                 launches_++;
                 HIP_TRY(hipMemcpyAsync(w.h_vec, w.dvec, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-                HIP_TRY(hipStreamSynchronize(stream_));
+                HIP_TRY(sync_stream());
                 double dmax = 0;
                 for (int i = 0; i < m; i++) dmax = std::max(dmax, fabs(w.h_vec[i]));
                 const double dpv = w.h_vec[added];
@@ -495,7 +491,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
             }
             if (!exchanged) return GOMILP_ERR_INFEASIBLE;  // :606
             HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-            HIP_TRY(hipStreamSynchronize(stream_));
+            HIP_TRY(sync_stream());
             for (int i = 0; i < m; i++) xb[i] = w.h_vec[i];
         }
         // ---- Phase I -> Phase II: nonbasic list rebuilt in ascending order (simplex.go:174-184), T columns follow
@@ -505,8 +501,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         std::vector<int32_t> pos_of(n + 1, -1), srcpos(nn2);
         for (int jp = 0; jp < nn; jp++) pos_of[old_nb[jp]] = jp;
         for (int jp = 0; jp < nn2; jp++) srcpos[jp] = pos_of[nonbasic[jp]];
-        HIP_TRY(hipMemcpyAsync(w.srcpos, srcpos.data(), (size_t)nn2 * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        if ((rc = stage_upload(w.srcpos, srcpos.data(), (size_t)nn2 * sizeof(int32_t))) != GOMILP_OK) return rc;
         const int ldt2 = tab_ld(nn2);
         bt_layout(P, false);
         launch_tab_permute_cols(w.T[tcur_], ldt_, w.T[tcur_ ^ 1], ldt2, m, nn2, w.srcpos, stream_);

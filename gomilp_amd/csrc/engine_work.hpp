@@ -86,11 +86,13 @@ struct Engine::Work {
     double *h_W = nullptr;  // pinned, cap_m * cap_ld
     double *h_vec = nullptr;  // pinned, max(cap_ld, cap_cols)
     int32_t *h_idx = nullptr; // pinned, max(cap_m, cap_cols)
-    int32_t *idx_stage[2] = {nullptr, nullptr};   // pinned staging of upload_index_lists (two slots)
-    hipEvent_t idx_stage_ev[2] = {nullptr, nullptr};
-    bool idx_stage_used[2] = {false, false};
-    size_t idx_stage_cap = 0;
-    int idx_stage_next = 0;
+    // pinned staging ring for small host -> device uploads whose source is pageable / short-lived: the copy is enqueued
+    // from a ring slot; a slot is reused only after a full stream sync has happened since (Engine::sync_stream counts)
+    static constexpr int kStageSlots = 32;
+    char *stage_buf[kStageSlots] = {};
+    size_t stage_cap[kStageSlots] = {};
+    int stage_next = 0;
+    int stage_inflight = 0;   // uploads enqueued since the last full stream sync (Engine::sync_stream)
     char *child_stage = nullptr;  // pinned staging block of upload_child
     size_t child_stage_cap = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -126,11 +128,10 @@ struct Engine::Work {
         for (int t = 0; t < 2; t++) {
             if (pipe_state[t]) hipHostFree(pipe_state[t]); pipe_state[t] = nullptr;
             if (pipe_ev[t]) hipEventDestroy(pipe_ev[t]); pipe_ev[t] = nullptr;
-            if (idx_stage[t]) hipHostFree(idx_stage[t]); idx_stage[t] = nullptr;
-            if (idx_stage_ev[t]) hipEventDestroy(idx_stage_ev[t]); idx_stage_ev[t] = nullptr;
-            idx_stage_used[t] = false;
         }
-        idx_stage_cap = 0;
+        for (int t = 0; t < kStageSlots; t++) {
+            if (stage_buf[t]) hipHostFree(stage_buf[t]); stage_buf[t] = nullptr; stage_cap[t] = 0;
+        }
         if (luctl) hipFree(luctl); luctl = nullptr;
         if (luctl_host) hipHostFree(luctl_host); luctl_host = nullptr;
     }
