@@ -84,6 +84,7 @@ int Engine::ensure_work(int m, int ncols) {
     HIP_TRY(dmalloc(&w.luLp, (size_t)32 * nld)); HIP_TRY(dmalloc(&w.luUp, (size_t)32 * nld));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_W), (size_t)nm * nld * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_vec), (size_t)std::max(nld, nc) * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_chk), (size_t)nld * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_idx), (size_t)std::max(nm, nc) * sizeof(int32_t), hipHostMallocDefault));
     {
         const size_t cap = std::max<size_t>(4096, sizeof(double) * ((size_t)std::max(nld, nc) + 64));

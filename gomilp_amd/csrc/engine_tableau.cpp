@@ -230,7 +230,7 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
     DevState &hs = *w.st_host;
     hs.done = 0; hs.status = ST_RUNNING; hs.pivots = 0; hs.kdone = 0; hs.bland_steps = 0; hs.lu_singular = 0;
     sync_state_to_device();
-    HIP_TRY(hipEventRecord(w.ev[0], stream_));
+    const double t_loop0 = now_s();
     int ret = GOMILP_OK;
     // block size: 8 when the block's rank-1 terms fit in registers (bt_kernels.hip), else 16
     const int K = block_k_ > 0 ? (int)block_k_ : (bt_reg_k(P.m, ldt_) > 0 ? 8 : 16);
@@ -316,12 +316,10 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
         ret = GOMILP_ERR_DEVICE;
         break;
     }
-    HIP_TRY(hipEventRecord(w.ev[1], stream_));
-    HIP_TRY(hipEventSynchronize(w.ev[1]));
-    float ms = 0;
-    hipEventElapsedTime(&ms, w.ev[0], w.ev[1]);
+    // host clock from the first launch to the arrival of the final state: no extra event / sync per loop (the loop is
+    // GPU-bound: the host only waits for chunk states)
     if (st) {
-        st->seconds_pivot_loop += ms * 1e-3;
+        st->seconds_pivot_loop += now_s() - t_loop0;
         st->bland_steps += hs.bland_steps;
         if (phase == 1) st->pivots_phase1 += hs.pivots; else st->pivots_phase2 += hs.pivots;
     }
@@ -428,11 +426,13 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         bt_layout(P, false);
         launch_tab_r(w.T[tcur_], ldt_, m, nn, P.dc1, w.basic, w.nonbasic, w.tscratch, w.R[rcur_], stream_);
         launches_ += 2;
-        HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(sync_stream());
-        for (int i = 0; i < m; i++) if (w.h_vec[i] < -1e-13) return GOMILP_ERR_PANIC;  // simplex.go:155-158
+        // the Phase-I starting vertex must be feasible (initializeFromBasic inside the recursive call panics otherwise,
+        // simplex.go:155-158): its x_B is copied out here and inspected after the loop's first host wait — a violation
+        // discards whatever the loop did
+        HIP_TRY(hipMemcpyAsync(w.h_chk, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
         rc = use_bt_ ? run_loop_bt(P, 1, 1e-10, nn, st) : run_loop_tab(P, 1, 1e-10, nn, st);
         if (rc == GOMILP_ERR_DEVICE) return rc;
+        for (int i = 0; i < m; i++) if (w.h_chk[i] < -1e-13) return GOMILP_ERR_PANIC;
         if (rc != GOMILP_OK) { st->wrapped_status = rc; return GOMILP_ERR_PHASE1_WRAPPED; }  // :557-559
         HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipMemcpyAsync(w.h_idx + m, w.nonbasic, (size_t)nn * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));  // m + nn <= n + 1

@@ -85,6 +85,7 @@ struct Engine::Work {
     int64_t trace_cap = 0;
     double *h_W = nullptr;  // pinned, cap_m * cap_ld
     double *h_vec = nullptr;  // pinned, max(cap_ld, cap_cols)
+    double *h_chk = nullptr;  // pinned, cap_ld: x_B of the Phase-I starting vertex (checked after the loop)
     int32_t *h_idx = nullptr; // pinned, max(cap_m, cap_cols)
     // pinned staging ring for small host -> device uploads whose source is pageable / short-lived: the copy is enqueued
     // from a ring slot; a slot is reused only after a full stream sync has happened since (Engine::sync_stream counts)
@@ -106,6 +107,7 @@ struct Engine::Work {
         for (int32_t **p : {&basic, &nonbasic, &lpos, &rowstep, &rho, &unitrow, &denseflag, &dlist}) { if (*p) hipFree(*p); *p = nullptr; }
         if (h_W) hipHostFree(h_W); h_W = nullptr;
         if (h_vec) hipHostFree(h_vec); h_vec = nullptr;
+        if (h_chk) hipHostFree(h_chk); h_chk = nullptr;
         if (h_idx) hipHostFree(h_idx); h_idx = nullptr;
         cap_m = cap_ld = cap_cols = 0;
     }
