@@ -604,7 +604,7 @@ int Engine::run_loop_fused(const Problem &P, int phase, double tol, int nn, cons
 // of Dgetrs (lapack/gonum/dgetrs.go:37-45 -> blas/gonum/level3double.go:75-118) on the host, because
 // the upper solve is one sequential dependency chain of m^2/2 rounded operations.
 // ------------------------------------------------------------------------------------------------
-int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *singular) {
+int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *singular, const int32_t *basic_host) {
     Work &w = *w_;
     const double tf0 = now_s();
     const int m = P.m, ldw = P.ld;
@@ -614,12 +614,15 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     if (compressed) launch_luc_gather(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
     else launch_gather_w(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
     // unit columns of ab (from the column statistics of the upload): the blocked LU skips their elimination steps
-    HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(sync_stream());
+    if (!basic_host) {   // the caller has no host copy of the basis positions yet
+        HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(sync_stream());
+        basic_host = w.h_idx;
+    }
     {
         std::vector<int32_t> ur(m);
         for (int pos = 0; pos < m; pos++) {
-            const int j = w.h_idx[pos];
+            const int j = basic_host[pos];
             ur[pos] = (j < P.n && P.nnz[j] == 1 && P.allone[j]) ? P.lastrow[j] : -1;
             if (ur[pos] < 0) nonunit++;
         }
@@ -647,6 +650,8 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
         for (;;) {
             launches_ += launch_luc_rounds(a, w.rho, batch, stream_);
             HIP_TRY(hipMemcpyAsync(w.luctl_host, w.luctl, sizeof(LUCtl), hipMemcpyDeviceToHost, stream_));
+            // the dense-step flags ride along (final once k_next == m): no separate round trip for them
+            HIP_TRY(hipMemcpyAsync(w.h_idx, w.denseflag, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
             HIP_TRY(sync_stream());
             if (w.luctl_host->k_next >= m) break;
             batch = std::max(4, (int)(((int64_t)(m - w.luctl_host->k_next) * w.luctl_host->rounds) / std::max(1, w.luctl_host->k_next)) + 2);
@@ -660,8 +665,10 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     // columns and the diagonal only: m*(nd+1) doubles cross PCIe instead of m*m.
     std::vector<int32_t> dl;
     if (blocked) {
-        HIP_TRY(hipMemcpyAsync(w.h_idx, w.denseflag, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(sync_stream());
+        if (!compressed) {
+            HIP_TRY(hipMemcpyAsync(w.h_idx, w.denseflag, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(sync_stream());
+        }
         for (int k = 0; k < m; k++) if (w.h_idx[k]) dl.push_back(k);
     } else {
         for (int k = 0; k < m; k++) dl.push_back(k);
@@ -1047,7 +1054,7 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     HIP_TRY(sync_stream());
     for (int i = 0; i < m; i++) { basic[i] = w.h_idx[i]; xb[i] = w.h_vec[i]; }
     const double t1 = now_s();
-    if ((rc = final_solve(P, n, xb_exact, &singular)) != GOMILP_OK) return finish(rc);
+    if ((rc = final_solve(P, n, xb_exact, &singular, basic.data())) != GOMILP_OK) return finish(rc);
     st->seconds_final_solve = now_s() - t1;
     if (singular) {
         xb_exact = xb;  // the reference keeps its previous x_B when Det()==0 (mat/lu.go:301); ours is the updated one

@@ -76,7 +76,7 @@ class Engine {
     void account_samples(gomilp_lp_stats *st, const std::vector<int64_t> &sample_t, int64_t executed, int nk);
     int host_bland(const Problem &P, LPArgs &a, gomilp_lp_stats *st);
     int refresh_xb_y(const Problem &P, const double *cost);
-    int final_solve(const Problem &P, int ncols_rows, std::vector<double> &xb_exact, bool *singular);
+    int final_solve(const Problem &P, int ncols_rows, std::vector<double> &xb_exact, bool *singular, const int32_t *basic_host = nullptr);
     bool ensure_host_A(const Problem &P);
     int stage_upload(void *dst, const void *src, size_t bytes);
     hipError_t sync_stream();
