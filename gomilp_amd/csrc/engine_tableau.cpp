@@ -490,9 +490,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
                 break;
             }
             if (!exchanged) return GOMILP_ERR_INFEASIBLE;  // :606
-            HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-            HIP_TRY(sync_stream());
-            for (int i = 0; i < m; i++) xb[i] = w.h_vec[i];
+            // (the host copy of x_B is refreshed by the epilogue of Engine::solve; nothing reads it before)
         }
         // ---- Phase I -> Phase II: nonbasic list rebuilt in ascending order (simplex.go:174-184), T columns follow
         std::vector<int32_t> old_nb = nonbasic;
