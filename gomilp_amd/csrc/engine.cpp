@@ -685,10 +685,14 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     lu_dense_ = nd;
     { int rcd = stage_upload(w.dlist, dl.data(), (size_t)nd * sizeof(int32_t)); if (rcd != GOMILP_OK) return rcd; }
     double *Wd = w.Wd;
-    if (compressed) launch_luc_pack(a, w.dlist, nd, Wd, w.ludiag, stream_);
+    // large bases: only the nd x nd part that couples the dense positions goes to the host (lu_compressed.hip,
+    // k_luc_pack_dense / k_luc_solve_rows); small ones take one host pass over all rows (one round trip fewer)
+    const bool split = compressed && m >= 1024 && nd > 0;
+    if (split) launch_luc_pack_dense(a, w.dlist, nd, w.rho, Wd, w.ludiag, stream_);
+    else if (compressed) launch_luc_pack(a, w.dlist, nd, Wd, w.ludiag, stream_);
     else launch_lu_pack(a, w.dlist, nd, Wd, w.ludiag, stream_);
     launches_++;
-    if (nd) HIP_TRY(hipMemcpyAsync(w.h_W, Wd, (size_t)m * nd * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    if (nd) HIP_TRY(hipMemcpyAsync(w.h_W, Wd, (size_t)(split ? nd : m) * nd * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(w.h_vec, w.ludiag, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(w.h_idx, w.lpos, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
@@ -705,6 +709,39 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     *singular = w.st_host->lu_singular != 0 || exp(logdet) == 0;
     x.assign(m, 0.0);
     if (*singular) return GOMILP_OK;
+    auto term = [](double bi, double va, double xk) { return va != 0 ? (-va) * xk + bi : bi; };
+    if (split) {
+        // coupled part on the host: row s of h_W is dense position dl[s] restricted to the dense columns
+        std::vector<double> xdl(nd), xdu(nd);
+        for (int s2 = 0; s2 < nd; s2++) {   // Dtrsm(Left, Lower, NoTrans, Unit)
+            const double *row = w.h_W + (size_t)s2 * nd;
+            double bi = P.hb[phys[dl[s2]]];
+            for (int t = 0; t < s2; t++) bi = term(bi, row[t], xdl[t]);
+            xdl[s2] = bi;
+        }
+        for (int s2 = nd - 1; s2 >= 0; s2--) {   // Dtrsm(Left, Upper, NoTrans, NonUnit)
+            const double *row = w.h_W + (size_t)s2 * nd;
+            double bi = xdl[s2];
+            for (int t = s2 + 1; t < nd; t++) bi = term(bi, row[t], xdu[t]);
+            const double tinv = 1 / diag[phys[dl[s2]]];
+            xdu[s2] = bi * tinv;
+        }
+        fs_host_ += now_s() - tf1;
+        const double tf2 = now_s();
+        double *dxl = w.yscratch, *dxu = w.yscratch + P.ld, *dx = w.yscratch + 2 * (size_t)P.ld;   // 64 * ld doubles
+        int rcs = stage_upload(dxl, xdl.data(), (size_t)nd * sizeof(double));
+        if (rcs == GOMILP_OK) rcs = stage_upload(dxu, xdu.data(), (size_t)nd * sizeof(double));
+        if (rcs != GOMILP_OK) return rcs;
+        launch_luc_solve_rows(a, w.dlist, nd, P.db, dxl, dxu, dx, stream_);
+        launches_++;
+        HIP_TRY(hipMemcpyAsync(w.h_vec, dx, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(sync_stream());
+        HIP_TRY(hipGetLastError());
+        for (int i = 0; i < m; i++) x[i] = w.h_vec[i];
+        for (int s2 = 0; s2 < nd; s2++) x[dl[s2]] = xdu[s2];
+        fs_device_ += now_s() - tf2;
+        return GOMILP_OK;
+    }
     // Dlaswp: b in logical row order
     for (int i = 0; i < m; i++) x[i] = P.hb[phys[i]];
     // The two Dtrsm of Dgetrs, per row in gonum's order: ascending k, zero multipliers skipped, b_i = (-a_ik)*b_k + b_i
@@ -718,7 +755,6 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     std::vector<int> nl;   // logical positions that are not dense, ascending
     nl.reserve(m - nd);
     for (int i = 0; i < m; i++) if (!isd[i]) nl.push_back(i);
-    auto term = [](double bi, double va, double xk) { return va != 0 ? (-va) * xk + bi : bi; };
     // ---- Dtrsm(Left, Lower, NoTrans, Unit)
     for (int s2 = 0; s2 < nd; s2++) {
         const int i = dl[s2];

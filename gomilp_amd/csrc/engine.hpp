@@ -166,6 +166,9 @@ int lu_compressed_nb(int m);
 void launch_luc_init(const LUArgs &a, hipStream_t s);
 int launch_luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t s);
 void launch_luc_gather(const double *At, int ld, int m, const int32_t *basic, double *W, int ldw, hipStream_t s);
+void launch_luc_pack_dense(const LUArgs &a, const int32_t *dlist, int nd, const int32_t *pivrow, double *Wdd, double *diag, hipStream_t s);
+void launch_luc_solve_rows(const LUArgs &a, const int32_t *dlist, int nd, const double *b, const double *xdL, const double *xdU,
+                           double *x, hipStream_t s);
 void launch_luc_pack(const LUArgs &a, const int32_t *dlist, int nd, double *Wd, double *diag, hipStream_t s);
 void launch_lu_pack(const LUArgs &a, const int32_t *dlist, int nd, double *Wd, double *diag, hipStream_t s);
 

@@ -24,6 +24,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "device_types.h"
 #include "kernels_common.h"
 
@@ -503,6 +505,56 @@ __global__ __launch_bounds__(256) void k_luc_pack(LUArgs a, const int32_t *__res
     }
 }
 
+
+// ---- Dgetrs split (large bases): the two triangular solves only couple the nd "dense" positions with each other; every
+// other row is a chain of its own once the solution at the dense positions is known.  The host solves the nd x nd
+// coupled part (k_luc_pack_dense hands it over), k_luc_solve_rows runs all remaining rows, one thread per physical row
+// (consecutive threads read consecutive elements of a column of the column-major L\U), in gonum's operation order:
+// ascending k, zero multipliers skipped, b_i = (-a_ik)*b_k + b_i as a rounded multiply and a rounded add, then
+// b_i *= 1/u_ii (level3double.go:75-118).
+__global__ __launch_bounds__(256) void k_luc_pack_dense(LUArgs a, const int32_t *__restrict__ dlist, int nd,
+                                                        const int32_t *__restrict__ pivrow, double *__restrict__ Wdd,
+                                                        double *__restrict__ diag) {
+    // Wdd[s*nd + t] = W(pivrow[dlist[s]], dlist[t]); diag[R] = W(R, lpos[R]) for every row (LU.Det() needs all of them)
+    const size_t ldw = (size_t)a.ldw;
+    const int s = blockIdx.x;
+    if (s < nd) {
+        const int R = pivrow[dlist[s]];
+        for (int t = threadIdx.x; t < nd; t += 256) Wdd[(size_t)s * nd + t] = a.W[(size_t)dlist[t] * ldw + R];
+    }
+    for (int R = blockIdx.x * 256 + threadIdx.x; R < a.m; R += gridDim.x * 256) diag[R] = a.W[(size_t)a.lpos[R] * ldw + R];
+}
+
+__global__ __launch_bounds__(256) void k_luc_solve_rows(LUArgs a, const int32_t *__restrict__ dlist, int nd,
+                                                        const double *__restrict__ b, const double *__restrict__ xdL,
+                                                        const double *__restrict__ xdU, double *__restrict__ x) {
+    const int R = blockIdx.x * 256 + threadIdx.x;
+    if (R >= a.m) return;
+    const int i = a.lpos[R];                       // logical position (= elimination step) of this physical row
+    if (a.dense_flag[i]) return;                   // coupled position: solved by the host
+    const size_t ldw = (size_t)a.ldw;
+    int lo = 0, hi = nd;                           // cnt = number of dense positions below i
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (dlist[mid] < i) lo = mid + 1; else hi = mid; }
+    const int cnt = lo;
+    double acc = b[R];                             // Dlaswp: b in logical order is b[physical row]
+    // Dtrsm(Left, Lower, NoTrans, Unit) over t < cnt, then Dtrsm(Left, Upper, NoTrans, NonUnit) over t >= cnt: one
+    // ascending sweep; 8 independent loads in flight per trip (a plain loop waits a memory round trip per term)
+    for (int t0 = 0; t0 < nd; t0 += 8) {
+        double va[8], xk[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int t = t0 + u;
+            va[u] = t < nd ? a.W[(size_t)dlist[t < nd ? t : 0] * ldw + R] : 0.0;
+            xk[u] = t < nd ? (t < cnt ? xdL[t] : xdU[t]) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (va[u] != 0) acc = __dadd_rn(__dmul_rn(-va[u], xk[u]), acc);
+    }
+    const double tinv = 1.0 / a.W[(size_t)i * ldw + R];
+    x[i] = __dmul_rn(acc, tinv);
+}
+
 template <int T, int RPT, int NB>
 static void luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t s) {
     const int m = a.m;
@@ -525,6 +577,14 @@ void launch_luc_init(const LUArgs &a, hipStream_t s) {
 }
 void launch_luc_gather(const double *At, int ld, int m, const int32_t *basic, double *W, int ldw, hipStream_t s) {
     hipLaunchKernelGGL(k_luc_gather, dim3(m), dim3(256), 0, s, At, ld, m, basic, W, ldw);
+}
+void launch_luc_pack_dense(const LUArgs &a, const int32_t *dlist, int nd, const int32_t *pivrow, double *Wdd, double *diag, hipStream_t s) {
+    const int grid = std::max(nd, (a.m + 255) / 256);
+    hipLaunchKernelGGL(k_luc_pack_dense, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, a, dlist, nd, pivrow, Wdd, diag);
+}
+void launch_luc_solve_rows(const LUArgs &a, const int32_t *dlist, int nd, const double *b, const double *xdL, const double *xdU,
+                           double *x, hipStream_t s) {
+    hipLaunchKernelGGL(k_luc_solve_rows, dim3((a.m + 255) / 256), dim3(256), 0, s, a, dlist, nd, b, xdL, xdU, x);
 }
 void launch_luc_pack(const LUArgs &a, const int32_t *dlist, int nd, double *Wd, double *diag, hipStream_t s) {
     dim3 grid((nd + 31) / 32 > 0 ? (nd + 31) / 32 : 1, (a.m + 31) / 32);
