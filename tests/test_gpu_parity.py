@@ -379,3 +379,22 @@ def test_supplied_initial_basis(ctx, m, seed, after):
     bad[0] = bad[1]
     assert rl.solve(0.0, initial_basic=bad).status == lp.ERR_PANIC == O.simplex(c, A, b, 0.0, bad).status
     rl.free()
+
+
+def test_random_roots_and_children_sweep(ctx):
+    """A small slice of tools/parity_sweep.py (300 random cases, 0 mismatches when this test was written): random
+    sizes, every second case a child with 1-5 branching rows (Phase I, Bland steps, the artificial exchange)."""
+    rng = np.random.default_rng(2024)
+    for k in range(14):
+        m = int(rng.integers(8, 160)); seed = int(rng.integers(1, 10**6))
+        c, A, b = synth.dense_lp_standard_form(m, seed)
+        if k % 2 == 1:
+            r0 = O.simplex(c, A, b, 0.0, None, fast_initial_basis=True)
+            frac = [j for j in range(m) if r0.x[j] != np.floor(r0.x[j])]
+            K = int(rng.integers(1, min(5, len(frac)) + 1))
+            cons = []
+            for j in rng.choice(frac, size=K, replace=False):
+                fl = float(np.floor(r0.x[j]))
+                cons.append((int(j), 1, fl) if rng.random() < 0.5 else (int(j), -1, -(fl + 1)))
+            c, A, b = O.child_standard_form(c, A, b, cons)
+        _check_against_oracle(ctx, c, A, b)
