@@ -30,7 +30,6 @@
 
 namespace gomilp {
 
-__device__ long long g_bt_prof[16];
 constexpr int kBtThreads = 1024;
 constexpr int kBtWaves = kBtThreads / 64;
 constexpr int kBtMaxK = 32;
@@ -137,11 +136,8 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
         return c;
     };
 
-    long long tstamp = clock64();
-    auto stamp = [&](int slot) { if (a.pad && tid == 0) { long long now = clock64(); g_bt_prof[slot] += now - tstamp; tstamp = now; } };
     for (int k = 0; k < a.kmax; k++) {
         const bool forced = (k == 0 && a.forced_q >= 0);
-        stamp(0);
         int q, p;
         double rq, dpv = 1.0;
         bool bland = false;
@@ -158,12 +154,9 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
             bt_block_argmin<kBtWaves>(c, sm2 + kBtWaves * (sm_par ^= 1));
             q = (int)c.i;
             rq = r_s[q];
-            stamp(1);
             if (rq >= -a.tol) { status = ST_OPTIMAL; break; }  // simplex.go:248
             column(q, k, dcol);
-            stamp(2);
             BtCand w = ratio(dcol, mvv);
-            stamp(3);
             p = (int)w.i;
             const double mv = orddecode(w.k);
             if (mv == inf) { status = ST_UNBOUNDED; break; }  // simplex.go:328-330
@@ -226,7 +219,6 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
         }
         if (KREG == 0 && tid < k) up[tid] = __hip_atomic_load(a.U + (size_t)tid * a.ldu + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        stamp(4);
         dpv = s_bcast[0];
         const double mult = rq / dpv;
         const double theta = s_bcast[1] / dpv;
@@ -280,7 +272,6 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
                 }
             }
         }
-        stamp(5);
         if (tid == 0 && !(forced && a.forced_nocommit)) {  // simplex.go:280
             const int ent = nonbasic_s[q], lea = basic_s[p];
             basic_s[p] = ent; nonbasic_s[q] = lea;
@@ -294,8 +285,6 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
         kd = k + 1;
         if (KREG == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // u_k / v_k reach L2 before the sc1 loads of other waves
         __syncthreads();
-        stamp(6);
-        if (a.pad && tid == 0) g_bt_prof[15] += 1;
     }
     for (int j = tid; j < a.ldt; j += kBtThreads) a.r[j] = r_s[j];
     for (int i = tid; i < a.ldu; i += kBtThreads) a.xb[i] = xb_s[i];
@@ -794,8 +783,6 @@ __global__ __launch_bounds__(kBlock) void k_bt_update_tiled(BTArgs a, int tilero
 // ---- launch wrappers ---------------------------------------------------------------------------
 
 int bt_max_k() { return kBtMaxK; }
-void bt_prof_read(long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bt_prof), sizeof(long long) * 16); }
-void bt_prof_reset() { long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_bt_prof), z, sizeof(z)); }
 
 // Thread count: the per-pivot reductions are instruction-issue bound and every wave repeats them, so the kernel runs
 // with ONE wave per SIMD (256 threads) whenever the rows/columns per thread still fit in registers.

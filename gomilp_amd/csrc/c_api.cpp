@@ -27,9 +27,7 @@ struct gomilp_pool {
     int64_t m0 = 0, n0 = 0;
 };
 
-namespace gomilp { void bt_prof_read(long long *out); void bt_prof_reset(); }
 extern "C" {
-void gomilp_dbg_bt_prof(long long *out, int reset) { if (reset) gomilp::bt_prof_reset(); else gomilp::bt_prof_read(out); }
 
 const char *gomilp_version(void) { return "gomilp_amd 0.1 (gfx950)"; }
 int gomilp_device_count(void) { return gomilp::device_count(); }

@@ -205,7 +205,6 @@ BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int
     a.basic = w.basic; a.nonbasic = w.nonbasic; a.st = w.st;
     a.trace = trace_on_ ? w.trace : nullptr; a.trace_cap = w.trace_cap;
     a.forced_q = a.forced_p = -1; a.forced_nocommit = 0;
-    a.pad = getenv("GOMILP_BT_PROF") ? 1 : 0;
     return a;
 }
 
