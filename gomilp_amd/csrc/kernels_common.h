@@ -180,12 +180,24 @@ __device__ __forceinline__ double vmin_f64(double a, double b) {
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-// min over each 16-lane row, result in lane 15 of the row (NaN operands lose: minnum)
+// min over each 16-lane row (NaN operands lose: minnum)
+// rotations (row_ror) have a source in every lane, so the DPP move needs no `old` operand (one v_mov less per
+// dword and step than row_shr with old = own value); afterwards EVERY lane of a row holds the row's minimum
+template <int CTRL>
+__device__ __forceinline__ unsigned int ror_u32(unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double ror_f64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned int lo = ror_u32<CTRL>((unsigned int)b), hi = ror_u32<CTRL>((unsigned int)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ double row_min_f64(double x) {
-    x = vmin_f64(x, dpp_f64<0x111>(x));
-    x = vmin_f64(x, dpp_f64<0x112>(x));
-    x = vmin_f64(x, dpp_f64<0x114>(x));
-    x = vmin_f64(x, dpp_f64<0x118>(x));
+    x = vmin_f64(x, ror_f64<0x121>(x));  // row_ror:1
+    x = vmin_f64(x, ror_f64<0x122>(x));  // row_ror:2
+    x = vmin_f64(x, ror_f64<0x124>(x));  // row_ror:4
+    x = vmin_f64(x, ror_f64<0x128>(x));  // row_ror:8
     return x;
 }
 __device__ __forceinline__ double wave_min_f64(double x) {
@@ -193,10 +205,10 @@ __device__ __forceinline__ double wave_min_f64(double x) {
     return vmin_f64(vmin_f64(readlane_f64(x, 15), readlane_f64(x, 31)), vmin_f64(readlane_f64(x, 47), readlane_f64(x, 63)));
 }
 __device__ __forceinline__ unsigned int row_min_u32(unsigned int x) {
-    x = min(x, dpp_u32<0x111>(x));
-    x = min(x, dpp_u32<0x112>(x));
-    x = min(x, dpp_u32<0x114>(x));
-    x = min(x, dpp_u32<0x118>(x));
+    x = min(x, ror_u32<0x121>(x));
+    x = min(x, ror_u32<0x122>(x));
+    x = min(x, ror_u32<0x124>(x));
+    x = min(x, ror_u32<0x128>(x));
     return x;
 }
 
