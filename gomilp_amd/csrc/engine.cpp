@@ -954,8 +954,10 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     }
     HIP_TRY(hipMemsetAsync(w.xb, 0, (size_t)P.ld * sizeof(double), stream_));
     ycur_ = 0;
-    HIP_TRY(hipMemsetAsync(w.yb[0], 0, (size_t)P.ld * sizeof(double), stream_));
-    HIP_TRY(hipMemsetAsync(w.yb[1], 0, (size_t)P.ld * sizeof(double), stream_));
+    if (!use_tab) {   // the duals only exist on the revised-simplex pipelines
+        HIP_TRY(hipMemsetAsync(w.yb[0], 0, (size_t)P.ld * sizeof(double), stream_));
+        HIP_TRY(hipMemsetAsync(w.yb[1], 0, (size_t)P.ld * sizeof(double), stream_));
+    }
     if ((rc = stage_upload(w.xb, xb.data(), (size_t)m * sizeof(double))) != GOMILP_OK) return finish(rc);
 
     // pipeline choice: the explicit tableau moves 16*m*(n-m) bytes per pivot in one launch, the revised form
@@ -976,8 +978,10 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
             HIP_TRY(dmalloc(&w.btU, (size_t)bt_max_k() * (w.cap_ld > P.ld ? w.cap_ld : P.ld))); HIP_TRY(dmalloc(&w.btV, (size_t)bt_max_k() * cl));
             w.cap_T = cap; w.cap_ldt = cl;
         }
-        HIP_TRY(hipMemsetAsync(w.R[0], 0, (size_t)w.cap_ldt * sizeof(double), stream_));
-        HIP_TRY(hipMemsetAsync(w.R[1], 0, (size_t)w.cap_ldt * sizeof(double), stream_));
+        if (!use_bt_) {   // the blocked kernels never read the padding of r
+            HIP_TRY(hipMemsetAsync(w.R[0], 0, (size_t)w.cap_ldt * sizeof(double), stream_));
+            HIP_TRY(hipMemsetAsync(w.R[1], 0, (size_t)w.cap_ldt * sizeof(double), stream_));
+        }
         rc = solve_tableau(P, tol, basic, rho, xb, feasible, st, &loop_rc, unit_basis ? nullptr : &binv_host);
         if (rc != GOMILP_OK) return finish(rc);
     } else {

@@ -245,14 +245,15 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
             HIP_TRY(hipEventCreateWithFlags(&w.pipe_ev[t], hipEventDisableTiming));
         }
     }
-    struct ChunkInfo { int64_t before_pred; size_t samp0, nsamp; };
+    struct ChunkInfo { int64_t before_pred; size_t samp0, nsamp; int64_t nblocks; };
     ChunkInfo info[2];
     size_t samp_total = 0;
-    auto enqueue_chunk = [&](int slot, int64_t before_pred) -> int {
+    auto enqueue_chunk = [&](int slot, int64_t before_pred, int64_t nblocks) -> int {
         info[slot].before_pred = before_pred;
         info[slot].samp0 = samp_total;
         info[slot].nsamp = 0;
-        for (int64_t bkk = 0; bkk < blocks_per_chunk; bkk++, block_no++) {
+        info[slot].nblocks = nblocks;
+        for (int64_t bkk = 0; bkk < nblocks; bkk++, block_no++) {
             int kmax = K;
             if (max_pivots_ > 0) kmax = (int)std::max<int64_t>(1, std::min<int64_t>(K, max_pivots_ - before_pred - bkk * K));
             BTArgs a = make_bt_args(P, phase, tol, nn, kmax);
@@ -275,8 +276,10 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
     };
     int cur = 0;
     int64_t pred = 0;   // pivots if every enqueued block ran in full
-    { int rc0 = enqueue_chunk(0, 0); if (rc0 != GOMILP_OK) return rc0; }
-    pred = blocks_per_chunk * K;
+    // small relaxations (B&B children) usually finish Phase I within a handful of pivots: their first chunk is one block
+    const int64_t first_blocks = (P.m <= 1024) ? 1 : blocks_per_chunk;
+    { int rc0 = enqueue_chunk(0, 0, first_blocks); if (rc0 != GOMILP_OK) return rc0; }
+    pred = first_blocks * K;
     int64_t seen = 0;   // pivots at the end of the previous inspected chunk
     for (;;) {
         // keep one chunk in flight behind the one whose state is awaited (not past a pivot budget)
@@ -284,13 +287,13 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
         // chunk would be pure no-op launches)
         const bool more = !(max_pivots_ > 0 && pred >= max_pivots_);
         const bool speculate = more && seen > 0;
-        if (speculate) { int rc1 = enqueue_chunk(cur ^ 1, pred); if (rc1 != GOMILP_OK) return rc1; pred += blocks_per_chunk * K; }
+        if (speculate) { int rc1 = enqueue_chunk(cur ^ 1, pred, blocks_per_chunk); if (rc1 != GOMILP_OK) return rc1; pred += blocks_per_chunk * K; }
         HIP_TRY(hipEventSynchronize(w.pipe_ev[cur]));
         HIP_TRY(hipGetLastError());
         hs = *w.pipe_state[cur];
         const int64_t executed = hs.pivots - seen;
         const ChunkInfo &ci = info[cur];
-        if (st && ci.nsamp && executed == blocks_per_chunk * K) {  // only chunks made of full blocks are samples
+        if (st && ci.nsamp && executed == ci.nblocks * K) {  // only chunks made of full blocks are samples
             for (size_t s2 = ci.samp0; s2 < ci.samp0 + ci.nsamp; s2++) {
                 float ms0 = 0, ms1 = 0;
                 if (hipEventElapsedTime(&ms0, w.sample_ev[s2 * 6], w.sample_ev[s2 * 6 + 1]) != hipSuccess) continue;
@@ -305,7 +308,7 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
         if (!hs.done) {
             if (max_pivots_ > 0 && hs.pivots >= max_pivots_) { ret = GOMILP_ERR_UNSUPPORTED; break; }
             if (!more) { ret = GOMILP_ERR_UNSUPPORTED; break; }
-            if (!speculate) { int rc1 = enqueue_chunk(cur ^ 1, pred); if (rc1 != GOMILP_OK) return rc1; pred += blocks_per_chunk * K; }
+            if (!speculate) { int rc1 = enqueue_chunk(cur ^ 1, pred, blocks_per_chunk); if (rc1 != GOMILP_OK) return rc1; pred += blocks_per_chunk * K; }
             cur ^= 1;
             continue;
         }
@@ -347,7 +350,6 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
     auto set_up_T = [&](int nn) -> int {  // T = B^-1 A_N
         ldt_ = tab_ld(nn);
         if (!binv_host) {  // slack basis: B^-1 is the permutation rho
-            HIP_TRY(hipMemsetAsync(w.T[0], 0, (size_t)m * ldt_ * sizeof(double), stream_));
             launch_tab_gather(P.dAt, P.ld, m, nn, w.nonbasic, w.rho, w.T[0], ldt_, stream_);
             launches_++;
             return GOMILP_OK;

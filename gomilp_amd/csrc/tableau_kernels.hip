@@ -226,12 +226,12 @@ __global__ void k_tab_gather(const double *__restrict__ At, int ld, int m, int n
     // the source rows are permuted by rho, so read one At row segment per (jp) and scatter through LDS
     for (int r = threadIdx.y; r < 32; r += 8) {
         const int jp = j0 + r, pos = p0 + threadIdx.x;
-        if (jp < nn && pos < m) tile[r][threadIdx.x] = At[(size_t)nonbasic[jp] * ld + rho[pos]];
+        tile[r][threadIdx.x] = (jp < nn && pos < m) ? At[(size_t)nonbasic[jp] * ld + rho[pos]] : 0.0;
     }
     __syncthreads();
     for (int r = threadIdx.y; r < 32; r += 8) {
         const int pos = p0 + r, jp = j0 + threadIdx.x;
-        if (jp < nn && pos < m) T[(size_t)pos * ldt + jp] = tile[threadIdx.x][r];
+        if (jp < ldt && pos < m) T[(size_t)pos * ldt + jp] = tile[threadIdx.x][r];   // the padding columns nn..ldt are zeroed here
     }
 }
 
@@ -301,7 +301,7 @@ int launch_tableau_pivot(const TabArgs &a, int flags, int nparts, long long t, h
 }
 void launch_tab_gather(const double *At, int ld, int m, int nn, const int32_t *nonbasic, const int32_t *rho, double *T, int ldt,
                        hipStream_t s) {
-    dim3 grid((m + 31) / 32, (nn + 31) / 32), block(32, 8);
+    dim3 grid((m + 31) / 32, (ldt + 31) / 32), block(32, 8);   // all ldt columns: the kernel zero-fills the padding
     hipLaunchKernelGGL(k_tab_gather, grid, block, 0, s, At, ld, m, nn, nonbasic, rho, T, ldt);
 }
 int tab_ld(int nn) { return ((nn + 511) / 512) * 512; }
