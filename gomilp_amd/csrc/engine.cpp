@@ -21,9 +21,12 @@ Engine::~Engine() {
     for (auto *vec : {&problems_, &child_pool_})
         for (auto &p : *vec) {
             if (!p) continue;
-            hipFree(p->dAt); hipFree(p->dc); hipFree(p->dc1); hipFree(p->db);
-            if (p->dvar) hipFree(p->dvar);
-            if (p->dsign) hipFree(p->dsign);
+            hipFree(p->dAt); hipFree(p->db);
+            if (!p->is_child) {   // a child's c / c1 / sign / var live inside its b block
+                hipFree(p->dc); hipFree(p->dc1);
+                if (p->dvar) hipFree(p->dvar);
+                if (p->dsign) hipFree(p->dsign);
+            }
         }
     w_->release_all();
     if (stream_) hipStreamDestroy(stream_);
@@ -77,7 +80,7 @@ int Engine::ensure_work(int m, int ncols) {
     HIP_TRY(dmalloc(&w.dvec, (size_t)nld));
     HIP_TRY(dmalloc(&w.move, (size_t)nld)); HIP_TRY(dmalloc(&w.rvec, (size_t)nc));
     HIP_TRY(dmalloc(&w.yscratch, (size_t)64 * nld));
-    HIP_TRY(dmalloc(&w.basic, (size_t)nm)); HIP_TRY(dmalloc(&w.nonbasic, (size_t)nc));
+    HIP_TRY(dmalloc(&w.basic, (size_t)nm + (size_t)nc)); w.nonbasic = w.basic + nm;   // one block: both lists go up in one copy
     HIP_TRY(dmalloc(&w.lpos, (size_t)nm)); HIP_TRY(dmalloc(&w.rowstep, (size_t)nm)); HIP_TRY(dmalloc(&w.rho, (size_t)nm));
     HIP_TRY(dmalloc(&w.unitrow, (size_t)nm)); HIP_TRY(dmalloc(&w.denseflag, (size_t)nm)); HIP_TRY(dmalloc(&w.dlist, (size_t)nm));
     HIP_TRY(dmalloc(&w.ludiag, (size_t)nm)); HIP_TRY(dmalloc(&w.Wd, (size_t)nm * nld));
@@ -198,13 +201,9 @@ int64_t Engine::upload_child(int64_t root, int K, const int32_t *var, const doub
             break;
         }
     }
-    auto release = [&](Problem &q) {
+    auto release = [&](Problem &q) {   // a child owns dAt and ONE block holding b | c | c1 | sign | var
         if (q.dAt) hipFree(q.dAt);
-        if (q.dc) hipFree(q.dc);
-        if (q.dc1) hipFree(q.dc1);
         if (q.db) hipFree(q.db);
-        if (q.dvar) hipFree(q.dvar);
-        if (q.dsign) hipFree(q.dsign);
         q.dAt = q.dc = q.dc1 = q.db = q.dsign = nullptr; q.dvar = nullptr;
     };
     if (!P) {
@@ -213,39 +212,35 @@ int64_t Engine::upload_child(int64_t root, int K, const int32_t *var, const doub
         // some head-room so that deeper children of the same root reuse the slot
         const int kcap = K + 8, mcap = m0 + kcap, ncap = n0 + kcap, ldcap = (mcap + 1) & ~1;
         P->cap_at = (size_t)(ncap + 1) * ldcap; P->cap_c = (size_t)ncap + 1; P->cap_b = (size_t)ldcap; P->cap_k = kcap;
-        if (dmalloc(&P->dAt, P->cap_at) != hipSuccess || dmalloc(&P->dc, P->cap_c) != hipSuccess ||
-            dmalloc(&P->dc1, P->cap_c) != hipSuccess || dmalloc(&P->db, P->cap_b) != hipSuccess ||
-            dmalloc(&P->dvar, (size_t)P->cap_k) != hipSuccess || dmalloc(&P->dsign, (size_t)P->cap_k) != hipSuccess) {
+        // b | c | c1 | sign (doubles) | var (ints) in one device block, mirrored by the pinned staging block: one copy
+        const size_t blk = P->cap_b + 2 * P->cap_c + 2 * (size_t)P->cap_k + 8;
+        if (dmalloc(&P->dAt, P->cap_at) != hipSuccess || dmalloc(&P->db, blk) != hipSuccess) {
             release(*P);
             return -GOMILP_ERR_DEVICE;
         }
+        P->dc = P->db + P->cap_b; P->dc1 = P->dc + P->cap_c; P->dsign = P->dc1 + P->cap_c;
+        P->dvar = reinterpret_cast<int32_t *>(P->dsign + P->cap_k);
     }
     P->m = m; P->n = n; P->ld = ld;
     auto fail = [&](int code) -> int64_t { release(*P); return -code; };
 #define UP_TRY(expr) do { if ((expr) != hipSuccess) return fail(GOMILP_ERR_DEVICE); } while (0)
     P->hc = R.hc; P->hc.resize(n, 0.0);        // c' = [c, 0]   (subproblem.go:110-114)
     P->hb = R.hb; P->hb.insert(P->hb.end(), rhs, rhs + K);  // b' = [b; h]  (:117-119)
-    // one pinned staging block: [b (ld) | c (n+1) | c1 (n+1) | sign (K)] doubles, then var (K) ints
+    // one pinned staging block with the layout of the child's device block (capacity offsets)
     Work &w = *w_;
-    const size_t stage_doubles = (size_t)ld + 2 * ((size_t)n + 1) + (size_t)K;
-    if (w.child_stage_cap < stage_doubles * sizeof(double) + (size_t)K * sizeof(int32_t) + 64) {
+    const size_t blk_bytes = (P->cap_b + 2 * P->cap_c + (size_t)P->cap_k) * sizeof(double) + (size_t)P->cap_k * sizeof(int32_t);
+    if (w.child_stage_cap < blk_bytes + 64) {
         if (w.child_stage) hipHostFree(w.child_stage);
-        w.child_stage_cap = 2 * (stage_doubles * sizeof(double) + (size_t)K * sizeof(int32_t) + 64);
+        w.child_stage_cap = 2 * (blk_bytes + 64);
         UP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.child_stage), w.child_stage_cap, hipHostMallocDefault));
     }
     double *sb = reinterpret_cast<double *>(w.child_stage);
-    double *sc = sb + ld, *sc1 = sc + (n + 1), *ss = sc1 + (n + 1);
-    int32_t *sv = reinterpret_cast<int32_t *>(ss + K);
+    double *sc = sb + P->cap_b, *sc1 = sc + P->cap_c, *ss = sc1 + P->cap_c;
+    int32_t *sv = reinterpret_cast<int32_t *>(ss + P->cap_k);
     for (int i = 0; i < ld; i++) sb[i] = i < m ? P->hb[i] : 0.0;
     for (int j = 0; j <= n; j++) { sc[j] = j < n ? P->hc[j] : 0.0; sc1[j] = j == n ? 1.0 : 0.0; }
     for (int k = 0; k < K; k++) { ss[k] = sign[k]; sv[k] = var[k]; }
-    if (K) {
-        UP_TRY(hipMemcpyAsync(P->dvar, sv, (size_t)K * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-        UP_TRY(hipMemcpyAsync(P->dsign, ss, (size_t)K * sizeof(double), hipMemcpyHostToDevice, stream_));
-    }
-    UP_TRY(hipMemcpyAsync(P->db, sb, (size_t)ld * sizeof(double), hipMemcpyHostToDevice, stream_));
-    UP_TRY(hipMemcpyAsync(P->dc, sc, ((size_t)n + 1) * sizeof(double), hipMemcpyHostToDevice, stream_));
-    UP_TRY(hipMemcpyAsync(P->dc1, sc1, ((size_t)n + 1) * sizeof(double), hipMemcpyHostToDevice, stream_));
+    UP_TRY(hipMemcpyAsync(P->db, sb, blk_bytes, hipMemcpyHostToDevice, stream_));
     launch_child_assemble(R.dAt, R.ld, m0, n0, P->dAt, ld, K, P->dvar, P->dsign, stream_);
     UP_TRY(sync_stream());  // the staging block is reused by the next child
     UP_TRY(hipGetLastError());
@@ -361,6 +356,14 @@ int Engine::stage_upload(void *dst, const void *src, size_t bytes) {
 
 int Engine::upload_index_lists(const std::vector<int32_t> &basic, const std::vector<int32_t> &nonbasic) {
     Work &w = *w_;
+    if (!basic.empty() && !nonbasic.empty()) {
+        // the two lists share one device block (basic at 0, nonbasic at cap_m): one copy, one queue packet
+        const size_t gap = (size_t)(w.nonbasic - w.basic);
+        std::vector<int32_t> both(gap + nonbasic.size(), 0);
+        memcpy(both.data(), basic.data(), basic.size() * sizeof(int32_t));
+        memcpy(both.data() + gap, nonbasic.data(), nonbasic.size() * sizeof(int32_t));
+        return stage_upload(w.basic, both.data(), both.size() * sizeof(int32_t));
+    }
     int rc = stage_upload(w.basic, basic.data(), basic.size() * sizeof(int32_t));
     if (rc != GOMILP_OK) return rc;
     return stage_upload(w.nonbasic, nonbasic.data(), nonbasic.size() * sizeof(int32_t));

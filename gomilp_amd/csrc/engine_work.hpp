@@ -104,7 +104,8 @@ struct Engine::Work {
     void release() {
         for (auto &p : binv) { if (p) hipFree(p); p = nullptr; }
         for (double **p : {&xb, &yb[0], &yb[1], &dvec, &move, &rvec, &yscratch, &W, &ludiag, &Wd, &luLp, &luUp}) { if (*p) hipFree(*p); *p = nullptr; }
-        for (int32_t **p : {&basic, &nonbasic, &lpos, &rowstep, &rho, &unitrow, &denseflag, &dlist}) { if (*p) hipFree(*p); *p = nullptr; }
+        nonbasic = nullptr;   // lives in the same block as `basic`
+        for (int32_t **p : {&basic, &lpos, &rowstep, &rho, &unitrow, &denseflag, &dlist}) { if (*p) hipFree(*p); *p = nullptr; }
         if (h_W) hipHostFree(h_W); h_W = nullptr;
         if (h_vec) hipHostFree(h_vec); h_vec = nullptr;
         if (h_chk) hipHostFree(h_chk); h_chk = nullptr;
