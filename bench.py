@@ -177,7 +177,7 @@ def main() -> int:
             return r.status, r.z, r.x, r.has_x
 
         dev = torch.device("cuda", local_rank)
-        fr.solve_wave(solve_shard, children[: 2 * world * args.workers], mask5, rank, world, dist, dev)  # warm-up wave
+        fr.solve_wave(solve_shard, children, mask5, rank, world, dist, dev)  # warm-up: a full wave (first-touch allocations of every worker)
         barrier()
         tf0 = time.perf_counter()
         wave = fr.solve_wave(solve_shard, children, mask5, rank, world, dist, dev)
