@@ -4,14 +4,17 @@
 // reduced-cost update) of the tableau T = B^-1 A_N; the rank-1 update of all m*(n-m) entries is bookkeeping that
 // can be deferred.  So pivots run in blocks of K:
 //
-//   k_bt_inner   ONE workgroup (1024 threads) performs up to K complete pivots.  It reads the needed column and row
-//                of the stale T and corrects them with the block's earlier rank-1 terms,
+//   k_bt_inner2  ONE workgroup performs up to K = 8 complete pivots (shapes up to 2048 rows / nonbasic columns; larger
+//   k_bt_inner   ones use the older k_bt_inner with K = 16 and the block terms re-read through L2).  It reads the
+//                needed column and row of the stale T and corrects them with the block's earlier rank-1 terms,
 //                   T_cur = T_stale + sum_j u_j v_j'^T,
-//                keeps r and x_B in LDS, takes every decision exactly like the other pipelines (first-index argmin,
-//                1e-13 rounding, unbounded / degenerate tests, Bland rule of simplex.go:347-383 in-kernel), and
-//                emits u_k (m) and v_k' (n-m) per pivot.  No grid-wide step, no launch per pivot.
-//   k_bt_update  all CUs: T += sum_k u_k v_k'^T in one streaming read+write pass (K FMAs per element, in place —
-//                an element depends only on its own old value).
+//                takes every decision exactly like the other pipelines (first-index argmin, 1e-13 rounding, unbounded /
+//                degenerate tests, Bland rule of simplex.go:347-383 in-kernel), and emits u_k (m) and v_k' (n-m) per
+//                pivot.  No grid-wide step, no launch per pivot.  k_bt_inner2: own terms in registers, two barriers
+//                per pivot, T in 4x4 tiles (see the comments at the kernel).
+//   k_bt_update_tiled / k_bt_update
+//                all CUs: T += sum_k u_k v_k'^T in one streaming read+write pass (K multiply-adds per element, in
+//                place — an element depends only on its own old value), 8 rows of loads in flight per lane.
 //
 // HBM traffic per pivot: 16*m*(n-m)/K + O(K*(m + n-m)) bytes instead of 16*m*(n-m).
 // One pivot as a pure rank-1 term:  with d = column q, v = row p, d_p = pivot element:
