@@ -793,8 +793,7 @@ int bt_max_k() { return kBtMaxK; }
 struct BtCfg { int nt, ri, cj, kreg; };
 static BtCfg bt_cfg(int m, int ldt) {
     auto per = [](int x, int nt) { return (x + nt - 1) / nt; };
-    int force = 0;
-    if (const char *e = getenv("GOMILP_BT_NT")) force = atoi(e);
+    static const int force = [] { const char *e = getenv("GOMILP_BT_NT"); return e ? atoi(e) : 0; }();   // developer knob, read once
     for (int nt : {256, 512, 1024}) {
         if (force && nt != force) continue;
         const int r = std::max(per(m, nt), per(ldt, nt));
@@ -849,7 +848,8 @@ void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e
 // true when launch_bt_inner picks the register-resident kernel, which works on the tiled layout of T
 bool bt_tiled(int m, int ldt, int kmax) {
     const BtCfg c = bt_cfg(m, ldt);
-    if (getenv("GOMILP_BT_OLD") || !(c.kreg > 0 && kmax <= c.kreg)) return false;
+    static const bool old_only = getenv("GOMILP_BT_OLD") != nullptr;   // developer knob, read once
+    if (old_only || !(c.kreg > 0 && kmax <= c.kreg)) return false;
     return c.ri == 2 || (c.ri == 4 && c.nt <= 512);
 }
 void launch_bt_tile(const double *src, double *dst, int m, int ldt, bool to_tiles, hipStream_t s) {
@@ -861,7 +861,6 @@ void launch_bt_update(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t 
         const int gx = (2 * a.ldt + kBlock - 1) / kBlock;
         const int ntr = (a.m + 3) / 4;
         int tr = 16;   // tile rows per workgroup (64 rows); aim for >= 512 workgroups
-        if (const char *e = getenv("GOMILP_BT_TR")) tr = atoi(e);
         while (tr > 4 && gx * ((ntr + tr - 1) / tr) < 512) tr >>= 1;
         dim3 grid(gx, (ntr + tr - 1) / tr);
         if (a.kmax <= 8) hipExtLaunchKernelGGL((k_bt_update_tiled<8>), grid, dim3(kBlock), 0, s, e0, e1, 0, a, tr);

@@ -676,14 +676,6 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     } else {
         for (int k = 0; k < m; k++) dl.push_back(k);
     }
-    if (const char *dump = getenv("GOMILP_LU_DUMP")) {  // developer aid: pivot rows / dense flags of the schedule that ran
-        std::vector<int32_t> pv(m), df(m, 1);
-        hipMemcpy(pv.data(), w.rho, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost);
-        if (blocked) hipMemcpy(df.data(), w.denseflag, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost);
-        FILE *probe = fopen(dump, "rb");   // keep the first call's dump
-        if (probe) fclose(probe);
-        else if (FILE *f = fopen(dump, "wb")) { fwrite(pv.data(), 4, m, f); fwrite(df.data(), 4, m, f); fclose(f); }
-    }
     const int nd = (int)dl.size();
     lu_dense_ = nd;
     { int rcd = stage_upload(w.dlist, dl.data(), (size_t)nd * sizeof(int32_t)); if (rcd != GOMILP_OK) return rcd; }

@@ -567,7 +567,8 @@ static void luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_
 
 bool lu_compressed_supported(int m) { return m <= 4096; }
 static int luc_cfg(int m) {
-    if (const char *e = getenv("GOMILP_LUC_CFG")) return atoi(e);
+    static const int forced = [] { const char *e = getenv("GOMILP_LUC_CFG"); return e ? atoi(e) : -1; }();   // developer knob, read once
+    if (forced >= 0) return forced;
     return m <= 512 ? 0 : (m <= 1024 ? 1 : (m <= 2048 ? 2 : 3));
 }
 int lu_compressed_nb(int m) { const int c = luc_cfg(m); return c <= 1 ? 32 : (c == 2 ? 16 : 8); }
