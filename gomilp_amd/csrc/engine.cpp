@@ -88,7 +88,7 @@ int Engine::ensure_work(int m, int ncols) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_W), (size_t)nm * nld * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_vec), (size_t)std::max(nld, nc) * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_chk), (size_t)nld * sizeof(double), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_idx), (size_t)std::max(nm, nc) * sizeof(int32_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_idx), ((size_t)nm + (size_t)nc) * sizeof(int32_t), hipHostMallocDefault));   // mirrors the basic | nonbasic device block
     {
         const size_t cap = std::max<size_t>(4096, sizeof(double) * ((size_t)std::max(nld, nc) + 64));
         for (int t = 0; t < Work::kStageSlots; t++) {
@@ -947,13 +947,16 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
         if ((rc = stage_upload(w.rho, rho.data(), (size_t)m * sizeof(int32_t))) != GOMILP_OK) return finish(rc);
         launch_set_binv_perm(w.binv[0], P.ld, m, w.rho, stream_);
     }
-    HIP_TRY(hipMemsetAsync(w.xb, 0, (size_t)P.ld * sizeof(double), stream_));
     ycur_ = 0;
     if (!use_tab) {   // the duals only exist on the revised-simplex pipelines
         HIP_TRY(hipMemsetAsync(w.yb[0], 0, (size_t)P.ld * sizeof(double), stream_));
         HIP_TRY(hipMemsetAsync(w.yb[1], 0, (size_t)P.ld * sizeof(double), stream_));
     }
-    if ((rc = stage_upload(w.xb, xb.data(), (size_t)m * sizeof(double))) != GOMILP_OK) return finish(rc);
+    {   // x_B with its zero padding in one copy
+        std::vector<double> xpad(P.ld, 0.0);
+        std::copy(xb.begin(), xb.begin() + m, xpad.begin());
+        if ((rc = stage_upload(w.xb, xpad.data(), (size_t)P.ld * sizeof(double))) != GOMILP_OK) return finish(rc);
+    }
 
     // pipeline choice: the explicit tableau moves 16*m*(n-m) bytes per pivot in one launch, the revised form
     // 8*[m(n-m) + 2m^2] in two: the tableau wins while n - m < 2m

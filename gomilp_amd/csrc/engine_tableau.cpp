@@ -435,13 +435,13 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         if (rc == GOMILP_ERR_DEVICE) return rc;
         for (int i = 0; i < m; i++) if (w.h_chk[i] < -1e-13) return GOMILP_ERR_PANIC;
         if (rc != GOMILP_OK) { st->wrapped_status = rc; return GOMILP_ERR_PHASE1_WRAPPED; }  // :557-559
-        HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipMemcpyAsync(w.h_idx + m, w.nonbasic, (size_t)nn * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));  // m + nn <= n + 1
+        const size_t gap = (size_t)(w.nonbasic - w.basic);   // the two lists share one device block: one copy
+        HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (gap + (size_t)nn) * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(sync_stream());
         int added = -1;
         for (int i = 0; i < m; i++) { basic[i] = w.h_idx[i]; xb[i] = w.h_vec[i]; if (basic[i] == n) added = i; }
-        for (int jp = 0; jp < nn; jp++) nonbasic[jp] = w.h_idx[m + jp];
+        for (int jp = 0; jp < nn; jp++) nonbasic[jp] = w.h_idx[gap + jp];
         double xart = added >= 0 ? xb[added] : 0.0;
         if (added >= 0 && fabs(xart) > 1e-13 && fabs(xart) < 1e-11) {
             std::vector<double> xe;
