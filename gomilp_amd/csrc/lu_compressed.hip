@@ -55,6 +55,7 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
     __shared__ idx_t s_ucol[MAXM];    // inverse: the unit column of a row (NONE: none)
     __shared__ unsigned char s_active[MAXM];
     __shared__ double prow[2][NB];
+    __shared__ double s_rinv[2];      // 1 / pivot of the running step, computed once by the pivot row's owner
     __shared__ double redM[2][16];
     __shared__ unsigned int redL[2][16];
     __shared__ int s_cols[2][NB];     // register columns, ascending; double buffered across insertions
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
             const int P = row.R;
 #pragma unroll
             for (int cc = 0; cc < NB; cc++) pr[cc] = row.v[cc];
+            s_rinv[s & 1] = 1.0 / row.v[0];   // dgetf2.go:54-56 scales by the reciprocal
             row.act = false;
             row.lp = -2 - P;   // marks the owner: its U entries go to W after the barrier, off everybody's critical path
             s_active[P] = 0;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
         const double piv = pr[0];
         const bool singular = (piv == 0);  // dgetf2.go:48-49: no scaling, the rank-1 update is a no-op
         if (singular && tid == 0) a.st->lu_singular = 1;
-        const double rinv = 1.0 / piv;
+        const double rinv = s_rinv[s & 1];
         // ---- the column that just became dense joins the register list (sorted position `pos` behind the columns
         // still to come) instead of ending the round in front of it; with a full list the last column is dropped
         // (W still holds its original: the trailing kernels redo it, except for the rows retired while it was listed)
