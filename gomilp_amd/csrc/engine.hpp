@@ -128,14 +128,14 @@ int launch_update_ftran_fused(const LPArgs &a, int pending, int nparts_price, hi
 int tab_ld(int nn);
 int launch_tableau_pivot(const TabArgs &a, int flags, int nparts, long long t, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 void launch_tab_gather(const double *At, int ld, int m, int nn, const int32_t *nonbasic, const int32_t *rho, double *T, int ldt,
-                       hipStream_t s);
+                       bool tiled, hipStream_t s);
 void launch_tab_permute_cols(const double *Tin, int ld_in, double *Tout, int ld_out, int m, int nn_out, const int32_t *srcpos,
                              hipStream_t s);
 int tab_r_chunks(int m);
 void launch_tab_r(const double *T, int ldt, int m, int nn, const double *cost, const int32_t *basic, const int32_t *nonbasic,
-                  double *scratch, double *r, hipStream_t s);
-void launch_tab_row_colmax(const double *T, int ldt, int m, int nn, int row, double *out, hipStream_t s);
-void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb, double *dvec, double *move, hipStream_t s);
+                  double *scratch, double *r, bool tiled, hipStream_t s);
+void launch_tab_row_colmax(const double *T, int ldt, int m, int nn, int row, double *out, bool tiled, hipStream_t s);
+void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb, double *dvec, double *move, bool tiled, hipStream_t s);
 // bt_kernels.hip
 bool bt_supported(int m, int nn);
 int bt_max_k();

@@ -71,7 +71,7 @@ int Engine::host_bland_tab(const Problem &P, int phase, double tol, int nn, gomi
     for (int i = 0; i < nn; i++) {
         if (r[i] > -1e-14) continue;  // blandNegTol, :352
         bt_layout(P, false);
-        launch_tab_column(w.T[tcur_], ldt_, m, i, w.xb, w.dvec, w.move, stream_);
+        launch_tab_column(w.T[tcur_], ldt_, m, i, w.xb, w.dvec, w.move, false, stream_);
         launches_++;
         HIP_TRY(hipMemcpyAsync(w.h_vec, w.move, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(sync_stream());
@@ -350,7 +350,10 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
     auto set_up_T = [&](int nn) -> int {  // T = B^-1 A_N
         ldt_ = tab_ld(nn);
         if (!binv_host) {  // slack basis: B^-1 is the permutation rho
-            launch_tab_gather(P.dAt, P.ld, m, nn, w.nonbasic, w.rho, w.T[0], ldt_, stream_);
+            // straight into the layout the block kernels want: no conversion pass before the first pivot
+            const int kr0 = bt_reg_k(P.m, ldt_);
+            t_tiled_ = use_bt_ && bt_tiled(P.m, ldt_, block_k_ > 0 ? (int)block_k_ : (kr0 > 0 ? 8 : 16));
+            launch_tab_gather(P.dAt, P.ld, m, nn, w.nonbasic, w.rho, w.T[0], ldt_, t_tiled_, stream_);
             launches_++;
             return GOMILP_OK;
         }
@@ -396,7 +399,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return rc;
         if ((rc = set_up_T(nn)) != GOMILP_OK) return rc;
         const int qa = nn - 1;  // position of the artificial
-        launch_tab_column(w.T[0], ldt_, m, qa, w.xb, w.dvec, w.move, stream_);
+        launch_tab_column(w.T[0], ldt_, m, qa, w.xb, w.dvec, w.move, t_tiled_, stream_);
         launches_++;
         double dp = 0;  // pivot element of the forced pivot: (B^-1 a_art)[minidx]
         if (!binv_host) dp = art[rho[minidx]];
@@ -424,8 +427,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
             }
         }
         if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return rc;
-        bt_layout(P, false);
-        launch_tab_r(w.T[tcur_], ldt_, m, nn, P.dc1, w.basic, w.nonbasic, w.tscratch, w.R[rcur_], stream_);
+        launch_tab_r(w.T[tcur_], ldt_, m, nn, P.dc1, w.basic, w.nonbasic, w.tscratch, w.R[rcur_], t_tiled_, stream_);
         launches_ += 2;
         // the Phase-I starting vertex must be feasible (initializeFromBasic inside the recursive call panics otherwise,
         // simplex.go:155-158): its x_B is copied out here and inspected after the loop's first host wait — a violation
@@ -457,8 +459,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
             std::sort(cand.begin(), cand.end());
             bool exchanged = false;
             // pivot elements T[added][jp] and column maxima of every candidate in one pass (tscratch holds 64 rows of ldt)
-            bt_layout(P, false);
-            launch_tab_row_colmax(w.T[tcur_], ldt_, m, nn, added, w.tscratch, stream_);
+            launch_tab_row_colmax(w.T[tcur_], ldt_, m, nn, added, w.tscratch, t_tiled_, stream_);
             launches_++;
             std::vector<double> rowmax((size_t)2 * ldt_);
             HIP_TRY(hipMemcpyAsync(rowmax.data(), w.tscratch, rowmax.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
@@ -466,8 +467,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
             for (auto &cv : cand) {
                 const int jp = cv.second;
                 if (!(fabs(rowmax[jp]) > 1e-9 * std::max(1.0, rowmax[(size_t)ldt_ + jp]))) continue;   // same test as below
-                bt_layout(P, false);
-                launch_tab_column(w.T[tcur_], ldt_, m, jp, w.xb, w.dvec, w.move, stream_);
+                launch_tab_column(w.T[tcur_], ldt_, m, jp, w.xb, w.dvec, w.move, t_tiled_, stream_);
                 launches_++;
                 HIP_TRY(hipMemcpyAsync(w.h_vec, w.dvec, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
                 HIP_TRY(sync_stream());
@@ -516,8 +516,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         if ((rc = set_up_T(nn)) != GOMILP_OK) return rc;
     }
     // ---- Phase II ----
-    bt_layout(P, false);
-    launch_tab_r(w.T[tcur_], ldt_, m, nn, P.dc, w.basic, w.nonbasic, w.tscratch, w.R[rcur_], stream_);
+    launch_tab_r(w.T[tcur_], ldt_, m, nn, P.dc, w.basic, w.nonbasic, w.tscratch, w.R[rcur_], t_tiled_, stream_);
     launches_ += 2;
     *loop_rc = use_bt_ ? run_loop_bt(P, 2, tol, nn, st) : run_loop_tab(P, 2, tol, nn, st);
     return GOMILP_OK;

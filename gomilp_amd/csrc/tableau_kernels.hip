@@ -219,8 +219,14 @@ __global__ __launch_bounds__(kBlock) void k_tableau_pivot(TabArgs a, int flags, 
 // ---- set-up kernels ---------------------------------------------------------------------------
 
 // T[pos, jp] = At[var(jp)][rho[pos]]  (B^-1 = permutation of the slack basis: row pos of T is row rho[pos] of A_N)
+// element (i, j) of T in either layout: row-major, or the 4x4 tiles of the blocked pipeline (bt_kernels.hip)
+__device__ __forceinline__ size_t tab_idx(int i, int j, int ldt, int tiled) {
+    return tiled ? ((size_t)(i >> 2) * (size_t)(ldt >> 2) + (size_t)(j >> 2)) * 16u + (size_t)(((i & 3) << 2) + (j & 3))
+                 : (size_t)i * ldt + j;
+}
+
 __global__ void k_tab_gather(const double *__restrict__ At, int ld, int m, int nn, const int32_t *__restrict__ nonbasic,
-                             const int32_t *__restrict__ rho, double *__restrict__ T, int ldt) {
+                             const int32_t *__restrict__ rho, double *__restrict__ T, int ldt, int tiled) {
     __shared__ double tile[32][33];
     const int j0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
     // the source rows are permuted by rho, so read one At row segment per (jp) and scatter through LDS
@@ -231,7 +237,9 @@ __global__ void k_tab_gather(const double *__restrict__ At, int ld, int m, int n
     __syncthreads();
     for (int r = threadIdx.y; r < 32; r += 8) {
         const int pos = p0 + r, jp = j0 + threadIdx.x;
-        if (jp < ldt && pos < m) T[(size_t)pos * ldt + jp] = tile[threadIdx.x][r];   // the padding columns nn..ldt are zeroed here
+        // the padding columns nn..ldt (and, tiled, the padding rows m..m4) are zeroed here
+        const int mrows = tiled ? ((m + 3) & ~3) : m;
+        if (jp < ldt && pos < mrows) T[tab_idx(pos, jp, ldt, tiled)] = pos < m ? tile[threadIdx.x][r] : 0.0;
     }
 }
 
@@ -246,7 +254,7 @@ __global__ void k_tab_permute_cols(const double *__restrict__ Tin, int ld_in, do
 // r[jp] = cost[nonbasic[jp]] - sum_i cost[basic[i]] * T[i, jp]   (row-chunked, fixed-order reduction)
 __global__ __launch_bounds__(kBlock) void k_tab_r_partial(const double *__restrict__ T, int ldt, int m, int nn,
                                                           const double *__restrict__ cost, const int32_t *__restrict__ basic,
-                                                          double *__restrict__ scratch, int rows_per_chunk) {
+                                                          double *__restrict__ scratch, int rows_per_chunk, int tiled) {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     const int chunk = blockIdx.y;
     const int i0 = chunk * rows_per_chunk, i1 = min(m, i0 + rows_per_chunk);
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void k_tab_r_partial(const double *__restri
     double acc = 0;
     for (int i = i0; i < i1; i++) {
         const double cb = cost[basic[i]];
-        if (cb != 0) acc += cb * T[(size_t)i * ldt + j];
+        if (cb != 0) acc += cb * T[tab_idx(i, j, ldt, tiled)];
     }
     scratch[(size_t)chunk * ldt + j] = acc;
 }
@@ -269,10 +277,10 @@ __global__ void k_tab_r_reduce(const double *__restrict__ scratch, int ldt, int 
 
 // column jp of T -> dvec, ratio vector (computeMove for a Bland candidate, simplex.go:306-342)
 __global__ void k_tab_column(const double *__restrict__ T, int ldt, int m, int jp, const double *__restrict__ xb,
-                             double *__restrict__ dvec, double *__restrict__ move) {
+                             double *__restrict__ dvec, double *__restrict__ move, int tiled) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    const double dn = T[(size_t)i * ldt + jp];
+    const double dn = T[tab_idx(i, jp, ldt, tiled)];
     double d = -dn;
     if (fabs(d) < 1e-13) d = 0;
     dvec[i] = dn;
@@ -300,9 +308,9 @@ int launch_tableau_pivot(const TabArgs &a, int flags, int nparts, long long t, h
     return g;
 }
 void launch_tab_gather(const double *At, int ld, int m, int nn, const int32_t *nonbasic, const int32_t *rho, double *T, int ldt,
-                       hipStream_t s) {
-    dim3 grid((m + 31) / 32, (ldt + 31) / 32), block(32, 8);   // all ldt columns: the kernel zero-fills the padding
-    hipLaunchKernelGGL(k_tab_gather, grid, block, 0, s, At, ld, m, nn, nonbasic, rho, T, ldt);
+                       bool tiled, hipStream_t s) {
+    dim3 grid((m + 3 + 31) / 32, (ldt + 31) / 32), block(32, 8);   // all ldt columns (+ pad rows): the kernel zero-fills the padding
+    hipLaunchKernelGGL(k_tab_gather, grid, block, 0, s, At, ld, m, nn, nonbasic, rho, T, ldt, tiled ? 1 : 0);
 }
 int tab_ld(int nn) { return ((nn + 511) / 512) * 512; }
 void launch_tab_permute_cols(const double *Tin, int ld_in, double *Tout, int ld_out, int m, int nn_out, const int32_t *srcpos,
@@ -312,30 +320,30 @@ void launch_tab_permute_cols(const double *Tin, int ld_in, double *Tout, int ld_
 }
 int tab_r_chunks(int m) { int c = (m + 63) / 64; return c > 64 ? 64 : c; }
 void launch_tab_r(const double *T, int ldt, int m, int nn, const double *cost, const int32_t *basic, const int32_t *nonbasic,
-                  double *scratch, double *r, hipStream_t s) {
+                  double *scratch, double *r, bool tiled, hipStream_t s) {
     const int nchunks = tab_r_chunks(m);
     const int rpc = (m + nchunks - 1) / nchunks;
     dim3 grid((ldt + kBlock - 1) / kBlock, nchunks);
-    hipLaunchKernelGGL(k_tab_r_partial, grid, dim3(kBlock), 0, s, T, ldt, m, nn, cost, basic, scratch, rpc);
+    hipLaunchKernelGGL(k_tab_r_partial, grid, dim3(kBlock), 0, s, T, ldt, m, nn, cost, basic, scratch, rpc, tiled ? 1 : 0);
     hipLaunchKernelGGL(k_tab_r_reduce, dim3((ldt + 255) / 256), dim3(256), 0, s, scratch, ldt, nn, nchunks, cost, nonbasic, r);
 }
 // out[jp] = T[row][jp] and out[ldt + jp] = max_i |T[i][jp]| for every nonbasic position: what the exchange of a
 // zero-level artificial (simplex.go:581-606) needs to rank ALL candidate columns in one pass instead of one
 // column fetch + host round trip per candidate
-__global__ void k_tab_row_colmax(const double *__restrict__ T, int ldt, int m, int nn, int row, double *__restrict__ out) {
+__global__ void k_tab_row_colmax(const double *__restrict__ T, int ldt, int m, int nn, int row, double *__restrict__ out, int tiled) {
     const int jp = blockIdx.x * blockDim.x + threadIdx.x;
     if (jp >= nn) return;
     double mx = 0;
-    for (int i = 0; i < m; i++) mx = fmax(mx, fabs(T[(size_t)i * ldt + jp]));
-    out[jp] = T[(size_t)row * ldt + jp];
+    for (int i = 0; i < m; i++) mx = fmax(mx, fabs(T[tab_idx(i, jp, ldt, tiled)]));
+    out[jp] = T[tab_idx(row, jp, ldt, tiled)];
     out[ldt + jp] = mx;
 }
-void launch_tab_row_colmax(const double *T, int ldt, int m, int nn, int row, double *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_tab_row_colmax, dim3((nn + 255) / 256), dim3(256), 0, s, T, ldt, m, nn, row, out);
+void launch_tab_row_colmax(const double *T, int ldt, int m, int nn, int row, double *out, bool tiled, hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_row_colmax, dim3((nn + 255) / 256), dim3(256), 0, s, T, ldt, m, nn, row, out, tiled ? 1 : 0);
 }
 
-void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb, double *dvec, double *move, hipStream_t s) {
-    hipLaunchKernelGGL(k_tab_column, dim3((m + 255) / 256), dim3(256), 0, s, T, ldt, m, jp, xb, dvec, move);
+void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb, double *dvec, double *move, bool tiled, hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_column, dim3((m + 255) / 256), dim3(256), 0, s, T, ldt, m, jp, xb, dvec, move, tiled ? 1 : 0);
 }
 
 }  // namespace gomilp
