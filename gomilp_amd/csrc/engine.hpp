@@ -130,7 +130,7 @@ int launch_tableau_pivot(const TabArgs &a, int flags, int nparts, long long t, h
 void launch_tab_gather(const double *At, int ld, int m, int nn, const int32_t *nonbasic, const int32_t *rho, double *T, int ldt,
                        bool tiled, hipStream_t s);
 void launch_tab_permute_cols(const double *Tin, int ld_in, double *Tout, int ld_out, int m, int nn_out, const int32_t *srcpos,
-                             hipStream_t s);
+                             bool tiled, hipStream_t s);
 int tab_r_chunks(int m);
 void launch_tab_r(const double *T, int ldt, int m, int nn, const double *cost, const int32_t *basic, const int32_t *nonbasic,
                   double *scratch, double *r, bool tiled, hipStream_t s);

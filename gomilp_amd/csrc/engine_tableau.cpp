@@ -419,8 +419,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
                 for (int jp = 0; jp < nn; jp++) pos_of[nonbasic[jp]] = jp;
                 for (int jp = 0; jp < nn; jp++) srcpos[jp] = pos_of[asc[jp]];
                 if ((rc = stage_upload(w.srcpos, srcpos.data(), (size_t)nn * sizeof(int32_t))) != GOMILP_OK) return rc;
-                bt_layout(P, false);
-                launch_tab_permute_cols(w.T[tcur_], ldt_, w.T[tcur_ ^ 1], ldt_, m, nn, w.srcpos, stream_);
+                launch_tab_permute_cols(w.T[tcur_], ldt_, w.T[tcur_ ^ 1], ldt_, m, nn, w.srcpos, t_tiled_, stream_);
                 launches_++;
                 tcur_ ^= 1;
                 nonbasic = asc;
@@ -502,8 +501,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         for (int jp = 0; jp < nn2; jp++) srcpos[jp] = pos_of[nonbasic[jp]];
         if ((rc = stage_upload(w.srcpos, srcpos.data(), (size_t)nn2 * sizeof(int32_t))) != GOMILP_OK) return rc;
         const int ldt2 = tab_ld(nn2);
-        bt_layout(P, false);
-        launch_tab_permute_cols(w.T[tcur_], ldt_, w.T[tcur_ ^ 1], ldt2, m, nn2, w.srcpos, stream_);
+        launch_tab_permute_cols(w.T[tcur_], ldt_, w.T[tcur_ ^ 1], ldt2, m, nn2, w.srcpos, t_tiled_, stream_);
         launches_++;
         tcur_ ^= 1;
         ldt_ = ldt2;

@@ -245,10 +245,10 @@ __global__ void k_tab_gather(const double *__restrict__ At, int ld, int m, int n
 
 // T_out[:, jp] = T_in[:, src[jp]]  (Phase I -> Phase II: nonbasic list rebuilt in ascending variable order)
 __global__ void k_tab_permute_cols(const double *__restrict__ Tin, int ld_in, double *__restrict__ Tout, int ld_out, int m,
-                                   int nn_out, const int32_t *__restrict__ srcpos) {
-    const int i = blockIdx.y;
+                                   int nn_out, const int32_t *__restrict__ srcpos, int tiled) {
+    const int i = blockIdx.y;   // tiled: the padding rows m..m4 are written too (zeros)
     const int jp = blockIdx.x * blockDim.x + threadIdx.x;
-    if (jp < ld_out) Tout[(size_t)i * ld_out + jp] = (jp < nn_out) ? Tin[(size_t)i * ld_in + srcpos[jp]] : 0.0;
+    if (jp < ld_out) Tout[tab_idx(i, jp, ld_out, tiled)] = (jp < nn_out && i < m) ? Tin[tab_idx(i, srcpos[jp], ld_in, tiled)] : 0.0;
 }
 
 // r[jp] = cost[nonbasic[jp]] - sum_i cost[basic[i]] * T[i, jp]   (row-chunked, fixed-order reduction)
@@ -314,9 +314,9 @@ void launch_tab_gather(const double *At, int ld, int m, int nn, const int32_t *n
 }
 int tab_ld(int nn) { return ((nn + 511) / 512) * 512; }
 void launch_tab_permute_cols(const double *Tin, int ld_in, double *Tout, int ld_out, int m, int nn_out, const int32_t *srcpos,
-                             hipStream_t s) {
-    dim3 grid((ld_out + 255) / 256, m);
-    hipLaunchKernelGGL(k_tab_permute_cols, grid, dim3(256), 0, s, Tin, ld_in, Tout, ld_out, m, nn_out, srcpos);
+                             bool tiled, hipStream_t s) {
+    dim3 grid((ld_out + 255) / 256, tiled ? ((m + 3) & ~3) : m);
+    hipLaunchKernelGGL(k_tab_permute_cols, grid, dim3(256), 0, s, Tin, ld_in, Tout, ld_out, m, nn_out, srcpos, tiled ? 1 : 0);
 }
 int tab_r_chunks(int m) { int c = (m + 63) / 64; return c > 64 ? 64 : c; }
 void launch_tab_r(const double *T, int ldt, int m, int nn, const double *cost, const int32_t *basic, const int32_t *nonbasic,
