@@ -691,8 +691,9 @@ __global__ __launch_bounds__(kBlock) void k_bt_update(BTArgs a, int rows_per_wg)
 // the column a gather of m separate 128-byte lines (8 useful bytes each) through ONE CU's L1 — 256 KB of fill traffic
 // per pivot at m = 2048, the largest item of the pivot's critical path.  In 4x4 tiles (one tile = one 128-byte line,
 // tile (I, J) at ((I * ldt/4) + J) * 16, element (i&3)*4 + (j&3)) a column and a row both touch m/4 resp. (n-m)/4
-// lines: 4x less fill for the column, 4x more for the (cheap) row, half in total.  The layout is private to the block
-// loop: k_bt_tile converts on entry and exit (two streaming passes per pivot LOOP, not per pivot).
+// lines: 4x less fill for the column, 4x more for the (cheap) row, half in total.  The tableau set-up kernels
+// (tableau_kernels.hip: tab_idx) read and write either layout, so the blocked pipeline is tiled from the start;
+// k_bt_tile converts only when a caller mixes pipelines.
 __device__ __forceinline__ unsigned int tile_off(unsigned int i, unsigned int j, unsigned int ldt) {
     return ((i >> 2) * (ldt >> 2) + (j >> 2)) * 16u + ((i & 3u) << 2) + (j & 3u);
 }
