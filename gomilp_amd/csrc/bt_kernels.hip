@@ -592,6 +592,12 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
                 ureg[s][0] = u;
             }
         }
+        // a host-chosen set-up pivot may leave the lists alone (forced_nocommit 1: the host uploads new ones) or exchange
+        // them without being counted or traced as a pivot of the loop (2)
+        if (tid == 0 && forced && a.forced_nocommit == 2) {
+            const int ent = nonbasic_s[q], lea = basic_s[p];
+            basic_s[p] = ent; nonbasic_s[q] = lea;
+        }
         if (tid == 0 && !(forced && a.forced_nocommit)) {  // simplex.go:280
             const int ent = nonbasic_s[q], lea = basic_s[p];
             basic_s[p] = ent; nonbasic_s[q] = lea;

@@ -399,17 +399,23 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return rc;
         if ((rc = set_up_T(nn)) != GOMILP_OK) return rc;
         const int qa = nn - 1;  // position of the artificial
-        launch_tab_column(w.T[0], ldt_, m, qa, w.xb, w.dvec, w.move, t_tiled_, stream_);
-        launches_++;
+        if (!use_bt_) {   // the single-kernel pipeline's forced pivot takes the column from dvec; the block kernel reads T itself
+            launch_tab_column(w.T[0], ldt_, m, qa, w.xb, w.dvec, w.move, t_tiled_, stream_);
+            launches_++;
+        }
         double dp = 0;  // pivot element of the forced pivot: (B^-1 a_art)[minidx]
         if (!binv_host) dp = art[rho[minidx]];
         else for (int i = 0; i < m; i++) dp += (*binv_host)[(size_t)minidx * m + i] * art[i];
         const int slack = basic[minidx];
-        if (use_bt_) rc = bt_forced_pivot(P, 1, 1e-10, nn, qa, (int)minidx, 1);
+        // the register-resident block kernel exchanges the two list entries itself (uncounted), which saves the second
+        // upload of the lists when no re-sort follows
+        const bool swap_on_device = use_bt_ && t_tiled_;
+        if (use_bt_) rc = bt_forced_pivot(P, 1, 1e-10, nn, qa, (int)minidx, swap_on_device ? 2 : 1);
         else rc = tab_forced_pivot(P, 1, 1e-10, nn, qa, n, 0.0, (int)minidx, dp, xb[minidx], slack, 4, 0);
         if (rc != GOMILP_OK) return rc;
         basic[minidx] = n;
         nonbasic[qa] = slack;  // slack basis: ascending order is preserved (every structural id < slack id < n)
+        bool lists_current = swap_on_device;
         {
             // general basis: the replaced variable may belong earlier in the ascending list of simplex.go:174-184
             std::vector<int32_t> asc = nonbasic;
@@ -423,9 +429,10 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
                 launches_++;
                 tcur_ ^= 1;
                 nonbasic = asc;
+                lists_current = false;
             }
         }
-        if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return rc;
+        if (!lists_current && (rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return rc;
         launch_tab_r(w.T[tcur_], ldt_, m, nn, P.dc1, w.basic, w.nonbasic, w.tscratch, w.R[rcur_], t_tiled_, stream_);
         launches_ += 2;
         // the Phase-I starting vertex must be feasible (initializeFromBasic inside the recursive call panics otherwise,
