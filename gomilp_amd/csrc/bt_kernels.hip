@@ -315,7 +315,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
 __device__ __forceinline__ unsigned int tile_off(unsigned int i, unsigned int j, unsigned int ldt);
 struct BtWin { double m; unsigned int i; };   // minimum and the first index that attains it (0xFFFFFFFF: none, all NaN)
 
-template <int NT, int RI, int CJ, int KR>
+template <int NT, int RI, int CJ, int KR, int VL>
 __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double sh2[];
@@ -324,6 +324,11 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
     double *r_s = sh2 + RI * NT;     // CJ*NT  needed); kept out of the register file, which the block terms fill
     int *basic_s = reinterpret_cast<int *>(sh2 + RI * NT + CJ * NT);  // RI*NT  only thread 0 touches the lists in the loop
     int *nonbasic_s = basic_s + RI * NT;                              // CJ*NT
+    // the block terms v'_k of the LAST VL column slots live in LDS (a ring over k: no shifting), the others in registers:
+    // at NT = 1024 the register file holds 128 VGPRs per thread, 16 short of what all terms in registers need
+    double *vl_s = reinterpret_cast<double *>(nonbasic_s + CJ * NT);   // VL*KR*NT, element (slot, ring position, thread)
+    constexpr int CR = CJ - VL;   // column slots with register-resident terms
+    int vhead = 0;                // ring position of the newest term
     __shared__ double redMA[16], redMB[16];
     __shared__ unsigned int redIA[16], redIB[16];
     __shared__ double payA[16][KR + 1];  // per wave: r_q, v'_k[q]
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
         if (tid == 0) st->kdone = 0;
         return;
     }
-    double ureg[RI][KR], vreg[CJ][KR];
+    double ureg[RI][KR], vreg[CR > 0 ? CR : 1][KR];
 #pragma unroll
     for (int s = 0; s < RI; s++) {
         const int i = tid + s * NT;
@@ -371,7 +376,10 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
         r_s[j] = r0[s];
         nonbasic_s[j] = n0[s];
 #pragma unroll
-        for (int j2 = 0; j2 < KR; j2++) vreg[s][j2] = 0;
+        for (int j2 = 0; j2 < KR; j2++) {
+            if (s < CR) vreg[s < CR ? s : 0][j2] = 0;
+            else vl_s[((s - CR) * KR + j2) * NT + tid] = 0;
+        }
     }
     if (tid < KR + 1) payA[0][tid] = 0;   // a host-chosen first pivot reads v'_k[q] = 0 from here
     __syncthreads();
@@ -414,7 +422,8 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
             if ((unsigned int)(tid + s * NT) == w.i) {
                 payA[wv][0] = r_s[tid + s * NT];
 #pragma unroll
-                for (int j = 0; j < KR; j++) payA[wv][1 + j] = vreg[s][j];
+                for (int j = 0; j < KR; j++)   // newest first
+                    payA[wv][1 + j] = s < CR ? vreg[s < CR ? s : 0][j] : vl_s[((s - CR) * KR + ((vhead - j) & (KR - 1))) * NT + tid];
             }
         if (lane == 0) { redMA[wv] = w.m; redIA[wv] = w.i; }
         __syncthreads();
@@ -569,17 +578,27 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
             const int j = tid + s * NT;
             if (j < a.ldt) {
                 double v = ldT(tile_off((unsigned int)p, (unsigned int)j, ldt));   // columns nn..ldt of T are zero
+                if (s < CR) {
 #pragma unroll
-                for (int jj = 0; jj < KR; jj++) v = __builtin_fma(up[jj], vreg[s][jj], v);
+                    for (int jj = 0; jj < KR; jj++) v = __builtin_fma(up[jj], vreg[s < CR ? s : 0][jj], v);
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < KR; jj++) v = __builtin_fma(up[jj], vl_s[((s - CR) * KR + ((vhead - jj) & (KR - 1))) * NT + tid], v);
+                }
                 // reduced costs (positional): r_j - (r_q/d_p) v_j ; the leaving variable takes slot q
                 r_s[j] = (j == q) ? -mult : __builtin_fma(-mult, v, r_s[j]);
                 const double vprime = (j == q) ? dpv + 1.0 : v;
                 *reinterpret_cast<double *>(Vk + ((unsigned int)j << 3)) = vprime;
+                if (s < CR) {
 #pragma unroll
-                for (int jj = KR - 1; jj > 0; jj--) vreg[s][jj] = vreg[s][jj - 1];
-                vreg[s][0] = vprime;
+                    for (int jj = KR - 1; jj > 0; jj--) vreg[s < CR ? s : 0][jj] = vreg[s < CR ? s : 0][jj - 1];
+                    vreg[s < CR ? s : 0][0] = vprime;
+                } else {
+                    vl_s[((s - CR) * KR + ((vhead + 1) & (KR - 1))) * NT + tid] = vprime;   // becomes the newest once vhead advances
+                }
             }
         }
+        vhead = (vhead + 1) & (KR - 1);
 #pragma unroll
         for (int s = 0; s < RI; s++) {
             const int i = tid + s * NT;
@@ -826,10 +845,19 @@ template <int NT>
 static void bt_launch_nt(const BTArgs &a, const BtCfg &c, bool reg, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
 #define GOMILP_BT_LAUNCH(RI, CJ, KR) hipExtLaunchKernelGGL((k_bt_inner<NT, RI, CJ, KR>), dim3(1), dim3(NT), lds, s, e0, e1, 0, a)
     if (a.tiled) {   // register-resident kernel on the tiled layout (the engine converted T: bt_tiled())
+        constexpr int VL2 = NT >= 1024 ? 1 : 0;   // terms of the last column slot in LDS where the register budget is 128
         const size_t lds2 = (size_t)(c.ri + c.cj) * NT * (sizeof(double) + sizeof(int));
-        if (c.ri == 2) { hipExtLaunchKernelGGL((k_bt_inner2<NT, 2, 2, 8>), dim3(1), dim3(NT), lds2, s, e0, e1, 0, a); return; }
+        if (c.ri == 2) {
+            const size_t lds = lds2 + (size_t)VL2 * 8 * NT * sizeof(double);
+            if (lds > 64 * 1024) {
+                static bool attr = false;
+                if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner2<NT, 2, 2, 8, VL2>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); attr = true; }
+            }
+            hipExtLaunchKernelGGL((k_bt_inner2<NT, 2, 2, 8, VL2>), dim3(1), dim3(NT), lds, s, e0, e1, 0, a);
+            return;
+        }
         if constexpr (NT <= 512) {
-            if (c.ri == 4) { hipExtLaunchKernelGGL((k_bt_inner2<NT, 4, 4, 8>), dim3(1), dim3(NT), lds2, s, e0, e1, 0, a); return; }
+            if (c.ri == 4) { hipExtLaunchKernelGGL((k_bt_inner2<NT, 4, 4, 8, 0>), dim3(1), dim3(NT), lds2, s, e0, e1, 0, a); return; }
         }
         return;   // unreachable: bt_tiled() admits exactly the two shapes above
     }
