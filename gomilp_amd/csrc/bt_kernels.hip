@@ -303,8 +303,10 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
 // ---- register-resident variant (m <= RI*NT, ldt <= CJ*NT, KR block terms in registers) ----------------------------
 // k_bt_inner above is VALU-issue bound (about 1600 instructions per wave and pivot, 4 waves per SIMD): (key, index)
 // candidates dragged through 64-bit integer compares, five barriers, r / x_B traffic through LDS.  This variant:
-//  * a thread's OWN r_j, u_k[i], v_k'[j] live in registers, x_B[i] in LDS slots only its owner touches;
-//  * first-index argmin without index payloads: v_min_f64 over DPP row shifts gives the minimum M, then
+//  * a thread's OWN block terms u_k[i], v_k'[j] live in registers (newest first, shifted each pivot) — except the v'
+//    terms of the last VL column slots, which sit in an LDS ring over k where 128 VGPRs per thread (NT = 1024) are not
+//    enough; its r_j and x_B[i] in LDS slots only the owner touches: no barrier guards any of it;
+//  * first-index argmin without index payloads: v_min_f64 over DPP row rotations gives the minimum M, then
 //    ballot(value == M) + ff1 gives the first lane, slot by slot — exactly floats.MinIdx (NaN never wins because
 //    v_min_f64 returns the other operand, -0 == +0, first index among equals);
 //  * the lane that owns a wave's winner publishes, next to the wave's (M, index), the scalars everybody needs about
