@@ -398,3 +398,26 @@ def test_random_roots_and_children_sweep(ctx):
                 cons.append((int(j), 1, fl) if rng.random() < 0.5 else (int(j), -1, -(fl + 1)))
             c, A, b = O.child_standard_form(c, A, b, cons)
         _check_against_oracle(ctx, c, A, b)
+
+
+@pytest.mark.parametrize("m,seed", [(1100, 14), (1300, 15), (2048, 2)])
+def test_1024_thread_block_kernel_vs_single_kernel_pipeline(m, seed):
+    """Sizes beyond 1024 rows run the 1024-thread register-resident kernel (LDS ring for one column slot's terms).  The
+    CPU oracle needs minutes there (tools/parity_big.py: identical), so the suite checks the blocked pipeline against the
+    single-kernel tableau pipeline — a different formulation validated against the oracle at the small sizes above:
+    same pivot sequence, same basis, bit-identical x."""
+    c, A, b = synth.dense_lp_standard_form(m, seed)
+    res = []
+    for blocked in (1, 0):
+        cx = lp.Context(blocked=blocked)
+        try:
+            rl = cx.upload(c, A, b)
+            res.append(rl.solve(0.0, trace=True))
+            rl.free()
+        finally:
+            cx.close()
+    g, t = res
+    assert g.stats["pipeline"] == "blocked" and t.stats["pipeline"] == "tableau"
+    assert g.status == lp.OK == t.status
+    assert _same_trace(g.pivots, t.pivots)
+    assert np.array_equal(g.basis, t.basis) and np.array_equal(g.x, t.x) and g.z == t.z
