@@ -36,6 +36,7 @@ namespace gomilp {
 constexpr int kBtThreads = 1024;
 constexpr int kBtWaves = kBtThreads / 64;
 constexpr int kBtMaxK = 32;
+constexpr int kStampSegs = 16;   // == kBtStampSegs (engine.hpp)
 
 // RI / CJ: rows / columns per thread (m <= RI*1024, n-m <= CJ*1024).
 // KREG > 0: the block's rank-1 terms of a thread's OWN rows / columns live in registers (newest first, shifted
@@ -317,9 +318,27 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
 __device__ __forceinline__ unsigned int tile_off(unsigned int i, unsigned int j, unsigned int ldt);
 struct BtWin { double m; unsigned int i; };   // minimum and the first index that attains it (0xFFFFFFFF: none, all NaN)
 
-template <int NT, int RI, int CJ, int KR, int VL>
+template <int NT, int RI, int CJ, int KR, int VL, bool STAMP = false>
 __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
     constexpr int NW = NT / 64;
+    // STAMP: diagnostic build (context knob "bt_stamps"): every wave sums the shader cycles it spends in each segment of
+    // a pivot (s_memtime, cdna_hip_programming.md §7 "In-kernel stamps") and adds them to a.stamps[wave][segment]; the
+    // loads are waited for where a segment ends, so this build's run time is not the product kernel's
+    unsigned long long tacc[kStampSegs] = {};
+    unsigned long long tprev = 0;
+    auto stamp = [&](auto seg) {
+        if constexpr (STAMP) {
+            unsigned long long t;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int S = decltype(seg)::value;
+            if (S >= 0) tacc[S >= 0 ? S : 0] += t - tprev;
+            tprev = t;
+        }
+    };
+    auto drain = [&]() { if constexpr (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+#define BT_STAMP(S) stamp(std::integral_constant<int, S>())
     extern __shared__ __attribute__((aligned(16))) double sh2[];
     // fixed offsets (not a.ldu / a.ldt): every slot address is 8*tid + a compile-time constant, one VGPR for all of them
     double *xb_s = sh2;              // RI*NT  x_B and r: every thread touches only its own rows / columns (no barrier
@@ -428,11 +447,14 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
                     payA[wv][1 + j] = s < CR ? vreg[s < CR ? s : 0][j] : vl_s[((s - CR) * KR + ((vhead - j) & (KR - 1))) * NT + tid];
             }
         if (lane == 0) { redMA[wv] = w.m; redIA[wv] = w.i; }
+        BT_STAMP(0);    // r from LDS, wave-level first-min, payload
         __syncthreads();
+        BT_STAMP(1);    // barrier A
         const BtWin f = block_first_min(redMA, redIA);
         const int ww = (f.i & (NT - 1)) >> 6;
         rq = payA[ww][0];
         vq = &payA[ww][1];
+        BT_STAMP(2);    // block-level first-min A
         return f;
     };
     // leaving row: returns (min, p); d_p, x_B[p] and u_k[p] through payB
@@ -447,16 +469,39 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
                 for (int j = 0; j < KR; j++) payB[wv][2 + j] = ureg[s][j];
             }
         if (lane == 0) { redMB[wv] = w.m; redIB[wv] = w.i; }
+        BT_STAMP(5);    // ratios, wave-level first-min, payload
         __syncthreads();
+        BT_STAMP(6);    // barrier B
         const BtWin f = block_first_min(redMB, redIB);
         const int ww = (f.i & (NT - 1)) >> 6;
         dp = payB[ww][0];
         xp = payB[ww][1];
         up = &payB[ww][2];
+        BT_STAMP(7);    // block-level first-min B
         return f;
     };
     // column q of the current tableau for this thread's rows
     auto column = [&](int q, const double *vq, double (&dcol)[RI]) {
+        if constexpr (STAMP) {
+#pragma unroll
+            for (int s = 0; s < RI; s++) {
+                const int i = tid + s * NT;
+                const unsigned int ic = (unsigned int)(i < a.m ? i : a.m - 1);
+                dcol[s] = ldT(tile_off(ic, (unsigned int)q, ldt));
+            }
+            drain();
+            BT_STAMP(3);   // column q of the stale tableau: issue -> data back
+#pragma unroll
+            for (int s = 0; s < RI; s++) {
+                const int i = tid + s * NT;
+                double d = dcol[s];
+#pragma unroll
+                for (int j = 0; j < KR; j++) d = __builtin_fma(ureg[s][j], vq[j], d);
+                dcol[s] = i < a.m ? d : 0.0;
+            }
+            BT_STAMP(4);   // block corrections of the column
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < RI; s++) {
             const int i = tid + s * NT;
@@ -488,6 +533,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
     };
 
     for (int k = 0; k < a.kmax; k++) {
+        BT_STAMP(-1);
         const bool forced = (k == 0 && a.forced_q >= 0);
         int q, p;
         double rq = 0, dpv = 1.0, xbp = 0;
@@ -575,11 +621,35 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
         const double rinv = 1.0 / dpv, nrinv = -rinv;
         char *Vk = reinterpret_cast<char *>(a.V + (size_t)k * a.ldt);
         char *Uk = reinterpret_cast<char *>(a.U + (size_t)k * a.ldu);
+        // the row loads go out first: the u terms / x_B update below need nothing from them and run under their latency
+        double vrow[CJ];
+#pragma unroll
+        for (int s = 0; s < CJ; s++) {
+            const int j = tid + s * NT;
+            vrow[s] = j < a.ldt ? ldT(tile_off((unsigned int)p, (unsigned int)j, ldt)) : 0.0;   // columns nn..ldt of T are zero
+        }
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            const int i = tid + s * NT;
+            if (i < a.ldu) {
+                const double u = (i == p) ? rinv - 1.0 : dcol[s] * nrinv;   // rows >= m: dcol = 0
+                if (i < a.m) xb_s[i] = (i == p) ? theta : __builtin_fma(-theta, dcol[s], xb_s[i]);
+                *reinterpret_cast<double *>(Uk + ((unsigned int)i << 3)) = u;
+#pragma unroll
+                for (int jj = KR - 1; jj > 0; jj--) ureg[s][jj] = ureg[s][jj - 1];
+                ureg[s][0] = u;
+            }
+        }
+        BT_STAMP(10);  // row loads issued; u terms, x_B, u store, term shift
+        if constexpr (STAMP) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RI) : "memory");   // the RI u stores behind the loads may stay in flight
+            BT_STAMP(8);   // what is left of the row-load latency
+        }
 #pragma unroll
         for (int s = 0; s < CJ; s++) {
             const int j = tid + s * NT;
             if (j < a.ldt) {
-                double v = ldT(tile_off((unsigned int)p, (unsigned int)j, ldt));   // columns nn..ldt of T are zero
+                double v = vrow[s];
                 if (s < CR) {
 #pragma unroll
                     for (int jj = 0; jj < KR; jj++) v = __builtin_fma(up[jj], vreg[s < CR ? s : 0][jj], v);
@@ -601,18 +671,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
             }
         }
         vhead = (vhead + 1) & (KR - 1);
-#pragma unroll
-        for (int s = 0; s < RI; s++) {
-            const int i = tid + s * NT;
-            if (i < a.ldu) {
-                const double u = (i == p) ? rinv - 1.0 : dcol[s] * nrinv;   // rows >= m: dcol = 0
-                if (i < a.m) xb_s[i] = (i == p) ? theta : __builtin_fma(-theta, dcol[s], xb_s[i]);
-                *reinterpret_cast<double *>(Uk + ((unsigned int)i << 3)) = u;
-#pragma unroll
-                for (int jj = KR - 1; jj > 0; jj--) ureg[s][jj] = ureg[s][jj - 1];
-                ureg[s][0] = u;
-            }
-        }
+        BT_STAMP(9);   // row corrections, reduced costs, v' store, term shift
         // a host-chosen set-up pivot may leave the lists alone (forced_nocommit 1: the host uploads new ones) or exchange
         // them without being counted or traced as a pivot of the loop (2)
         if (tid == 0 && forced && a.forced_nocommit == 2) {
@@ -631,6 +690,14 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
         }
         kd = k + 1;
     }
+    if constexpr (STAMP) {
+        if (a.stamps && lane == 0) {
+#pragma unroll
+            for (int sg = 0; sg < kStampSegs; sg++) a.stamps[wv * kStampSegs + sg] += tacc[sg];
+            if (wv == 0) a.stamps[16 * kStampSegs] += (unsigned long long)kd;   // pivots behind the sums
+        }
+    }
+#undef BT_STAMP
 #pragma unroll
     for (int s = 0; s < CJ; s++) {
         const int j = tid + s * NT;
@@ -819,9 +886,8 @@ int bt_max_k() { return kBtMaxK; }
 // with ONE wave per SIMD (256 threads) whenever the rows/columns per thread still fit in registers.
 // Register-resident block terms cost (RI + CJ) * KREG doubles per thread.
 struct BtCfg { int nt, ri, cj, kreg; };
-static BtCfg bt_cfg(int m, int ldt) {
+static BtCfg bt_cfg(int m, int ldt, int force) {   // force: context knob "bt_nt" (0 = by shape)
     auto per = [](int x, int nt) { return (x + nt - 1) / nt; };
-    static const int force = [] { const char *e = getenv("GOMILP_BT_NT"); return e ? atoi(e) : 0; }();   // developer knob, read once
     for (int nt : {256, 512, 1024}) {
         if (force && nt != force) continue;
         const int r = std::max(per(m, nt), per(ldt, nt));
@@ -842,7 +908,7 @@ bool bt_supported(int m, int nn) {  // r, x_B (doubles) and the two index lists 
     const long ldt = ((nn + 511) / 512) * 512, ldu = (m + 1) & ~1;
     return m <= 8 * 1024 && ldt <= 8 * 1024 && (ldt + ldu) * 12 <= 140 * 1024;
 }
-int bt_reg_k(int m, int ldt) { return bt_cfg(m, ldt).kreg; }
+int bt_reg_k(int m, int ldt, int nt_force) { return bt_cfg(m, ldt, nt_force).kreg; }
 template <int NT>
 static void bt_launch_nt(const BTArgs &a, const BtCfg &c, bool reg, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
 #define GOMILP_BT_LAUNCH(RI, CJ, KR) hipExtLaunchKernelGGL((k_bt_inner<NT, RI, CJ, KR>), dim3(1), dim3(NT), lds, s, e0, e1, 0, a)
@@ -854,6 +920,14 @@ static void bt_launch_nt(const BTArgs &a, const BtCfg &c, bool reg, size_t lds, 
             if (lds > 64 * 1024) {
                 static bool attr = false;
                 if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner2<NT, 2, 2, 8, VL2>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); attr = true; }
+            }
+            if (a.stamps) {
+                if constexpr (NT >= 512) {   // diagnostic build: the two instances the headline sizes run
+                    static bool attr2 = false;
+                    if (!attr2) { hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner2<NT, 2, 2, 8, VL2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); attr2 = true; }
+                    hipExtLaunchKernelGGL((k_bt_inner2<NT, 2, 2, 8, VL2, true>), dim3(1), dim3(NT), lds, s, e0, e1, 0, a);
+                    return;
+                }
             }
             hipExtLaunchKernelGGL((k_bt_inner2<NT, 2, 2, 8, VL2>), dim3(1), dim3(NT), lds, s, e0, e1, 0, a);
             return;
@@ -876,16 +950,15 @@ void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner<1024, 8, 8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
         attr_done = true;
     }
-    const BtCfg c = bt_cfg(a.m, a.ldt);
+    const BtCfg c = bt_cfg(a.m, a.ldt, a.nt_force);
     const bool reg = c.kreg > 0 && a.kmax <= c.kreg;
     if (c.nt == 256) bt_launch_nt<256>(a, c, reg, lds, s, e0, e1);
     else if (c.nt == 512) bt_launch_nt<512>(a, c, reg, lds, s, e0, e1);
     else bt_launch_nt<1024>(a, c, reg, lds, s, e0, e1);
 }
 // true when launch_bt_inner picks the register-resident kernel, which works on the tiled layout of T
-bool bt_tiled(int m, int ldt, int kmax) {
-    const BtCfg c = bt_cfg(m, ldt);
-    static const bool old_only = getenv("GOMILP_BT_OLD") != nullptr;   // developer knob, read once
+bool bt_tiled(int m, int ldt, int kmax, int nt_force, bool old_only) {
+    const BtCfg c = bt_cfg(m, ldt, nt_force);
     if (old_only || !(c.kreg > 0 && kmax <= c.kreg)) return false;
     return c.ri == 2 || (c.ri == 4 && c.nt <= 512);
 }

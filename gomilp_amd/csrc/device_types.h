@@ -121,8 +121,9 @@ struct BTArgs {
     DevPivot *trace;
     int64_t trace_cap;
     int32_t forced_q, forced_p, forced_nocommit;  // first pivot of the block chosen by the host (set-up pivots)
-    int32_t pad;
-    int32_t tiled, pad2;  // T is in the 4x4-tile layout of the register-resident inner kernel
+    int32_t nt_force;     // context knob "bt_nt": 0 = pick the thread count by shape, else 256 / 512 / 1024
+    int32_t tiled, old_only;  // T is in the 4x4-tile layout of the register-resident inner kernel; knob "bt_old"
+    unsigned long long *stamps;   // diagnostic build only (knob "bt_stamps"): per-wave cycle sums per pivot segment
 };
 
 // Control block of the compressed LU schedule (lu_compressed.hip): written by the panel kernel of a round, read by the

@@ -43,6 +43,9 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "lu_blocked") lu_blocked_ = v < 0 ? 0 : (v > 2 ? 2 : v);  // 0 per column, 1 blocked panels, 2 compressed rounds
     else if (key == "tableau") tableau_ = v ? 1 : 0;
     else if (key == "blocked") blocked_ = v ? 1 : 0;
+    else if (key == "bt_nt") { if (v != 0 && v != 256 && v != 512 && v != 1024) return GOMILP_ERR_BAD_SHAPE; bt_nt_ = v; }
+    else if (key == "bt_old") bt_old_ = v ? 1 : 0;
+    else if (key == "bt_stamps") bt_stamps_ = v ? 1 : 0;
     else if (key == "block_k") { if (v < 0 || v > bt_max_k()) return GOMILP_ERR_BAD_SHAPE; block_k_ = v; }
     else return GOMILP_ERR_BAD_SHAPE;
     return GOMILP_OK;
@@ -918,7 +921,9 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
         }
     }
     const int nn_max = n + 1 - m;
-    const bool use_tab = tableau_ && (n - m) < 2 * m && (size_t)tab_ld(nn_max) * sizeof(double) <= 64 * 1024;
+    // a non-slack starting basis (equality rows, supplied basis) always takes the tableau pipelines: their set-up accepts
+    // any B^-1; the n - m < 2m rule is only the bytes-per-pivot trade-off between the two formulations
+    const bool use_tab = tableau_ && ((n - m) < 2 * m || !unit_basis) && (size_t)tab_ld(nn_max) * sizeof(double) <= 64 * 1024;
     std::vector<double> xb(m, 0.0), binv_host;
     bool feasible = true;
     if (unit_basis) {
@@ -962,20 +967,28 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     // pipeline choice: the explicit tableau moves 16*m*(n-m) bytes per pivot in one launch, the revised form
     // 8*[m(n-m) + 2m^2] in two: the tableau wins while n - m < 2m
     use_bt_ = use_tab && blocked_ && bt_supported(m, nn_max);
-    st->reserved = use_tab ? (use_bt_ ? 3 : 2) : ((fused_ && fused_supported(P.ld)) ? 1 : 0);
+    st->pipeline = use_tab ? (use_bt_ ? 3 : 2) : ((fused_ && fused_supported(P.ld)) ? 1 : 0);
     int loop_rc = GOMILP_OK;
     if (use_tab) {
         const int ldt = tab_ld(nn_max);
         if (w.cap_T < (size_t)(m + 3) * ldt || w.cap_ldt < ldt) {   // + 3 rows: the tiled layout pads m to a multiple of 4
-            for (double **pp : {&w.T[0], &w.T[1], &w.R[0], &w.R[1], &w.tscratch, &w.btU, &w.btV}) { if (*pp) hipFree(*pp); *pp = nullptr; }
+            for (double **pp : {&w.T[0], &w.T[1], &w.R[0], &w.R[1], &w.tscratch, &w.btV}) { if (*pp) hipFree(*pp); *pp = nullptr; }
             if (w.srcpos) hipFree(w.srcpos); w.srcpos = nullptr;
             const size_t cap = std::max(w.cap_T, (size_t)(m + 3 + 32 + m / 16) * ldt);   // head-room for deeper children
             const int cl = std::max(w.cap_ldt, ldt);
             HIP_TRY(dmalloc(&w.T[0], cap)); HIP_TRY(dmalloc(&w.T[1], cap));
             HIP_TRY(dmalloc(&w.R[0], (size_t)cl)); HIP_TRY(dmalloc(&w.R[1], (size_t)cl));
             HIP_TRY(dmalloc(&w.tscratch, (size_t)64 * cl)); HIP_TRY(dmalloc(&w.srcpos, (size_t)cl));
-            HIP_TRY(dmalloc(&w.btU, (size_t)bt_max_k() * (w.cap_ld > P.ld ? w.cap_ld : P.ld))); HIP_TRY(dmalloc(&w.btV, (size_t)bt_max_k() * cl));
-            w.cap_T = cap; w.cap_ldt = cl;
+            HIP_TRY(dmalloc(&w.btV, (size_t)bt_max_k() * cl));
+            w.cap_T = cap; w.cap_ldt = cl; w.cap_btU = 0;
+        }
+        // the rank-1 u terms are rows of P.ld doubles: sized by the ROW count, which can grow while the T buffers
+        // (sized by m * ldt) still fit — a wide problem followed by a taller, narrower one on the same context
+        if (w.cap_btU < (size_t)bt_max_k() * (size_t)P.ld) {
+            if (w.btU) hipFree(w.btU); w.btU = nullptr;
+            const size_t cap = (size_t)bt_max_k() * (size_t)std::max(w.cap_ld, P.ld);
+            HIP_TRY(dmalloc(&w.btU, cap));
+            w.cap_btU = cap;
         }
         if (!use_bt_) {   // the blocked kernels never read the padding of r
             HIP_TRY(hipMemsetAsync(w.R[0], 0, (size_t)w.cap_ldt * sizeof(double), stream_));
@@ -1068,6 +1081,7 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
                 cur_ ^= 1;
                 basic[added] = j;
                 exchanged = true;
+                st->art_exchanges++;
             }
             if (!exchanged) return finish(GOMILP_ERR_INFEASIBLE);  // :606
         }

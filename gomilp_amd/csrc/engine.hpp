@@ -90,7 +90,8 @@ class Engine {
     std::vector<std::unique_ptr<Problem>> child_pool_;  // released children, buffers kept
     std::unique_ptr<Work> w_;
     // knobs
-    int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 2, tableau_ = 1, blocked_ = 1, block_k_ = 0;  // block_k_ 0 = auto
+    int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 2, tableau_ = 1, blocked_ = 1, block_k_ = 0,  // block_k_ 0 = auto
+            bt_nt_ = 0, bt_old_ = 0, bt_stamps_ = 0;   // developer knobs of the block kernels (per context: tests force the 1024-thread instance)
     // per-solve state
     int cur_ = 0;   // which Binv buffer is current
     int ycur_ = 0;  // which y buffer is current
@@ -139,8 +140,9 @@ void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb
 // bt_kernels.hip
 bool bt_supported(int m, int nn);
 int bt_max_k();
-int bt_reg_k(int m, int ldt);
-bool bt_tiled(int m, int ldt, int kmax);
+int bt_reg_k(int m, int ldt, int nt_force);
+bool bt_tiled(int m, int ldt, int kmax, int nt_force, bool old_only);
+constexpr int kBtStampSegs = 16;   // cycle sums per wave written by the diagnostic build of k_bt_inner2
 void launch_bt_tile(const double *src, double *dst, int m, int ldt, bool to_tiles, hipStream_t s);
 void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 void launch_bt_update(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);

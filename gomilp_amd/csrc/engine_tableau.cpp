@@ -1,6 +1,7 @@
 // Host control of the single-kernel tableau pipeline (tableau_kernels.hip).  Same reference control flow as
 // engine.cpp (simplex.go:93-302); only the per-pivot device work differs: T = B^-1 A_N is kept explicitly and
 // one launch applies a whole pivot.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "engine_work.hpp"
@@ -205,6 +206,8 @@ BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int
     a.basic = w.basic; a.nonbasic = w.nonbasic; a.st = w.st;
     a.trace = trace_on_ ? w.trace : nullptr; a.trace_cap = w.trace_cap;
     a.forced_q = a.forced_p = -1; a.forced_nocommit = 0;
+    a.nt_force = (int)bt_nt_; a.old_only = bt_old_ ? 1 : 0;
+    a.stamps = bt_stamps_ ? w.stamps : nullptr;
     return a;
 }
 
@@ -214,7 +217,7 @@ int Engine::bt_forced_pivot(const Problem &P, int phase, double tol, int nn, int
     DevState &hs = *w.st_host;
     hs.done = 0; hs.status = ST_RUNNING; hs.kdone = 0;
     sync_state_to_device();
-    bt_layout(P, bt_tiled(P.m, ldt_, 1));
+    bt_layout(P, bt_tiled(P.m, ldt_, 1, (int)bt_nt_, bt_old_ != 0));
     BTArgs a = make_bt_args(P, phase, tol, nn, 1);
     a.forced_q = q; a.forced_p = p; a.forced_nocommit = nocommit;
     launch_bt_inner(a, stream_, nullptr, nullptr);
@@ -229,11 +232,19 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
     DevState &hs = *w.st_host;
     hs.done = 0; hs.status = ST_RUNNING; hs.pivots = 0; hs.kdone = 0; hs.bland_steps = 0; hs.lu_singular = 0;
     sync_state_to_device();
+    if (bt_stamps_) {   // diagnostic build of the block kernel: cycle sums per wave and pivot segment
+        const size_t nb = (size_t)(16 * kBtStampSegs + 8) * sizeof(unsigned long long);
+        if (!w.stamps) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.stamps), nb));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.stamps_host), nb, hipHostMallocDefault));
+        }
+        HIP_TRY(hipMemsetAsync(w.stamps, 0, nb, stream_));
+    }
     const double t_loop0 = now_s();
     int ret = GOMILP_OK;
     // block size: 8 when the block's rank-1 terms fit in registers (bt_kernels.hip), else 16
-    const int K = block_k_ > 0 ? (int)block_k_ : (bt_reg_k(P.m, ldt_) > 0 ? 8 : 16);
-    bt_layout(P, bt_tiled(P.m, ldt_, K));
+    const int K = block_k_ > 0 ? (int)block_k_ : (bt_reg_k(P.m, ldt_, (int)bt_nt_) > 0 ? 8 : 16);
+    bt_layout(P, bt_tiled(P.m, ldt_, K, (int)bt_nt_, bt_old_ != 0));
     const int64_t blocks_per_chunk = std::max<int64_t>(1, chunk_ / K);
     const bool sampling = sample_events_ > 0;
     int64_t block_no = 0;
@@ -320,6 +331,19 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
     }
     // host clock from the first launch to the arrival of the final state: no extra event / sync per loop (the loop is
     // GPU-bound: the host only waits for chunk states)
+    if (bt_stamps_ && w.stamps) {
+        const size_t nb = (size_t)(16 * kBtStampSegs + 8) * sizeof(unsigned long long);
+        HIP_TRY(hipMemcpyAsync(w.stamps_host, w.stamps, nb, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(sync_stream());
+        const unsigned long long np = w.stamps_host[16 * kBtStampSegs];
+        fprintf(stderr, "{\"bt_stamps\": {\"m\": %d, \"nn\": %d, \"phase\": %d, \"pivots\": %llu, \"cycles_per_pivot_by_wave\": [", P.m, nn, phase, np);
+        for (int wv = 0; wv < 16; wv++) {
+            fprintf(stderr, "%s[", wv ? ", " : "");
+            for (int sg = 0; sg < 11; sg++) fprintf(stderr, "%s%.1f", sg ? ", " : "", np ? (double)w.stamps_host[wv * kBtStampSegs + sg] / (double)np : 0.0);
+            fprintf(stderr, "]");
+        }
+        fprintf(stderr, "]}}\n");
+    }
     if (st) {
         st->seconds_pivot_loop += now_s() - t_loop0;
         st->bland_steps += hs.bland_steps;
@@ -351,8 +375,8 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         ldt_ = tab_ld(nn);
         if (!binv_host) {  // slack basis: B^-1 is the permutation rho
             // straight into the layout the block kernels want: no conversion pass before the first pivot
-            const int kr0 = bt_reg_k(P.m, ldt_);
-            t_tiled_ = use_bt_ && bt_tiled(P.m, ldt_, block_k_ > 0 ? (int)block_k_ : (kr0 > 0 ? 8 : 16));
+            const int kr0 = bt_reg_k(P.m, ldt_, (int)bt_nt_);
+            t_tiled_ = use_bt_ && bt_tiled(P.m, ldt_, block_k_ > 0 ? (int)block_k_ : (kr0 > 0 ? 8 : 16), (int)bt_nt_, bt_old_ != 0);
             launch_tab_gather(P.dAt, P.ld, m, nn, w.nonbasic, w.rho, w.T[0], ldt_, t_tiled_, stream_);
             launches_++;
             return GOMILP_OK;
@@ -494,6 +518,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
                 basic[added] = cv.first;
                 nonbasic[jp] = n;
                 exchanged = true;
+                st->art_exchanges++;
                 break;
             }
             if (!exchanged) return GOMILP_ERR_INFEASIBLE;  // :606

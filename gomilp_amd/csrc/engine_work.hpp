@@ -77,6 +77,8 @@ struct Engine::Work {
     double *luLp = nullptr, *luUp = nullptr;  // compressed LU: compact multiplier / U-row panels of the running round
     double *Wd = nullptr;       // packed dense columns of L\\U for the host solves (m x nd)
     size_t cap_T = 0;  // doubles per T buffer
+    size_t cap_btU = 0;  // doubles in btU (kBtMaxK rows of the padded row count)
+    unsigned long long *stamps = nullptr, *stamps_host = nullptr;   // diagnostic build of the block kernel (knob "bt_stamps")
     int cap_ldt = 0;
     DevState *st = nullptr;
     DevState *st_host = nullptr;  // pinned
@@ -120,7 +122,9 @@ struct Engine::Work {
         if (px_ratio) hipFree(px_ratio); px_ratio = nullptr;
         for (double **p : {&T[0], &T[1], &R[0], &R[1], &tscratch, &btU, &btV}) { if (*p) hipFree(*p); *p = nullptr; }
         if (srcpos) hipFree(srcpos); srcpos = nullptr;
-        cap_T = 0; cap_ldt = 0;
+        cap_T = 0; cap_ldt = 0; cap_btU = 0;
+        if (stamps) hipFree(stamps); stamps = nullptr;
+        if (stamps_host) hipHostFree(stamps_host); stamps_host = nullptr;
         if (st) hipFree(st); st = nullptr;
         if (st_host) hipHostFree(st_host); st_host = nullptr;
         if (child_stage) hipHostFree(child_stage); child_stage = nullptr; child_stage_cap = 0;

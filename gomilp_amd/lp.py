@@ -34,11 +34,11 @@ class Stats(C.Structure):
     _fields_ = [
         ("pivots_phase1", C.c_int64), ("pivots_phase2", C.c_int64), ("bland_steps", C.c_int64),
         ("refreshes", C.c_int64), ("kernel_launches", C.c_int64),
-        ("phase1_used", C.c_int32), ("device_id", C.c_int32), ("wrapped_status", C.c_int32), ("reserved", C.c_int32),
+        ("phase1_used", C.c_int32), ("device_id", C.c_int32), ("wrapped_status", C.c_int32), ("pipeline", C.c_int32),
         ("seconds_total", C.c_double), ("seconds_upload", C.c_double), ("seconds_pivot_loop", C.c_double),
         ("seconds_final_solve", C.c_double), ("drift_xb", C.c_double), ("pivot_kernel_seconds", C.c_double * 4),
         ("seconds_final_device", C.c_double), ("seconds_final_host", C.c_double), ("lu_dense_steps", C.c_int64),
-        ("lu_rounds", C.c_int64),
+        ("lu_rounds", C.c_int64), ("art_exchanges", C.c_int64), ("cond_fallbacks", C.c_int64),
     ]
 
 
@@ -125,8 +125,8 @@ class LPResult:
 
 
 def _stats_dict(s: Stats) -> dict:
-    d = {k: getattr(s, k) for k, _ in Stats._fields_ if k not in ("pivot_kernel_seconds", "reserved")}
-    d["pipeline"] = {0: "three-kernel", 1: "fused", 2: "tableau", 3: "blocked"}.get(s.reserved, str(s.reserved))
+    d = {k: getattr(s, k) for k, _ in Stats._fields_ if k not in ("pivot_kernel_seconds", "pipeline")}
+    d["pipeline"] = {0: "three-kernel", 1: "fused", 2: "tableau", 3: "blocked"}.get(s.pipeline, str(s.pipeline))
     d["pivot_kernel_seconds"] = list(s.pivot_kernel_seconds)
     return d
 
@@ -145,6 +145,8 @@ def simplex(c, A, b, tol: float = 0.0, initial_basic=None) -> LPResult:
     has_x = C.c_int32(0)
     st = Stats()
     ib = None if initial_basic is None else np.ascontiguousarray(initial_basic, dtype=np.int64)
+    if ib is not None and ib.shape != (m,):
+        return LPResult(ERR_PANIC, math.nan, None, None)  # "lp: incorrect number of initial vectors" (simplex.go:149-151)
     rc = lib().gomilp_lp_simplex(_dp(c), _dp(A), n, _dp(b), m, n, float(tol), None if ib is None else _ip(ib),
                                  C.byref(z), _dp(x), C.byref(has_x), _ip(basis), C.byref(st))
     return LPResult(rc, z.value, x if has_x.value else None, basis if has_x.value and m != n else None, _stats_dict(st))

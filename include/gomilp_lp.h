@@ -50,7 +50,7 @@ typedef struct gomilp_lp_stats {
     int32_t phase1_used;        /* 1 when the initial basis was infeasible and Phase I ran */
     int32_t device_id;
     int32_t wrapped_status;     /* inner status when the result is GOMILP_ERR_PHASE1_WRAPPED */
-    int32_t reserved;           /* pivot pipeline that ran: 0 three-kernel, 1 fused two-kernel, 2 single-kernel tableau,
+    int32_t pipeline;           /* pivot pipeline that ran: 0 three-kernel, 1 fused two-kernel, 2 single-kernel tableau,
                                    3 blocked tableau (deferred rank-K updates) */
     double seconds_total;       /* host wall clock of the call (upload included for the flat call) */
     double seconds_upload;      /* host->device copies + layout conversion */
@@ -63,6 +63,8 @@ typedef struct gomilp_lp_stats {
     double seconds_final_host;   /* part of seconds_final_solve: the two triangular solves on the host */
     int64_t lu_dense_steps;      /* elimination steps of the final LU that did arithmetic (the rest hit the unit-column fast path) */
     int64_t lu_rounds;           /* panel rounds of the compressed LU schedule (0 for the other schedules) */
+    int64_t art_exchanges;       /* 1 when a zero-level artificial was exchanged out of the basis after Phase I (simplex.go:581-606) */
+    int64_t cond_fallbacks;      /* exact condition-number evaluations made because a cheap guard was near a threshold */
 } gomilp_lp_stats;
 
 /* One record per pivot, execution order (Phase I first).  Same fields as the oracle's trace. */

@@ -246,6 +246,7 @@ static int find_initial_basic(oracle_ctx *ctx, int depth, const double *A, int64
             goto out;
         }
         /* :581-606 the artificial stayed basic at zero: try to exchange it */
+        ctx->art_exchanges++;
         char *inbasic = (char *)calloc((size_t)n1, 1);
         for (int64_t i = 0; i < m; i++) inbasic[newbasic[i]] = 1;
         ret = ORACLE_ERR_INFEASIBLE;
@@ -418,6 +419,7 @@ int oracle_lp_simplex(const double *c, const double *A, int64_t lda, const doubl
     ctx->lu_factorizations = ctx->cond_evaluations = 0;
     ctx->phase1_used = ctx->truncated = ctx->wrapped_code = 0;
     ctx->seconds_loop = 0;
+    ctx->art_exchanges = 0;
     *has_x = 0;
     if (m <= 0 || n <= 0 || lda < n) { *opt_f = NAN; return ORACLE_ERR_BAD_SHAPE; }
     return simplex(ctx, 0, initial_basic, c, A, lda, b, m, n, tol, opt_f, opt_x, has_x, basis_out);

@@ -56,6 +56,7 @@ typedef struct {
     int32_t truncated;          /* stop_after_pivots was hit */
     int32_t wrapped_code;       /* ORACLE_ERR_* inside a PHASE1_WRAPPED error */
     double seconds_loop;        /* wall time of the outermost Phase-II loop */
+    int64_t art_exchanges;      /* the Phase-I artificial stayed basic at level zero and was exchanged (simplex.go:581-606) */
 } oracle_ctx;
 
 void oracle_ctx_init(oracle_ctx *ctx);

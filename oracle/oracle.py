@@ -53,6 +53,7 @@ class _Ctx(C.Structure):
         ("lu_factorizations", C.c_int64), ("cond_evaluations", C.c_int64),
         ("phase1_used", C.c_int32), ("truncated", C.c_int32), ("wrapped_code", C.c_int32),
         ("seconds_loop", C.c_double),
+        ("art_exchanges", C.c_int64),
     ]
 
 
@@ -123,6 +124,7 @@ class LPResult:
     truncated: bool = False
     wrapped_code: int = 0
     seconds_loop: float = 0.0
+    art_exchanges: int = 0
 
     @property
     def ok(self) -> bool:
@@ -169,7 +171,7 @@ def simplex(c, A, b, tol: float = 0.0, initial_basic=None, *, fast_initial_basis
         pivots=piv, pivots_phase1=ctx.pivots_phase1, pivots_phase2=ctx.pivots_phase2, bland_steps=ctx.bland_steps,
         lu_factorizations=ctx.lu_factorizations, cond_evaluations=ctx.cond_evaluations,
         phase1_used=bool(ctx.phase1_used), truncated=bool(ctx.truncated), wrapped_code=ctx.wrapped_code,
-        seconds_loop=ctx.seconds_loop)
+        seconds_loop=ctx.seconds_loop, art_exchanges=ctx.art_exchanges)
 
 
 def find_linearly_independent(A, fast: bool = False) -> List[int]:

@@ -67,3 +67,20 @@ def test_tree_pins():
             zs.append(n.z)
     assert zs[:3] == pins["K8_z_sequence"]
     assert all(n.constraints[-1][0] == 2 for n in res.nodes[1:])
+
+
+def test_c1_plumbing_case_fixture_is_reproducible():
+    """BASELINE config 1 (10 variables / 5 constraints, CPU oracle only): the committed tree fixtures are what the
+    oracle produces today (tools/gen_golden.py c1)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from gen_golden import DECISIONS, c1_problem
+    for single, name in ((False, "milp_C1.npz"), (True, "milp_C1_single.npz")):
+        fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+        c, G, h, integ = c1_problem(single)
+        res = O.solve_milp(c, None, None, G, h, integ, max_nodes=int(fx["budget"]))
+        solved = [nd for nd in res.nodes if nd.status != -1]
+        assert [nd.status for nd in solved] == list(fx["status"])
+        assert [DECISIONS.index(nd.decision) for nd in solved] == list(fx["decision"])
+        assert np.array_equal(np.array([nd.z for nd in solved]), fx["z"], equal_nan=True)
+        assert (res.error or "") == str(fx["error"])

@@ -1,15 +1,16 @@
-"""Developer tool: N complete solves of a named config (for rocprofv3 --kernel-trace --stats).
-   cd /tmp && rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof -- python3 /root/repo/tools/solve_n.py M 5"""
-import sys; sys.path.insert(0, '/root/repo')
+"""Developer tool: time full solves of one config under context knobs.  usage: solve_n.py M [reps] [knob=value ...]"""
+import sys, time, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gomilp_amd import lp, synth
-name = sys.argv[1] if len(sys.argv) > 1 else 'M'
-reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+name = sys.argv[1] if len(sys.argv) > 1 else "M"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+knobs = dict((k, int(v)) for k, v in (a.split("=") for a in sys.argv[3:]))
 m, seed = synth.CONFIGS[name]
 c, A, b = synth.dense_lp_standard_form(m, seed)
-cx = lp.Context(); rl = cx.upload(c, A, b)
+cx = lp.Context(sample_events=64, chunk=64, **knobs)
+p = cx.upload(c, A, b)
 for i in range(reps):
-    r = rl.solve(0.0)
-s = r.stats
-print(name, lp.STATUS_NAMES[r.status], 'pivots', s['pivots_phase2'], 'total %.2f ms loop %.2f final %.2f (dev %.2f host %.2f) rounds %d dense %d' % (
-    s['seconds_total'] * 1e3, s['seconds_pivot_loop'] * 1e3, s['seconds_final_solve'] * 1e3, s['seconds_final_device'] * 1e3, s['seconds_final_host'] * 1e3, s['lu_rounds'], s['lu_dense_steps']))
+    t0 = time.perf_counter(); r = p.solve(0.0); dt = time.perf_counter() - t0
+    ks = r.stats["pivot_kernel_seconds"]
+    print(name, knobs, "status", r.status, "pivots", r.stats["pivots_phase2"], "total %.2f ms loop %.2f ms" % (1e3 * dt, 1e3 * r.stats["seconds_pivot_loop"]),
+          "inner %.2f us/launch update %.2f us/launch" % (1e6 * ks[0] / max(ks[1], 1), 1e6 * ks[2] / max(ks[1], 1)), "z %.17g" % r.z, flush=True)
 cx.close()
