@@ -1,0 +1,406 @@
+// Device-batched relaxations (gfx950): the set-up, phase-change and reduced-cost kernels that let a whole wave of
+// branch-and-bound children (reference: the solveWorker pool of tree.go:98-100,196-205, one lp.Simplex per node,
+// subproblem.go:141-159) advance through ONE fixed schedule of launches — grid.x / grid.z = relaxation, per-relaxation
+// argument block (BatchLP) in HBM, finished relaxations leave at once.  The pivots themselves are the block kernels of
+// bt_kernels.hip (k_bt_inner2_batch / k_bt_update_tiled_batch: same device code as the single-relaxation path).
+//
+// What the host does per relaxation on the single path (engine_tableau.cpp: Phase-I set-up, the forced pivot, the
+// Phase I -> II column permutation, the reduced-cost rebuilds) happens here on the device:
+//   k_b_setup     x_B, index lists, feasibility of the slack basis, artificial column, forced-pivot order (simplex.go:492-556)
+//   k_b_gather    T = B^-1 A_N straight from the ROOT's columns + the child's branch rows (no per-child copy of A)
+//   k_b_ctrl      the stage machine: after the forced pivot, at the end of Phase I (infeasible / Phase II / hand to the
+//                 host) and at the end of Phase II; rebuilds the ascending nonbasic list of simplex.go:174-184
+//   k_b_permute   T columns follow the rebuilt list
+//   k_b_tab_r     reduced costs r = c_N - c_B^T T in the fixed chunk order of the single path (same bits)
+// Anything outside the common path (a zero-level artificial that needs the exchange of simplex.go:581-606, the guard band
+// around phaseIZeroTol, a zero artificial column) sets BS_HOST: the host solves that relaxation through the
+// single-relaxation engine, whose parity with the oracle the test-suite pins.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+#include "kernels_common.h"
+
+namespace gomilp {
+
+__device__ __forceinline__ int b_rho(const BatchLP &lp, int pos) {   // row of the 1 in the slack column at basis position pos
+    return pos < lp.K ? lp.m0 + lp.K - 1 - pos : lp.rho0[pos - lp.K];
+}
+__device__ __forceinline__ double b_rhs(const BatchLP &lp, int r) { return r < lp.m0 ? lp.b0[r] : lp.rhs[r - lp.m0]; }
+// cost of variable j in the given phase: Phase I minimises the artificial (simplex.go:545-547), Phase II c' = [c0, 0]
+__device__ __forceinline__ double b_cost(const BatchLP &lp, int phase, int j) {
+    if (phase == 1) return j == lp.n ? 1.0 : 0.0;
+    return j < lp.n0 ? lp.c0[j] : 0.0;
+}
+__host__ __device__ __forceinline__ int b_ldt(int nn) { return ((nn + 63) / 64) * 64; }
+
+__device__ __forceinline__ void b_reset_state(DevState *st) {
+    st->done = 0; st->status = ST_RUNNING; st->pivots = 0; st->kdone = 0; st->bland_steps = 0; st->trace_len = 0;
+    st->max_pivots = 0; st->lu_singular = 0;
+}
+
+// ---- set-up: slack basis of the child, feasibility, Phase-I order ---------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_b_setup(BatchLP *__restrict__ lps) {
+    __shared__ unsigned long long sk[kWavesPerBlock];
+    __shared__ unsigned int si[kWavesPerBlock];
+    __shared__ int s_bad;
+    BatchLP &lp = lps[blockIdx.x];
+    const int tid = threadIdx.x, m = lp.m, n = lp.n;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    unsigned long long k = ~0ull;
+    unsigned int idx = 0xFFFFFFFFu;
+    int bad = 0;
+    for (int pos = tid; pos < lp.ldu; pos += kBlock) {
+        double x = 0.0;
+        if (pos < m) {
+            x = b_rhs(lp, b_rho(lp, pos));   // ab = permutation: x_B = ab^-1 b exactly (initializeFromBasic, simplex.go:447-471)
+            lp.basic[pos] = n - 1 - pos;      // descending scan of findLinearlyIndependent (simplex.go:618-635)
+            amin_take(k, idx, ordkey(x), (unsigned int)pos);
+            if (x < -1e-13) bad = 1;          // initPosTol
+        }
+        lp.xb[pos] = x;
+    }
+    if (bad) s_bad = 1;
+    block_argmin(k, idx, sk, si);   // floats.MinIdx (simplex.go:532); barriers inside
+    const int infeasible = s_bad;
+    const int minidx = idx == 0xFFFFFFFFu ? 0 : (int)idx;
+    const int nn2 = n - m;
+    for (int jp = tid; jp < nn2; jp += kBlock) lp.nonbasic[jp] = jp;   // ascending ids not in the basis (simplex.go:174-184)
+    int art_zero = 0;
+    if (infeasible) {
+        // a_{n+1} = b - sum_{i != minidx} a_{basic_i}: unit columns, one exact "- 1" per row (floats.Sub, simplex.go:536-542)
+        const int rmin = b_rho(lp, minidx);
+        int nz = 0;
+        for (int r = tid; r < lp.ldu; r += kBlock) {
+            double v = 0.0;
+            if (r < m) v = (r == rmin) ? b_rhs(lp, r) : -1 * 1.0 + b_rhs(lp, r);
+            lp.art[r] = v;
+            if (v != 0) nz = 1;
+        }
+        art_zero = !__syncthreads_or(nz);
+    }
+    if (tid == 0) {
+        BTArgs &a = lp.bt;
+        a.m = m; a.ldu = lp.ldu; a.T = lp.T[0]; a.U = lp.U; a.V = lp.V; a.r = lp.R; a.xb = lp.xb;
+        a.basic = lp.basic; a.nonbasic = lp.nonbasic; a.st = lp.st; a.trace = nullptr; a.trace_cap = 0;
+        a.nt_force = 0; a.tiled = 1; a.old_only = 0; a.stamps = nullptr;
+        lp.tcur = 0; lp.do_permute = 0; lp.do_r = 0; lp.wrapped = 0; lp.piv1 = lp.piv2 = lp.bland = 0;
+        lp.status = 0;
+        b_reset_state(lp.st);
+        if (!infeasible) {
+            lp.phase1_used = 0;
+            a.nn = nn2; a.ldt = b_ldt(nn2); a.phase = 2; a.tol = lp.tol_user; a.kmax = 0;   // no pivot in the forced round
+            a.forced_q = a.forced_p = -1; a.forced_nocommit = 0;
+            lp.stage = BS_P2_START;
+        } else {
+            lp.phase1_used = 1;
+            const int nn1 = nn2 + 1;
+            lp.nonbasic[nn2] = n;   // the artificial is the last nonbasic column; one forced pivot brings it to position minidx
+            a.nn = nn1; a.ldt = b_ldt(nn1); a.phase = 1; a.tol = 1e-10; a.kmax = 1;
+            a.forced_q = nn1 - 1; a.forced_p = minidx; a.forced_nocommit = 2;   // lists exchanged on the device, uncounted
+            lp.stage = art_zero ? BS_HOST : BS_FORCED;   // zero artificial column: verifyInputs of the recursive call fails (host path reports it)
+        }
+    }
+}
+
+// ---- T[pos, jp] = A'[rho(pos)][var(jp)] in 4x4 tiles, A' = [[A0, 0], [G#, I_K]] never materialised ---------------------
+__device__ __forceinline__ double b_entry(const BatchLP &lp, int pos, int jp, int nn) {
+    if (pos >= lp.m || jp >= nn) return 0.0;
+    const int r = b_rho(lp, pos);
+    const int nn2 = lp.n - lp.m;
+    const int j = jp < nn2 ? jp : lp.n;   // slack start: the nonbasic list is 0 .. nn2-1 (+ the artificial)
+    if (j == lp.n) return lp.art[r];
+    if (j < lp.n0) {
+        if (r < lp.m0) return lp.At0[(size_t)j * lp.ld0 + r];
+        const int kk = r - lp.m0;
+        return lp.var[kk] == j ? lp.sign[kk] : 0.0;   // G# row k = sign_k * e_{var_k} (subproblem.go:245-255)
+    }
+    return (r == lp.m0 + (j - lp.n0)) ? 1.0 : 0.0;    // (a branch slack can only be nonbasic here if the list said so)
+}
+
+__global__ void k_b_gather(const BatchLP *__restrict__ lps) {
+    __shared__ double tile[32][33];
+    const BatchLP &lp = lps[blockIdx.z];
+    if (lp.stage == BS_HOST || lp.stage == BS_DONE) return;
+    const int m = lp.m, nn = lp.bt.nn, ldt = lp.bt.ldt;
+    const int m4 = (m + 3) & ~3;
+    const int p0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    if (p0 >= m4 || j0 >= ldt) return;
+    for (int rr = threadIdx.y; rr < 32; rr += 8) tile[rr][threadIdx.x] = b_entry(lp, p0 + threadIdx.x, j0 + rr, nn);
+    __syncthreads();
+    double *T = lp.T[0];
+    for (int rr = threadIdx.y; rr < 32; rr += 8) {
+        const int pos = p0 + rr, jp = j0 + threadIdx.x;
+        if (jp < ldt && pos < m4) T[tab_idx(pos, jp, ldt, 1)] = tile[threadIdx.x][rr];   // padding rows / columns are zeros
+    }
+}
+
+// ---- the stage machine ----------------------------------------------------------------------------------------------
+// dynamic LDS: 2 * (n_max + 2) ints (flags, old positions)
+__global__ __launch_bounds__(kBlock) void k_b_ctrl(BatchLP *__restrict__ lps) {
+    extern __shared__ __attribute__((aligned(16))) int sh_ctrl[];
+    __shared__ int s_scan[kBlock];
+    __shared__ double s_red[kBlock];
+    __shared__ int s_added;
+    BatchLP &lp = lps[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int m = lp.m, n = lp.n;
+    const int stage = lp.stage;
+    DevState *st = lp.st;
+    if (tid == 0) { lp.do_permute = 0; lp.do_r = 0; s_added = -1; }
+    __syncthreads();
+    bool to_phase2 = false;   // uniform
+    if (stage == BS_FORCED) {
+        // the Phase-I starting vertex must be feasible: initializeFromBasic inside the recursive call panics otherwise
+        // (simplex.go:155-158) — the host path reports that
+        int bad = 0;
+        for (int i = tid; i < m; i += kBlock) if (lp.xb[i] < -1e-13) bad = 1;
+        bad = __syncthreads_or(bad);
+        if (tid == 0) {
+            if (bad) lp.stage = BS_HOST;
+            else {
+                BTArgs &a = lp.bt;
+                a.forced_q = a.forced_p = -1; a.forced_nocommit = 0; a.kmax = lp.kblock;
+                b_reset_state(st);
+                lp.do_r = 1; lp.r_phase = 1; lp.stage = BS_P1;
+            }
+        }
+    } else if (stage == BS_P2_START) {
+        if (tid == 0) {
+            lp.bt.kmax = lp.kblock;
+            b_reset_state(st);
+            lp.do_r = 1; lp.r_phase = 2; lp.stage = BS_P2;
+        }
+    } else if (stage == BS_P1 && st->done) {
+        const int status = st->status;
+        if (status != ST_OPTIMAL) {   // simplex.go:557-559: any error of the recursive call comes back wrapped
+            if (tid == 0) {
+                lp.piv1 += st->pivots; lp.bland += st->bland_steps;
+                lp.wrapped = status == ST_UNBOUNDED ? 4 : (status == ST_BLAND_FAILED ? 1 : 12);
+                lp.status = 9;   // GOMILP_ERR_PHASE1_WRAPPED
+                lp.stage = BS_DONE;
+            }
+        } else {
+            for (int i = tid; i < m; i += kBlock) if (lp.basic[i] == n) s_added = i;
+            __syncthreads();
+            const int added = s_added;
+            const double xart = added >= 0 ? lp.xb[added] : 0.0;
+            const double ax = fabs(xart);
+            if (added >= 0 && ax > 1e-13 && ax < 1e-11) {
+                // guard band around phaseIZeroTol: the engine takes the value from a fresh gonum-order solve there
+                if (tid == 0) lp.stage = BS_HOST;
+            } else if (ax > 1e-12) {
+                if (tid == 0) {
+                    lp.piv1 += st->pivots; lp.bland += st->bland_steps;
+                    lp.status = 2;   // lp.ErrInfeasible, phaseIZeroTol (simplex.go:563-565)
+                    lp.stage = BS_DONE;
+                }
+            } else if (added >= 0) {
+                // ---- simplex.go:581-606: the artificial stayed basic at level zero: exchange it for the first nonbasic variable
+                // (ascending id) whose pivot element is usable and whose basis is feasible — the tests of engine_tableau.cpp
+                int *pos_of = sh_ctrl;
+                const int nn1 = lp.bt.nn, ldt = lp.bt.ldt;
+                const double *T = lp.bt.T;
+                for (int j = tid; j <= n; j += kBlock) pos_of[j] = -1;
+                __syncthreads();
+                for (int jp = tid; jp < nn1; jp += kBlock) pos_of[lp.nonbasic[jp]] = jp;
+                __syncthreads();
+                int found = -1, tries = 0;
+                for (int id = 0; id < n && found < 0 && tries < 512; id++) {
+                    const int jp = pos_of[id];
+                    if (jp < 0) continue;
+                    const double dpv = T[tab_idx(added, jp, ldt, 1)];
+                    if (!(fabs(dpv) > 1e-9)) continue;   // 1e-9 * max(1, column max) >= 1e-9
+                    tries++;
+                    const double theta = xart / dpv;
+                    double mx = 0;
+                    int bad = 0;
+                    for (int i = tid; i < m; i += kBlock) {
+                        const double dv = T[tab_idx(i, jp, ldt, 1)];
+                        mx = fmax(mx, fabs(dv));
+                        const double v = (i == added) ? theta : lp.xb[i] - theta * dv;
+                        if (v < -1e-13) bad = 1;
+                    }
+                    s_red[tid] = mx;
+                    bad = __syncthreads_or(bad);
+                    for (int off = kBlock / 2; off > 0; off >>= 1) {
+                        if (tid < off) s_red[tid] = fmax(s_red[tid], s_red[tid + off]);
+                        __syncthreads();
+                    }
+                    const double dmax = s_red[0];
+                    __syncthreads();
+                    if (!(fabs(dpv) > 1e-9 * fmax(1.0, dmax)) || bad) continue;
+                    found = jp;
+                }
+                if (tid == 0) {
+                    lp.piv1 += st->pivots; lp.bland += st->bland_steps;
+                    if (found >= 0) {
+                        BTArgs &a = lp.bt;
+                        a.forced_q = found; a.forced_p = added; a.forced_nocommit = 3; a.kmax = 1;   // lists exchanged on the device, runs once
+                        b_reset_state(st);
+                        lp.stage = BS_EXCH;
+                    } else if (tries >= 512) {
+                        lp.stage = BS_HOST;
+                    } else {
+                        lp.status = 2;   // no column works: lp.ErrInfeasible (simplex.go:606)
+                        lp.stage = BS_DONE;
+                    }
+                }
+            } else {
+                if (tid == 0) { lp.piv1 += st->pivots; lp.bland += st->bland_steps; }
+                to_phase2 = true;
+            }
+        }
+    } else if (stage == BS_EXCH && st->done) {
+        to_phase2 = true;   // the forced exchange pivot has run (ST_FORCED_DONE): the artificial is nonbasic now
+    } else if (stage == BS_P2 && st->done) {
+        if (tid == 0) {
+            lp.piv2 += st->pivots; lp.bland += st->bland_steps;
+            const int status = st->status;
+            lp.status = status == ST_OPTIMAL ? 0 : (status == ST_UNBOUNDED ? 4 : (status == ST_BLAND_FAILED ? 1 : 12));
+            lp.stage = BS_DONE;
+        }
+    }
+    if (to_phase2) {
+        // ---- Phase I -> Phase II: nonbasic list rebuilt in ascending variable order (simplex.go:174-184), the
+        // artificial (nonbasic now) dropped; srcpos[new position] = old position, T columns follow (k_b_permute)
+        __syncthreads();
+        int *flag = sh_ctrl, *pos_of = sh_ctrl + (n + 2);
+        const int nn1 = lp.bt.nn;
+        for (int j = tid; j <= n; j += kBlock) flag[j] = 0;
+        __syncthreads();
+        for (int i = tid; i < m; i += kBlock) flag[lp.basic[i]] = 1;
+        for (int jp = tid; jp < nn1; jp += kBlock) pos_of[lp.nonbasic[jp]] = jp;
+        __syncthreads();
+        const int chunk = (n + kBlock - 1) / kBlock;
+        const int lo = min(n, tid * chunk), hi = min(n, lo + chunk);
+        int cnt = 0;
+        for (int j = lo; j < hi; j++) cnt += !flag[j];
+        s_scan[tid] = cnt;
+        __syncthreads();
+        if (tid == 0) {   // exclusive scan over 256 counts
+            int run = 0;
+            for (int t = 0; t < kBlock; t++) { const int c = s_scan[t]; s_scan[t] = run; run += c; }
+        }
+        __syncthreads();
+        int at = s_scan[tid];
+        for (int j = lo; j < hi; j++)
+            if (!flag[j]) { lp.nonbasic[at] = j; lp.srcpos[at] = pos_of[j]; at++; }
+        if (tid == 0) {
+            const int nn2 = n - m;
+            BTArgs &a = lp.bt;
+            lp.perm_ld_in = a.ldt; lp.perm_nn_out = nn2;
+            lp.tcur ^= 1;
+            a.T = lp.T[lp.tcur]; a.ldt = b_ldt(nn2); a.nn = nn2; a.phase = 2; a.tol = lp.tol_user; a.kmax = lp.kblock;
+            a.forced_q = a.forced_p = -1; a.forced_nocommit = 0;
+            b_reset_state(st);
+            lp.do_permute = 1; lp.do_r = 1; lp.r_phase = 2;
+            lp.stage = BS_P2;
+        }
+    }
+}
+
+// the active list for the launches of the next superstep, in relaxation order (one workgroup; nlp <= 65535)
+__global__ __launch_bounds__(kBlock) void k_b_compact(const BatchLP *__restrict__ lps, int nlp, int *__restrict__ ids, int *__restrict__ count) {
+    __shared__ int s_cnt[kBlock];
+    const int tid = threadIdx.x;
+    const int chunk = (nlp + kBlock - 1) / kBlock;
+    const int lo = min(nlp, tid * chunk), hi = min(nlp, lo + chunk);
+    int cnt = 0;
+    for (int i = lo; i < hi; i++) { const int sg = lps[i].stage; cnt += (sg != BS_DONE && sg != BS_HOST); }
+    s_cnt[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < kBlock; t++) { const int c = s_cnt[t]; s_cnt[t] = run; run += c; }
+        *count = run;
+    }
+    __syncthreads();
+    int at = s_cnt[tid];
+    for (int i = lo; i < hi; i++) { const int sg = lps[i].stage; if (sg != BS_DONE && sg != BS_HOST) ids[at++] = i; }
+}
+__global__ void k_b_init_ids(int *__restrict__ ids, int *__restrict__ count, int nlp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nlp) ids[i] = i;
+    if (i == 0) *count = nlp;
+}
+
+// T_out[:, jp] = T_in[:, srcpos[jp]] (both 4x4-tiled); the control kernel already made T_out the current buffer.
+// One workgroup = 16 rows of one relaxation (a launch without work orders is nlp * m/16 empty workgroups, not m * nlp).
+__global__ __launch_bounds__(kBlock) void k_b_permute(const BatchLP *__restrict__ lps) {
+    const BatchLP &lp = lps[blockIdx.y];
+    if (!lp.do_permute) return;
+    const int m = lp.m, m4 = (m + 3) & ~3, ld_out = lp.bt.ldt;
+    const int i0 = blockIdx.x * 16;
+    if (i0 >= m4) return;
+    const double *Tin = lp.T[lp.tcur ^ 1];
+    double *Tout = lp.T[lp.tcur];
+    const int nn_out = lp.perm_nn_out, ld_in = lp.perm_ld_in;
+    for (int jp = threadIdx.x; jp < ld_out; jp += kBlock) {
+        const int src = jp < nn_out ? lp.srcpos[jp] : 0;
+#pragma unroll 4
+        for (int i = i0; i < min(i0 + 16, m4); i++)
+            Tout[tab_idx(i, jp, ld_out, 1)] = (jp < nn_out && i < m) ? Tin[tab_idx(i, src, ld_in, 1)] : 0.0;
+    }
+}
+
+// r[jp] = cost[nonbasic[jp]] - sum_i cost[basic[i]] * T[i, jp]: row chunks, fixed-order reduction — the arithmetic of
+// k_tab_r_partial / k_tab_r_reduce (tableau_kernels.hip), so the batched and the single path see the same bits
+__host__ __device__ __forceinline__ int b_r_chunks(int m) { int c = (m + 63) / 64; return c > 64 ? 64 : c; }
+
+__global__ __launch_bounds__(kBlock) void k_b_tab_r_partial(const BatchLP *__restrict__ lps) {
+    const BatchLP &lp = lps[blockIdx.z];
+    if (!lp.do_r) return;
+    const int m = lp.m, ldt = lp.bt.ldt, phase = lp.r_phase;
+    const int nchunks = b_r_chunks(m), rpc = (m + nchunks - 1) / nchunks;
+    const int chunk = blockIdx.y, j = blockIdx.x * kBlock + threadIdx.x;
+    if (chunk >= nchunks || j >= ldt) return;
+    const int i0 = chunk * rpc, i1 = min(m, i0 + rpc);
+    const double *T = lp.bt.T;
+    double acc = 0;
+    for (int i = i0; i < i1; i++) {
+        const double cb = b_cost(lp, phase, lp.basic[i]);
+        if (cb != 0) acc += cb * T[tab_idx(i, j, ldt, 1)];
+    }
+    lp.scratch[(size_t)chunk * ldt + j] = acc;
+}
+__global__ void k_b_tab_r_reduce(const BatchLP *__restrict__ lps) {
+    const BatchLP &lp = lps[blockIdx.z];
+    if (!lp.do_r) return;
+    const int ldt = lp.bt.ldt, nn = lp.bt.nn, phase = lp.r_phase;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ldt) return;
+    const int nchunks = b_r_chunks(lp.m);
+    double acc = 0;
+    for (int c = 0; c < nchunks; c++) acc += lp.scratch[(size_t)c * ldt + j];
+    lp.R[j] = (j < nn) ? b_cost(lp, phase, lp.nonbasic[j]) - acc : 0.0;
+}
+
+// ---- launch wrappers --------------------------------------------------------------------------------------------------
+int batch_ldt(int nn) { return b_ldt(nn); }
+
+void launch_b_setup(BatchLP *lps, int nlp, hipStream_t s) { hipLaunchKernelGGL(k_b_setup, dim3(nlp), dim3(kBlock), 0, s, lps); }
+void launch_b_gather(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s) {
+    dim3 grid(((m_max + 3) / 4 * 4 + 31) / 32, (ldt_max + 31) / 32, nlp), block(32, 8);
+    hipLaunchKernelGGL(k_b_gather, grid, block, 0, s, lps);
+}
+void launch_b_ctrl(BatchLP *lps, int nlp, int n_max, int *ids_out, int *active_slot, hipStream_t s) {
+    const size_t lds = (size_t)2 * (n_max + 2) * sizeof(int);
+    hipLaunchKernelGGL(k_b_ctrl, dim3(nlp), dim3(kBlock), lds, s, lps);
+    hipLaunchKernelGGL(k_b_compact, dim3(1), dim3(kBlock), 0, s, lps, nlp, ids_out, active_slot);
+}
+void launch_b_init_ids(int *ids, int *count, int nlp, hipStream_t s) {
+    hipLaunchKernelGGL(k_b_init_ids, dim3((nlp + 255) / 256), dim3(256), 0, s, ids, count, nlp);
+}
+void launch_b_permute(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s) {
+    dim3 grid(((m_max + 3) / 4 * 4 + 15) / 16, nlp);
+    hipLaunchKernelGGL(k_b_permute, grid, dim3(kBlock), 0, s, lps);
+}
+void launch_b_tab_r(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s) {
+    dim3 grid((ldt_max + kBlock - 1) / kBlock, b_r_chunks(m_max), nlp);
+    hipLaunchKernelGGL(k_b_tab_r_partial, grid, dim3(kBlock), 0, s, lps);
+    hipLaunchKernelGGL(k_b_tab_r_reduce, dim3((ldt_max + 255) / 256, 1, nlp), dim3(256), 0, s, lps);
+}
+
+}  // namespace gomilp

@@ -319,7 +319,7 @@ __device__ __forceinline__ unsigned int tile_off(unsigned int i, unsigned int j,
 struct BtWin { double m; unsigned int i; };   // minimum and the first index that attains it (0xFFFFFFFF: none, all NaN)
 
 template <int NT, int RI, int CJ, int KR, int VL, bool STAMP = false>
-__global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
+__device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
     constexpr int NW = NT / 64;
     // STAMP: diagnostic build (context knob "bt_stamps"): every wave sums the shader cycles it spends in each segment of
     // a pivot (s_memtime, cdna_hip_programming.md §7 "In-kernel stamps") and adds them to a.stamps[wave][segment]; the
@@ -674,10 +674,11 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
         BT_STAMP(9);   // row corrections, reduced costs, v' store, term shift
         // a host-chosen set-up pivot may leave the lists alone (forced_nocommit 1: the host uploads new ones) or exchange
         // them without being counted or traced as a pivot of the loop (2)
-        if (tid == 0 && forced && a.forced_nocommit == 2) {
+        if (tid == 0 && forced && a.forced_nocommit >= 2) {
             const int ent = nonbasic_s[q], lea = basic_s[p];
             basic_s[p] = ent; nonbasic_s[q] = lea;
         }
+        if (forced && a.forced_nocommit == 3) status = ST_FORCED_DONE;   // batched schedule: this order runs once (kmax = 1)
         if (tid == 0 && !(forced && a.forced_nocommit)) {  // simplex.go:280
             const int ent = nonbasic_s[q], lea = basic_s[p];
             basic_s[p] = ent; nonbasic_s[q] = lea;
@@ -718,6 +719,22 @@ __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
         st->bland_steps += blands;
         if (status != ST_RUNNING) { st->done = 1; st->status = status; }
     }
+}
+
+template <int NT, int RI, int CJ, int KR, int VL, bool STAMP = false>
+__global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
+    bt_inner2_body<NT, RI, CJ, KR, VL, STAMP>(a);
+}
+// one workgroup per relaxation of a wave (device-batched frontier): the argument block comes from HBM, where the
+// control kernel rewrites it at phase changes; relaxations in a terminal stage leave at once
+template <int NT, int RI, int CJ, int KR, int VL>
+__global__ __launch_bounds__(NT) void k_bt_inner2_batch(const BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count) {
+    if ((int)blockIdx.x >= *count) return;   // the grid is sized from an older (larger) count of active relaxations
+    const BatchLP &lp = lps[ids[blockIdx.x]];
+    const int stage = lp.stage;
+    if (stage == BS_DONE || stage == BS_HOST) return;
+    const BTArgs a = lp.bt;
+    bt_inner2_body<NT, RI, CJ, KR, VL, false>(a);
 }
 
 // T[i, j] += sum_{k < kdone} U[k][i] * V[k][j]  — in place, one streaming pass.
@@ -817,12 +834,12 @@ __global__ __launch_bounds__(256) void k_bt_tile(const double *__restrict__ src,
 // looping over `tilerows_per_wg` tile rows: consecutive lanes touch consecutive 16 bytes (the access shape of
 // k_bt_update); v_k'[4J+2h], v_k'[4J+2h+1] in registers, u in LDS.
 template <int KMAX>
-__global__ __launch_bounds__(kBlock) void k_bt_update_tiled(BTArgs a, int tilerows_per_wg) {
+__device__ __forceinline__ void bt_update_tiled_body(const BTArgs &a, int tilerows_per_wg, unsigned int bx, unsigned int by) {
     __shared__ double us[KMAX][64];
     const int kd = a.st->kdone;   // tested below, after the loads that do not depend on it are in flight
-    const unsigned int cx = blockIdx.x * kBlock + threadIdx.x;   // half piece within a tile row: 0 .. 2*ldt-1
+    const unsigned int cx = bx * kBlock + threadIdx.x;   // half piece within a tile row: 0 .. 2*ldt-1
     const unsigned int J = cx >> 3, r = (cx >> 1) & 3u, h = cx & 1u;
-    const int I0 = blockIdx.y * tilerows_per_wg;
+    const int I0 = by * tilerows_per_wg;
     const int m4 = (a.m + 3) & ~3;
     const int nI = min(tilerows_per_wg, m4 / 4 - I0);
     for (int idx = threadIdx.x; idx < KMAX * 64; idx += kBlock) {
@@ -876,6 +893,30 @@ __global__ __launch_bounds__(kBlock) void k_bt_update_tiled(BTArgs a, int tilero
         }
         *cell = t;
     }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(kBlock) void k_bt_update_tiled(BTArgs a, int tilerows_per_wg) {
+    bt_update_tiled_body<KMAX>(a, tilerows_per_wg, blockIdx.x, blockIdx.y);
+}
+// Batched form: 1-D grid, block L works on the relaxation at position L % nlp_pad of the active list, tile L / nlp_pad.
+// nlp_pad is a multiple of 8 and blocks are dealt round-robin over the 8 XCDs, so every block of the relaxation at list
+// position b — and block b of the batched inner kernel — runs on the XCD b % 8: the relaxation's tableau (2 MB at
+// 520 x 512) stays in ONE XCD's L2 between the update and the column / row reads of the next block (speed only: nothing
+// depends on the placement; the list is rebuilt once per superstep).
+template <int KMAX>
+__global__ __launch_bounds__(kBlock) void k_bt_update_tiled_batch(const BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count,
+                                                                  int nlp_pad, int gx, int tilerows_per_wg) {
+    const unsigned int L = blockIdx.x;
+    const unsigned int li = L % (unsigned int)nlp_pad, tile = L / (unsigned int)nlp_pad;
+    if ((int)li >= *count) return;
+    const BatchLP &lp = lps[ids[li]];
+    const int stage = lp.stage;
+    if (stage == BS_DONE || stage == BS_HOST) return;
+    const BTArgs a = lp.bt;
+    const unsigned int bx = tile % (unsigned int)gx, by = tile / (unsigned int)gx;
+    if (bx * kBlock >= 2u * (unsigned int)a.ldt || (int)by * tilerows_per_wg * 4 >= ((a.m + 3) & ~3)) return;
+    bt_update_tiled_body<KMAX>(a, tilerows_per_wg, bx, by);
 }
 
 // ---- launch wrappers ---------------------------------------------------------------------------
@@ -962,6 +1003,36 @@ bool bt_tiled(int m, int ldt, int kmax, int nt_force, bool old_only) {
     if (old_only || !(c.kreg > 0 && kmax <= c.kreg)) return false;
     return c.ri == 2 || (c.ri == 4 && c.nt <= 512);
 }
+// ---- batched launches (device-batched frontier, engine_batch.cpp): one configuration for the whole wave, chosen from
+// the largest relaxation; the register-resident kernel on the tiled layout only
+bool bt_batch_supported(int m_max, int ldt_max) {
+    if (!bt_tiled(m_max, ldt_max, 8, 0, false)) return false;
+    const BtCfg c = bt_cfg(m_max, ldt_max, 0);
+    return c.ri == 2 || (c.ri == 4 && c.nt == 512);
+}
+template <int NT, int RI, int VL>
+static void bt_inner_batch_nt(const BatchLP *lps, const int *ids, const int *count, int nlp, hipStream_t s) {
+    const size_t lds = (size_t)(RI + RI) * NT * (sizeof(double) + sizeof(int)) + (size_t)VL * 8 * NT * sizeof(double);
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) { hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner2_batch<NT, RI, RI, 8, VL>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); attr = true; }
+    hipLaunchKernelGGL((k_bt_inner2_batch<NT, RI, RI, 8, VL>), dim3(nlp), dim3(NT), lds, s, lps, ids, count);
+}
+// ids / count: the active list of the previous control step (device); nlp: an upper bound of *count the host knows
+void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s) {
+    const BtCfg c = bt_cfg(m_max, ldt_max, 0);
+    if (c.ri == 2) { if (c.nt == 512) bt_inner_batch_nt<512, 2, 0>(lps, ids, count, nlp, s); else bt_inner_batch_nt<1024, 2, 1>(lps, ids, count, nlp, s); }
+    else bt_inner_batch_nt<512, 4, 0>(lps, ids, count, nlp, s);
+}
+void launch_bt_update_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s) {
+    const int gx = (2 * ldt_max + kBlock - 1) / kBlock;
+    const int ntr = (m_max + 3) / 4;
+    int tr = 16;   // tile rows per workgroup; at least 32 workgroups per relaxation (the CUs of one XCD)
+    while (tr > 4 && gx * ((ntr + tr - 1) / tr) < 32) tr >>= 1;
+    const int gy = (ntr + tr - 1) / tr;
+    const int nlp_pad = (nlp + 7) & ~7;
+    hipLaunchKernelGGL((k_bt_update_tiled_batch<8>), dim3((unsigned int)(gx * gy * nlp_pad)), dim3(kBlock), 0, s, lps, ids, count, nlp_pad, gx, tr);
+}
+
 void launch_bt_tile(const double *src, double *dst, int m, int ldt, bool to_tiles, hipStream_t s) {
     const size_t pieces = (size_t)((m + 3) / 4) * 4 * (size_t)(ldt / 4);
     hipLaunchKernelGGL(k_bt_tile, dim3((unsigned int)((pieces + 255) / 256)), dim3(256), 0, s, src, dst, m, ldt, to_tiles ? 1 : 0);

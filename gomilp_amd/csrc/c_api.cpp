@@ -4,6 +4,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -12,19 +15,68 @@
 #include <vector>
 
 #include "engine.hpp"
+#include "engine_batch.hpp"
 
+using gomilp::BatchEngine;
 using gomilp::Engine;
 
 struct gomilp_ctx {
     std::unique_ptr<Engine> eng;
 };
 
-// One worker = one Engine (stream + work buffers) with its own resident copy of the root.
+// One worker = one Engine (stream + work buffers) with its own resident copy of the root and a persistent host thread;
+// the pivot loops of a wave run device-batched on the pool's BatchEngine (engine_batch.hpp), the workers take what is
+// left per relaxation: the final gonum-order solve of a finished basis, or a whole solve where the batched schedule
+// hands a relaxation back.
 struct gomilp_pool {
     int device = 0;
     std::vector<std::unique_ptr<Engine>> eng;
     std::vector<int64_t> root;  // root problem id inside each engine
     int64_t m0 = 0, n0 = 0;
+    int batched = 1;            // knob: 0 = every relaxation through a worker's single-relaxation engine (round-1 path)
+    std::unique_ptr<BatchEngine> batch;
+    Engine::RootView view;      // of eng[0]'s root (all workers hold the same data)
+    std::mutex call_mu;         // one wave at a time per pool
+    // persistent workers
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv, cv_idle;
+    std::deque<std::function<void(int)>> queue;
+    int busy = 0;
+    bool stop = false;
+
+    void worker(int w) {
+        for (;;) {
+            std::function<void(int)> task;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !queue.empty(); });
+                if (stop && queue.empty()) return;
+                task = std::move(queue.front());
+                queue.pop_front();
+                busy++;
+            }
+            task(w);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                busy--;
+                if (queue.empty() && busy == 0) cv_idle.notify_all();
+            }
+        }
+    }
+    void submit(std::function<void(int)> f) {
+        { std::lock_guard<std::mutex> lk(mu); queue.push_back(std::move(f)); }
+        cv.notify_one();
+    }
+    void drain() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_idle.wait(lk, [&] { return queue.empty() && busy == 0; });
+    }
+    ~gomilp_pool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : threads) t.join();
+    }
 };
 
 extern "C" {
@@ -77,14 +129,26 @@ gomilp_pool *gomilp_pool_create(int device, int workers, int *status) {
     gomilp_pool *p = new gomilp_pool;
     p->device = device;
     for (int w = 0; w < workers; w++) { p->eng.emplace_back(new Engine(device)); p->root.push_back(-1); }
+    p->batch.reset(new BatchEngine(device));
+    for (int w = 0; w < workers; w++) p->threads.emplace_back([p, w] { p->worker(w); });
     if (status) *status = GOMILP_OK;
     return p;
 }
 void gomilp_pool_destroy(gomilp_pool *pool) { delete pool; }
 
+int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value) {
+    if (!pool || !key) return GOMILP_ERR_BAD_SHAPE;
+    std::lock_guard<std::mutex> g(pool->call_mu);
+    if (std::string(key) == "batched") { pool->batched = value ? 1 : 0; return GOMILP_OK; }
+    int rc = GOMILP_OK;
+    for (auto &e : pool->eng) { const int r = e->set(key, value); if (r != GOMILP_OK) rc = r; }
+    return rc;
+}
+
 int gomilp_pool_set_root(gomilp_pool *pool, const double *c0, const double *A0, int64_t lda, const double *b0, int64_t m0,
                          int64_t n0) {
     if (!pool) return GOMILP_ERR_BAD_SHAPE;
+    std::lock_guard<std::mutex> g(pool->call_mu);
     for (size_t w = 0; w < pool->eng.size(); w++) {
         if (pool->root[w] >= 0) pool->eng[w]->free_problem(pool->root[w]);
         int64_t id = pool->eng[w]->upload(c0, A0, lda, b0, m0, n0);
@@ -92,6 +156,7 @@ int gomilp_pool_set_root(gomilp_pool *pool, const double *c0, const double *A0, 
         pool->root[w] = id;
     }
     pool->m0 = m0; pool->n0 = n0;
+    if (!pool->eng[0]->root_view(pool->root[0], &pool->view)) return GOMILP_ERR_DEVICE;
     return GOMILP_OK;
 }
 
@@ -100,48 +165,91 @@ int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff,
                           int32_t *has_x_out, gomilp_frontier_stats *stats) {
     if (!pool || count < 0 || !koff || !z_out || !x_out || !status_out || !has_x_out) return GOMILP_ERR_BAD_SHAPE;
     for (auto r : pool->root) if (r < 0) return GOMILP_ERR_BAD_SHAPE;
+    std::lock_guard<std::mutex> call_guard(pool->call_mu);
     const auto t0 = std::chrono::steady_clock::now();
     const int64_t n0 = pool->n0;
-    std::atomic<int64_t> next(0);
     const int W = (int)pool->eng.size();
     std::vector<gomilp_frontier_stats> ws(W);
-    auto work = [&](int w) {
+    for (auto &S : ws) S = gomilp_frontier_stats();
+    for (int64_t i = 0; i < count; i++) { z_out[i] = NAN; has_x_out[i] = 0; status_out[i] = GOMILP_ERR_DEVICE; }
+    auto busy_since = [](std::chrono::steady_clock::time_point s0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count(); };
+    // a whole relaxation on worker w's engine (the round-1 path; also the fall-back of the batched schedule)
+    auto full_solve = [&](int w, int64_t i) {
+        const auto s0 = std::chrono::steady_clock::now();
         Engine &E = *pool->eng[w];
         gomilp_frontier_stats &S = ws[w];
-        S = gomilp_frontier_stats();
-        std::vector<double> x;
-        for (;;) {
-            const int64_t i = next.fetch_add(1);
-            if (i >= count) break;
-            const auto s0 = std::chrono::steady_clock::now();
-            const int64_t k0 = koff[i], K = koff[i + 1] - koff[i];
-            z_out[i] = NAN; has_x_out[i] = 0;
-            int64_t id = E.upload_child(pool->root[w], (int)K, var + k0, sign + k0, rhs + k0);
-            if (id < 0) { status_out[i] = (int32_t)-id; continue; }
-            x.assign((size_t)(n0 + K), 0.0);
-            gomilp_lp_stats st;
-            int32_t hx = 0;
-            double z = NAN;
-            const int rc = E.solve(id, tol, nullptr, &z, x.data(), &hx, nullptr, &st);
-            E.free_problem(id);
-            status_out[i] = rc; z_out[i] = z; has_x_out[i] = hx;
-            if (hx) for (int64_t j = 0; j < n0; j++) x_out[i * n0 + j] = x[j];  // subproblem.go:157-159
-            S.relaxations++; S.pivots_phase1 += st.pivots_phase1; S.pivots_phase2 += st.pivots_phase2;
-            S.bland_steps += st.bland_steps; S.phase1_runs += st.phase1_used; S.kernel_launches += st.kernel_launches;
-            S.seconds_busy_sum += std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count();
-        }
+        const int64_t k0 = koff[i], K = koff[i + 1] - koff[i];
+        int64_t id = E.upload_child(pool->root[w], (int)K, var + k0, sign + k0, rhs + k0);
+        if (id < 0) { status_out[i] = (int32_t)-id; return; }
+        std::vector<double> x((size_t)(n0 + K), 0.0);
+        gomilp_lp_stats st;
+        int32_t hx = 0;
+        double z = NAN;
+        const int rc = E.solve(id, tol, nullptr, &z, x.data(), &hx, nullptr, &st);
+        E.free_problem(id);
+        status_out[i] = rc; z_out[i] = z; has_x_out[i] = hx;
+        if (hx) for (int64_t j = 0; j < n0; j++) x_out[i * n0 + j] = x[j];  // subproblem.go:157-159
+        S.relaxations++; S.pivots_phase1 += st.pivots_phase1; S.pivots_phase2 += st.pivots_phase2;
+        S.bland_steps += st.bland_steps; S.phase1_runs += st.phase1_used; S.kernel_launches += st.kernel_launches;
+        S.seconds_busy_sum += busy_since(s0);
     };
-    std::vector<std::thread> th;
-    for (int w = 1; w < W; w++) th.emplace_back(work, w);
-    work(0);
-    for (auto &t : th) t.join();
+    // the epilogue of a relaxation whose pivot loops ran device-batched: final gonum-order solve of its basis
+    auto finish = [&](int w, int64_t i, const int32_t *basic, const double *xb, int loop_rc) {
+        const auto s0 = std::chrono::steady_clock::now();
+        Engine &E = *pool->eng[w];
+        gomilp_frontier_stats &S = ws[w];
+        const int64_t k0 = koff[i], K = koff[i + 1] - koff[i];
+        int64_t id = E.upload_child(pool->root[w], (int)K, var + k0, sign + k0, rhs + k0);
+        if (id < 0) { status_out[i] = (int32_t)-id; return; }
+        std::vector<double> x((size_t)(n0 + K), 0.0);
+        gomilp_lp_stats st;
+        int32_t hx = 0;
+        double z = NAN;
+        const int rc = E.finish_from_basis(id, basic, xb, loop_rc, &z, x.data(), &hx, nullptr, &st);
+        E.free_problem(id);
+        status_out[i] = rc; z_out[i] = z; has_x_out[i] = hx;
+        if (hx) for (int64_t j = 0; j < n0; j++) x_out[i * n0 + j] = x[j];
+        S.kernel_launches += st.kernel_launches;
+        S.seconds_busy_sum += busy_since(s0);
+    };
+    int K_max = 0;
+    for (int64_t i = 0; i < count; i++) K_max = std::max<int>(K_max, (int)(koff[i + 1] - koff[i]));
+    gomilp_frontier_stats agg = gomilp_frontier_stats();
+    BatchEngine::Stats bs;
+    const bool use_batch = pool->batched && count > 0 && pool->batch->eligible(pool->view, K_max);
+    if (use_batch) {
+        auto on_done = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) {
+            if (o.stage != gomilp::BS_DONE) {   // a path the device schedule does not cover
+                agg.host_fallbacks++;
+                pool->submit([&full_solve, i](int w) { full_solve(w, i); });
+                return;
+            }
+            agg.relaxations++; agg.batched_relaxations++;
+            agg.pivots_phase1 += o.piv1; agg.pivots_phase2 += o.piv2; agg.bland_steps += o.bland; agg.phase1_runs += o.phase1_used;
+            if (o.status == GOMILP_OK || o.status == GOMILP_ERR_BLAND) {
+                const int rc0 = o.status;
+                pool->submit([&finish, i, basic, xb, rc0](int w) { finish(w, i, basic, xb, rc0); });
+            } else {
+                status_out[i] = o.status;
+                if (o.status == GOMILP_ERR_UNBOUNDED) z_out[i] = -INFINITY;   // simplex.go:261-263
+            }
+        };
+        const int rc = pool->batch->run(pool->view, count, koff, var, sign, rhs, tol, on_done, &bs);
+        pool->drain();
+        if (rc != GOMILP_OK) return rc;
+    } else {
+        for (int64_t i = 0; i < count; i++) pool->submit([&full_solve, i](int w) { full_solve(w, i); });
+        pool->drain();
+    }
     if (stats) {
-        *stats = gomilp_frontier_stats();
+        *stats = agg;
         for (auto &S : ws) {
             stats->relaxations += S.relaxations; stats->pivots_phase1 += S.pivots_phase1; stats->pivots_phase2 += S.pivots_phase2;
             stats->bland_steps += S.bland_steps; stats->phase1_runs += S.phase1_runs; stats->kernel_launches += S.kernel_launches;
             stats->seconds_busy_sum += S.seconds_busy_sum;
         }
+        stats->kernel_launches += bs.launches;
+        stats->supersteps = bs.supersteps; stats->seconds_batch = bs.seconds_total;
         stats->workers = W; stats->device_id = pool->device;
         stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }

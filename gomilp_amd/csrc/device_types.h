@@ -12,7 +12,8 @@ enum : int32_t {
     ST_NEED_BLAND = 3,  // move[replace] <= 0: degenerate     (simplex.go:269)
     ST_MAX_PIVOTS = 4,  // safety cap hit
     ST_LU_SINGULAR = 5,  // exact zero pivot in the final gonum-order LU
-    ST_BLAND_FAILED = 6  // replaceBland exhausted its candidates (lp.ErrBland, simplex.go:382)
+    ST_BLAND_FAILED = 6,  // replaceBland exhausted its candidates (lp.ErrBland, simplex.go:382)
+    ST_FORCED_DONE = 7    // a set-up pivot ordered with forced_nocommit = 3 has run: later launches of the superstep are no-ops
 };
 
 constexpr int kMaxPartials = 1024;  // per-workgroup partial arg-reductions (grid <= 1024 workgroups)
@@ -124,6 +125,49 @@ struct BTArgs {
     int32_t nt_force;     // context knob "bt_nt": 0 = pick the thread count by shape, else 256 / 512 / 1024
     int32_t tiled, old_only;  // T is in the 4x4-tile layout of the register-resident inner kernel; knob "bt_old"
     unsigned long long *stamps;   // diagnostic build only (knob "bt_stamps"): per-wave cycle sums per pivot segment
+};
+
+// ---- device-batched relaxations (batch_kernels.hip, engine_batch.cpp) ------------------------------------------------
+// One BatchLP per relaxation of a wave, resident in HBM.  `bt` is the argument block of the block kernels for the
+// relaxation's current phase; the control kernel (k_b_ctrl) rewrites it at the phase changes, so the host enqueues a fixed
+// schedule of launches with grid.x / grid.z = relaxation and never waits for a single relaxation.
+enum : int32_t {
+    BS_FORCED = 0,    // Phase I needed: the set-up pivot (artificial enters at argmin x_B) is queued as a forced pivot
+    BS_P2_START = 1,  // slack basis feasible: Phase II starts after the reduced costs are built
+    BS_P1 = 2,        // Phase-I loop running
+    BS_P2 = 3,        // Phase-II loop running
+    BS_EXCH = 6,      // the zero-level artificial is being exchanged out of the basis (one forced pivot, simplex.go:581-606)
+    BS_DONE = 4,      // terminal: `status` holds the outcome (GOMILP_OK = basis + x_B ready for the final gonum-order solve)
+    BS_HOST = 5       // terminal: a path the device schedule does not cover (artificial exchange, guard band, ...): the
+                      // host solves this relaxation through the single-relaxation engine
+};
+
+struct BatchLP {
+    BTArgs bt;
+    // root data (shared by the children of a frontier) and this child's branch-and-bound rows (subproblem.go:36-44)
+    const double *At0;       // (n0 + 1) x ld0 : row j = column j of the root A
+    const double *c0, *b0;   // root cost (n0), right-hand side (m0)
+    const int32_t *rho0;     // m0 : row of the 1 in root column n0 - 1 - pos (the unit columns the descending scan meets)
+    const int32_t *var;      // K
+    const double *sign, *rhs;
+    int32_t ld0, m0, n0, K;
+    int32_t m, n;            // child: m0 + K, n0 + K
+    int32_t ldu, cap_ldt;    // padded row count (U rows), row length the T buffers were sized for
+    double *T[2];            // tableau buffers (4x4 tiles); bt.T is the current one
+    double *R, *xb, *U, *V, *scratch, *art;
+    int32_t *basic, *nonbasic, *srcpos;
+    DevState *st;
+    double tol_user;         // Phase-II tolerance of the call (GoMILP: 0)
+    int32_t stage;           // BS_*
+    int32_t tcur;            // index of the current T buffer
+    int32_t do_permute, do_r, r_phase;   // work orders for the set-up kernels of this superstep (written by k_b_ctrl)
+    int32_t perm_ld_in, perm_nn_out;     // k_b_permute: row length of the source, columns of the target
+    int32_t kblock;          // pivots per block (8)
+    // outcome
+    int32_t status;          // gomilp_status
+    int32_t wrapped;         // inner status of GOMILP_ERR_PHASE1_WRAPPED
+    int32_t phase1_used, pad0;
+    int64_t piv1, piv2, bland;
 };
 
 // Control block of the compressed LU schedule (lu_compressed.hip): written by the panel kernel of a round, read by the

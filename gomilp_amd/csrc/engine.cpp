@@ -1106,8 +1106,35 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(sync_stream());
     for (int i = 0; i < m; i++) { basic[i] = w.h_idx[i]; xb[i] = w.h_vec[i]; }
+    rc = epilogue(P, basic, xb, loop_rc, opt_f, opt_x, has_x, basis_out, st);
+    if (rc == GOMILP_ERR_DEVICE) return finish(rc);
+    if (trace_on_) {
+        HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(sync_stream());
+        last_trace_total_ = w.st_host->trace_len;
+        const int64_t cnt = std::min<int64_t>(last_trace_total_, w.trace_cap);
+        std::vector<DevPivot> tmp((size_t)cnt);
+        if (cnt) HIP_TRY(hipMemcpy(tmp.data(), w.trace, (size_t)cnt * sizeof(DevPivot), hipMemcpyDeviceToHost));
+        last_trace_.resize((size_t)cnt);
+        for (int64_t i = 0; i < cnt; i++) {
+            last_trace_[i].phase = tmp[i].phase; last_trace_[i].bland = tmp[i].bland;
+            last_trace_[i].min_idx = tmp[i].min_idx; last_trace_[i].replace = tmp[i].replace;
+            last_trace_[i].entering = tmp[i].entering; last_trace_[i].leaving = tmp[i].leaving;
+        }
+    }
+    return finish(rc);
+}
+
+// x_B = ab^-1 b from a fresh gonum-order LU of the final basis (the device list w.basic must hold `basic`), z = DotUnitary,
+// scatter (simplex.go:296-301).  Returns loop_rc (or mat.Condition when the final basis is exactly singular).
+int Engine::epilogue(const Problem &P, std::vector<int32_t> &basic, std::vector<double> &xb, int loop_rc, double *opt_f,
+                     double *opt_x, int32_t *has_x, int64_t *basis_out, gomilp_lp_stats *st) {
+    const int m = P.m, n = P.n;
+    std::vector<double> xb_exact;
+    bool singular = false;
     const double t1 = now_s();
-    if ((rc = final_solve(P, n, xb_exact, &singular, basic.data())) != GOMILP_OK) return finish(rc);
+    int rc = final_solve(P, n, xb_exact, &singular, basic.data());
+    if (rc != GOMILP_OK) return rc;
     st->seconds_final_solve = now_s() - t1;
     if (singular) {
         xb_exact = xb;  // the reference keeps its previous x_B when Det()==0 (mat/lu.go:301); ours is the updated one
@@ -1123,21 +1150,49 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     for (int i = 0; i < m; i++) opt_x[basic[i]] = xb_exact[i];
     *has_x = 1;
     if (basis_out) for (int i = 0; i < m; i++) basis_out[i] = basic[i];
-    if (trace_on_) {
-        HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(sync_stream());
-        last_trace_total_ = w.st_host->trace_len;
-        const int64_t cnt = std::min<int64_t>(last_trace_total_, w.trace_cap);
-        std::vector<DevPivot> tmp((size_t)cnt);
-        if (cnt) HIP_TRY(hipMemcpy(tmp.data(), w.trace, (size_t)cnt * sizeof(DevPivot), hipMemcpyDeviceToHost));
-        last_trace_.resize((size_t)cnt);
-        for (int64_t i = 0; i < cnt; i++) {
-            last_trace_[i].phase = tmp[i].phase; last_trace_[i].bland = tmp[i].bland;
-            last_trace_[i].min_idx = tmp[i].min_idx; last_trace_[i].replace = tmp[i].replace;
-            last_trace_[i].entering = tmp[i].entering; last_trace_[i].leaving = tmp[i].leaving;
-        }
+    return loop_rc;
+}
+
+bool Engine::root_view(int64_t id, RootView *out) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (id < 0 || (size_t)id >= problems_.size() || !problems_[id]) return false;
+    const Problem &P = *problems_[id];
+    out->m = P.m; out->n = P.n; out->ld = P.ld; out->dAt = P.dAt; out->dc = P.dc; out->db = P.db;
+    out->verify_status = P.verify_status;
+    out->rho0.assign(P.m, 0);
+    out->unit_basis = P.m < P.n;
+    std::vector<char> used(P.m, 0);
+    for (int pos = 0; pos < P.m && out->unit_basis; pos++) {
+        const int j = P.n - 1 - pos;
+        if (!(P.nnz[j] == 1 && P.allone[j]) || used[P.lastrow[j]]) { out->unit_basis = false; break; }
+        out->rho0[pos] = P.lastrow[j]; used[P.lastrow[j]] = 1;
     }
-    return finish(loop_rc);
+    return true;
+}
+
+int Engine::finish_from_basis(int64_t id, const int32_t *basic_in, const double *xb_updated, int loop_rc, double *opt_f,
+                              double *opt_x, int32_t *has_x, int64_t *basis_out, gomilp_lp_stats *stats) {
+    std::lock_guard<std::mutex> g(mu_);
+    const double t0 = now_s();
+    gomilp_lp_stats local;
+    gomilp_lp_stats *st = stats ? stats : &local;
+    memset(st, 0, sizeof(*st));
+    st->device_id = device_;
+    if (has_x) *has_x = 0;
+    if (opt_f) *opt_f = std::numeric_limits<double>::quiet_NaN();
+    if (id < 0 || (size_t)id >= problems_.size() || !problems_[id] || !opt_f || !opt_x || !has_x || !basic_in || !xb_updated) return GOMILP_ERR_BAD_SHAPE;
+    const Problem &P = *problems_[id];
+    launches_ = 0; fs_device_ = fs_host_ = 0;
+    int rc = ensure_work(P.m, P.n + 1);
+    if (rc != GOMILP_OK) return rc;
+    std::vector<int32_t> basic(basic_in, basic_in + P.m);
+    std::vector<double> xb(xb_updated, xb_updated + P.m);
+    if ((rc = upload_index_lists(basic, {})) != GOMILP_OK) return rc;
+    rc = epilogue(P, basic, xb, loop_rc, opt_f, opt_x, has_x, basis_out, st);
+    st->seconds_total = now_s() - t0; st->kernel_launches = launches_;
+    st->seconds_final_device = fs_device_; st->seconds_final_host = fs_host_;
+    st->lu_dense_steps = lu_dense_; st->lu_rounds = lu_rounds_;
+    return rc;
 }
 
 int64_t Engine::last_trace(gomilp_pivot *out, int64_t cap) {

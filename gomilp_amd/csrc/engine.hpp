@@ -55,6 +55,21 @@ class Engine {
               int64_t *basis_out, gomilp_lp_stats *stats);
     int64_t last_trace(gomilp_pivot *out, int64_t cap);
 
+    // ---- hooks of the device-batched frontier (engine_batch.cpp) ----
+    // device pointers / statistics of a resident problem: the batch engine reads the root's columns where they lie
+    struct RootView {
+        int m = 0, n = 0, ld = 0;
+        const double *dAt = nullptr, *dc = nullptr, *db = nullptr;
+        bool unit_basis = false;          // the descending scan of simplex.go:618-635 meets m distinct unit columns
+        std::vector<int32_t> rho0;        // their rows, by basis position
+        int verify_status = GOMILP_OK;
+    };
+    bool root_view(int64_t id, RootView *out);
+    // epilogue of simplex() (simplex.go:296-301) for a relaxation whose pivot loop ran elsewhere: final basis positions
+    // `basic` (m entries) and updated x_B in, gonum-order solve of that basis, z, x out; `loop_rc` as Engine::solve
+    int finish_from_basis(int64_t id, const int32_t *basic, const double *xb_updated, int loop_rc, double *opt_f, double *opt_x,
+                          int32_t *has_x, int64_t *basis_out, gomilp_lp_stats *stats);
+
    private:
     struct Work;  // device work buffers, sized for the largest problem seen
     int ensure_work(int m, int ncols);
@@ -76,6 +91,8 @@ class Engine {
     void account_samples(gomilp_lp_stats *st, const std::vector<int64_t> &sample_t, int64_t executed, int nk);
     int host_bland(const Problem &P, LPArgs &a, gomilp_lp_stats *st);
     int refresh_xb_y(const Problem &P, const double *cost);
+    int epilogue(const Problem &P, std::vector<int32_t> &basic, std::vector<double> &xb, int loop_rc, double *opt_f, double *opt_x,
+                 int32_t *has_x, int64_t *basis_out, gomilp_lp_stats *st);
     int final_solve(const Problem &P, int ncols_rows, std::vector<double> &xb_exact, bool *singular, const int32_t *basic_host = nullptr);
     bool ensure_host_A(const Problem &P);
     int stage_upload(void *dst, const void *src, size_t bytes);
@@ -146,6 +163,17 @@ constexpr int kBtStampSegs = 16;   // cycle sums per wave written by the diagnos
 void launch_bt_tile(const double *src, double *dst, int m, int ldt, bool to_tiles, hipStream_t s);
 void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 void launch_bt_update(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+bool bt_batch_supported(int m_max, int ldt_max);
+void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s);
+void launch_bt_update_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s);
+// batch_kernels.hip
+int batch_ldt(int nn);
+void launch_b_setup(BatchLP *lps, int nlp, hipStream_t s);
+void launch_b_gather(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s);
+void launch_b_ctrl(BatchLP *lps, int nlp, int n_max, int *ids_out, int *active_slot, hipStream_t s);
+void launch_b_init_ids(int *ids, int *count, int nlp, hipStream_t s);
+void launch_b_permute(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s);
+void launch_b_tab_r(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s);
 void launch_transpose_in(const double *A, int64_t lda, int m, int n, double *At, int ld, hipStream_t s);
 void launch_col_stats(const double *At, int ld, int m, int n, int32_t *nnz, int32_t *lastrow, int32_t *allone,
                       int32_t *rowflag, hipStream_t s);

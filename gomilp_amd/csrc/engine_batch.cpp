@@ -1,0 +1,298 @@
+// Host side of the device-batched wave (engine_batch.hpp): buffers for `count` relaxations, the fixed launch schedule,
+// and the hand-over of finished relaxations while the others keep pivoting.
+#include "engine_batch.hpp"
+
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+
+namespace gomilp {
+
+namespace {
+double bnow() {
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+#define B_TRY(expr)                                     \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return GOMILP_ERR_DEVICE; \
+    } while (0)
+constexpr int kRing = 2;          // snapshots in flight
+constexpr int kMaxSteps = 4096;   // supersteps per wave (slots of the active counter; the last slot serves the prologue)
+constexpr int kBlockK = 8;        // pivots per block: the register-resident kernel (bt_kernels.hip)
+template <typename T>
+hipError_t bmalloc(T **p, size_t count) { return hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T)); }
+template <typename T>
+hipError_t bhost(T **p, size_t count) { return hipHostMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault); }
+}  // namespace
+
+struct BatchEngine::Buf {
+    int cap_lp = 0, cap_m4 = 0, cap_ldt = 0, cap_ldu = 0, cap_n = 0;
+    int64_t cap_k = 0;
+    BatchLP *d_lps = nullptr, *h_lps = nullptr;            // device array, pinned build area
+    BatchLP *h_snap[kRing] = {nullptr, nullptr};           // pinned snapshots of the device array, one per superstep in flight
+    int *h_active[kRing] = {nullptr, nullptr};
+    hipEvent_t ev[kRing] = {nullptr, nullptr};
+    double *d_T = nullptr, *d_R = nullptr, *d_xb = nullptr, *d_U = nullptr, *d_V = nullptr, *d_scratch = nullptr, *d_art = nullptr;
+    int32_t *d_basic = nullptr, *d_nonbasic = nullptr, *d_srcpos = nullptr;
+    DevState *d_st = nullptr;
+    int32_t *d_var = nullptr, *h_var = nullptr;
+    double *d_sr = nullptr, *h_sr = nullptr;               // sign | rhs
+    int32_t *d_rho0 = nullptr;
+    const double *rho_key = nullptr; int rho_m0 = 0, rho_n0 = 0;
+    int *d_active = nullptr;
+    int *d_ids[2] = {nullptr, nullptr};   // active lists, double buffered by superstep parity
+    int32_t *h_basic = nullptr;                            // pinned result arenas
+    double *h_xb = nullptr;
+    std::vector<hipEvent_t> lp_ev;
+
+    void free_lp_buffers() {
+        for (void *p : {(void *)d_lps, (void *)d_T, (void *)d_R, (void *)d_xb, (void *)d_U, (void *)d_V, (void *)d_scratch, (void *)d_art,
+                        (void *)d_basic, (void *)d_nonbasic, (void *)d_srcpos, (void *)d_st, (void *)d_ids[0], (void *)d_ids[1]})
+            if (p) hipFree(p);
+        d_lps = nullptr; d_T = d_R = d_xb = d_U = d_V = d_scratch = d_art = nullptr; d_basic = d_nonbasic = d_srcpos = nullptr; d_st = nullptr; d_ids[0] = d_ids[1] = nullptr;
+        for (void *p : {(void *)h_lps, (void *)h_snap[0], (void *)h_snap[1], (void *)h_basic, (void *)h_xb})
+            if (p) hipHostFree(p);
+        h_lps = h_snap[0] = h_snap[1] = nullptr; h_basic = nullptr; h_xb = nullptr;
+        cap_lp = cap_m4 = cap_ldt = cap_ldu = cap_n = 0;
+    }
+    void free_all() {
+        free_lp_buffers();
+        for (void *p : {(void *)d_var, (void *)d_sr, (void *)d_rho0, (void *)d_active}) if (p) hipFree(p);
+        for (void *p : {(void *)h_var, (void *)h_sr, (void *)h_active[0], (void *)h_active[1]}) if (p) hipHostFree(p);
+        d_var = nullptr; d_sr = nullptr; d_rho0 = nullptr; d_active = nullptr; h_var = nullptr; h_sr = nullptr; h_active[0] = h_active[1] = nullptr;
+        for (auto &e : ev) { if (e) hipEventDestroy(e); e = nullptr; }
+        for (auto &e : lp_ev) hipEventDestroy(e);
+        lp_ev.clear();
+        cap_k = 0;
+    }
+};
+
+BatchEngine::BatchEngine(int device) : device_(device), b_(new Buf) {}
+
+BatchEngine::~BatchEngine() {
+    hipSetDevice(device_);
+    if (stream_) hipStreamSynchronize(stream_);
+    if (copy_stream_) hipStreamSynchronize(copy_stream_);
+    b_->free_all();
+    delete b_;
+    if (stream_) hipStreamDestroy(stream_);
+    if (copy_stream_) hipStreamDestroy(copy_stream_);
+}
+
+bool BatchEngine::eligible(const Engine::RootView &R, int K_max) const {
+    if (R.verify_status != GOMILP_OK || !R.unit_basis) return false;
+    const int m = R.m + K_max, n = R.n + K_max;
+    if (m >= n || !((n - m) < 2 * m)) return false;              // the tableau formulation (engine.cpp: use_tab)
+    if (n + 2 > 8000) return false;                              // k_b_ctrl keeps two int lists of n in (default-limit) LDS
+    const int ldt1 = batch_ldt(n - m + 1);
+    return bt_batch_supported(m, ldt1);
+}
+
+int BatchEngine::ensure(int nlp, int m_max, int n_max, int ldt1, int64_t ktot) {
+    B_TRY(hipSetDevice(device_));
+    if (!stream_) B_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    if (!copy_stream_) B_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    Buf &b = *b_;
+    if (!b.d_active) {
+        B_TRY(bmalloc(&b.d_active, kMaxSteps));
+        for (int r = 0; r < kRing; r++) {
+            B_TRY(bhost(&b.h_active[r], 1));
+            B_TRY(hipEventCreateWithFlags(&b.ev[r], hipEventDisableTiming));
+        }
+    }
+    const int m4 = (m_max + 3) & ~3, ldu = (m_max + 1) & ~1;
+    if (nlp > b.cap_lp || m4 > b.cap_m4 || ldt1 > b.cap_ldt || ldu > b.cap_ldu || n_max > b.cap_n) {
+        B_TRY(hipStreamSynchronize(stream_));
+        B_TRY(hipStreamSynchronize(copy_stream_));
+        const int clp = std::max(nlp, b.cap_lp), cm4 = std::max(m4 + 8, b.cap_m4), cldt = std::max(ldt1, b.cap_ldt),
+                  cldu = std::max(ldu + 8, b.cap_ldu), cn = std::max(n_max + 8, b.cap_n);   // head-room: deeper children add a row each
+        b.free_lp_buffers();
+        const size_t L = (size_t)clp;
+        B_TRY(bmalloc(&b.d_lps, L));
+        B_TRY(bhost(&b.h_lps, L));
+        for (int r = 0; r < kRing; r++) B_TRY(bhost(&b.h_snap[r], L));
+        B_TRY(bmalloc(&b.d_T, L * 2 * (size_t)cm4 * cldt));
+        B_TRY(bmalloc(&b.d_R, L * cldt)); B_TRY(bmalloc(&b.d_xb, L * cldu)); B_TRY(bmalloc(&b.d_art, L * cldu));
+        B_TRY(bmalloc(&b.d_U, L * kBlockK * cldu)); B_TRY(bmalloc(&b.d_V, L * kBlockK * cldt));
+        B_TRY(bmalloc(&b.d_scratch, L * 64 * cldt));
+        B_TRY(bmalloc(&b.d_basic, L * cldu)); B_TRY(bmalloc(&b.d_nonbasic, L * cldt)); B_TRY(bmalloc(&b.d_srcpos, L * cldt));
+        B_TRY(bmalloc(&b.d_st, L));
+        B_TRY(bmalloc(&b.d_ids[0], L)); B_TRY(bmalloc(&b.d_ids[1], L));
+        B_TRY(bhost(&b.h_basic, L * cldu)); B_TRY(bhost(&b.h_xb, L * cldu));
+        b.cap_lp = clp; b.cap_m4 = cm4; b.cap_ldt = cldt; b.cap_ldu = cldu; b.cap_n = cn;
+        while ((int)b.lp_ev.size() < clp) { hipEvent_t e; B_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); b.lp_ev.push_back(e); }
+    }
+    if (ktot > b.cap_k) {
+        B_TRY(hipStreamSynchronize(stream_));
+        for (void *p : {(void *)b.d_var, (void *)b.d_sr}) if (p) hipFree(p);
+        for (void *p : {(void *)b.h_var, (void *)b.h_sr}) if (p) hipHostFree(p);
+        b.d_var = nullptr; b.d_sr = nullptr; b.h_var = nullptr; b.h_sr = nullptr;
+        const int64_t ck = std::max<int64_t>(2 * ktot, 1024);
+        B_TRY(bmalloc(&b.d_var, (size_t)ck)); B_TRY(bmalloc(&b.d_sr, (size_t)2 * ck));
+        B_TRY(bhost(&b.h_var, (size_t)ck)); B_TRY(bhost(&b.h_sr, (size_t)2 * ck));
+        b.cap_k = ck;
+    }
+    return GOMILP_OK;
+}
+
+int BatchEngine::run(const Engine::RootView &R, int64_t count, const int64_t *koff, const int32_t *var, const double *sign,
+                     const double *rhs, double tol, const DoneFn &on_done, Stats *stats) {
+    const double t0 = bnow();
+    Stats local;
+    Stats &S = stats ? *stats : local;
+    S = Stats();
+    if (count <= 0) return GOMILP_OK;
+    if (count > 65535) return GOMILP_ERR_UNSUPPORTED;
+    const int nlp = (int)count;
+    int K_max = 0;
+    for (int i = 0; i < nlp; i++) K_max = std::max<int>(K_max, (int)(koff[i + 1] - koff[i]));
+    const int64_t ktot = koff[nlp] - koff[0];
+    const int m_max = R.m + K_max, n_max = R.n + K_max;
+    const int ldt1 = batch_ldt(R.n - R.m + 1);   // Phase-I tableau: one column more (the artificial); the same for every child
+    int rc = ensure(nlp, m_max, n_max, ldt1, ktot);
+    if (rc != GOMILP_OK) return rc;
+    Buf &b = *b_;
+    // ---- root data the kernels read in place + the unit-column rows of the root's slack basis
+    if (b.rho_key != R.dAt || b.rho_m0 != R.m || b.rho_n0 != R.n) {
+        B_TRY(hipStreamSynchronize(stream_));
+        if (b.d_rho0) hipFree(b.d_rho0);
+        b.d_rho0 = nullptr;
+        B_TRY(bmalloc(&b.d_rho0, (size_t)R.m));
+        B_TRY(hipMemcpy(b.d_rho0, R.rho0.data(), (size_t)R.m * sizeof(int32_t), hipMemcpyHostToDevice));
+        b.rho_key = R.dAt; b.rho_m0 = R.m; b.rho_n0 = R.n;
+    }
+    // ---- per-relaxation argument blocks
+    const size_t sT = (size_t)b.cap_m4 * b.cap_ldt;
+    for (int64_t k = 0; k < ktot; k++) { b.h_var[k] = var[koff[0] + k]; b.h_sr[k] = sign[koff[0] + k]; b.h_sr[b.cap_k + k] = rhs[koff[0] + k]; }
+    for (int i = 0; i < nlp; i++) {
+        BatchLP &lp = b.h_lps[i];
+        memset(&lp, 0, sizeof(lp));
+        const int K = (int)(koff[i + 1] - koff[i]);
+        const int64_t k0 = koff[i] - koff[0];
+        lp.At0 = R.dAt; lp.c0 = R.dc; lp.b0 = R.db; lp.rho0 = b.d_rho0;
+        lp.var = b.d_var + k0; lp.sign = b.d_sr + k0; lp.rhs = b.d_sr + b.cap_k + k0;
+        lp.ld0 = R.ld; lp.m0 = R.m; lp.n0 = R.n; lp.K = K; lp.m = R.m + K; lp.n = R.n + K;
+        lp.ldu = (lp.m + 1) & ~1; lp.cap_ldt = b.cap_ldt;
+        lp.T[0] = b.d_T + (size_t)(2 * i) * sT; lp.T[1] = b.d_T + (size_t)(2 * i + 1) * sT;
+        lp.R = b.d_R + (size_t)i * b.cap_ldt; lp.xb = b.d_xb + (size_t)i * b.cap_ldu; lp.art = b.d_art + (size_t)i * b.cap_ldu;
+        lp.U = b.d_U + (size_t)i * kBlockK * b.cap_ldu; lp.V = b.d_V + (size_t)i * kBlockK * b.cap_ldt;
+        lp.scratch = b.d_scratch + (size_t)i * 64 * b.cap_ldt;
+        lp.basic = b.d_basic + (size_t)i * b.cap_ldu; lp.nonbasic = b.d_nonbasic + (size_t)i * b.cap_ldt; lp.srcpos = b.d_srcpos + (size_t)i * b.cap_ldt;
+        lp.st = b.d_st + i;
+        lp.tol_user = tol; lp.kblock = kBlockK; lp.stage = BS_HOST;
+    }
+    B_TRY(hipMemsetAsync(b.d_active, 0, kMaxSteps * sizeof(int), stream_));
+    B_TRY(hipMemcpyAsync(b.d_lps, b.h_lps, (size_t)nlp * sizeof(BatchLP), hipMemcpyHostToDevice, stream_));
+    if (ktot) {
+        B_TRY(hipMemcpyAsync(b.d_var, b.h_var, (size_t)ktot * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        B_TRY(hipMemcpyAsync(b.d_sr, b.h_sr, (size_t)ktot * sizeof(double), hipMemcpyHostToDevice, stream_));
+        B_TRY(hipMemcpyAsync(b.d_sr + b.cap_k, b.h_sr + b.cap_k, (size_t)ktot * sizeof(double), hipMemcpyHostToDevice, stream_));
+    }
+    int step = 0;
+    int bound = nlp;   // upper bound of the active relaxations the host knows (from the last snapshot it has seen)
+    launch_b_init_ids(b.d_ids[1], b.d_active + (kMaxSteps - 1), nlp, stream_);   // list of "superstep -1": everybody
+    auto snapshot = [&](int slot) -> int {
+        B_TRY(hipMemcpyAsync(b.h_snap[slot], b.d_lps, (size_t)nlp * sizeof(BatchLP), hipMemcpyDeviceToHost, stream_));
+        B_TRY(hipMemcpyAsync(b.h_active[slot], b.d_active + step, sizeof(int), hipMemcpyDeviceToHost, stream_));
+        B_TRY(hipEventRecord(b.ev[slot], stream_));
+        return GOMILP_OK;
+    };
+    // the blocks of superstep `step` work on the active list the control step of superstep step - 1 left behind
+    auto blocks = [&](int nb) {
+        const int *ids = b.d_ids[(step + 1) & 1];
+        const int *cnt = step == 0 ? b.d_active + (kMaxSteps - 1) : b.d_active + (step - 1);
+        for (int t = 0; t < nb; t++) {
+            launch_bt_inner_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_);
+            launch_bt_update_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_);
+        }
+        S.launches += 2 * nb; S.blocks += nb;
+    };
+    auto control = [&](bool permute) {
+        launch_b_ctrl(b.d_lps, nlp, n_max, b.d_ids[step & 1], b.d_active + step, stream_);
+        if (permute) launch_b_permute(b.d_lps, nlp, m_max, ldt1, stream_);
+        launch_b_tab_r(b.d_lps, nlp, m_max, ldt1, stream_);
+        S.launches += permute ? 5 : 4;
+    };
+    // ---- prologue: set-up, T, the forced Phase-I pivots, first reduced costs
+    launch_b_setup(b.d_lps, nlp, stream_);
+    launch_b_gather(b.d_lps, nlp, m_max, ldt1, stream_);
+    S.launches += 2;
+    blocks(1);
+    control(false);
+    if ((rc = snapshot(0)) != GOMILP_OK) return rc;
+    S.seconds_setup = bnow() - t0;
+    // ---- supersteps; finished relaxations are handed over while the others keep pivoting
+    std::vector<char> reported(nlp, 0);
+    struct Pending { int i; Outcome o; };
+    std::vector<Pending> pending;
+    auto flush_pending = [&](bool wait) {
+        for (size_t k = 0; k < pending.size();) {
+            const int i = pending[k].i;
+            hipError_t q = wait ? hipEventSynchronize(b.lp_ev[i]) : hipEventQuery(b.lp_ev[i]);
+            if (q == hipSuccess) {
+                on_done(i, pending[k].o, b.h_basic + (size_t)i * b.cap_ldu, b.h_xb + (size_t)i * b.cap_ldu);
+                pending[k] = pending.back();
+                pending.pop_back();
+            } else k++;
+        }
+    };
+    auto harvest = [&](int slot) -> int {   // look at a completed snapshot
+        for (int i = 0; i < nlp; i++) {
+            if (reported[i]) continue;
+            const BatchLP &lp = b.h_snap[slot][i];
+            if (lp.stage != BS_DONE && lp.stage != BS_HOST) continue;
+            reported[i] = 1;
+            Outcome o;
+            o.stage = lp.stage; o.status = lp.status; o.wrapped = lp.wrapped; o.phase1_used = lp.phase1_used;
+            o.piv1 = lp.piv1; o.piv2 = lp.piv2; o.bland = lp.bland;
+            if (lp.stage == BS_DONE && (lp.status == GOMILP_OK || lp.status == GOMILP_ERR_BLAND)) {
+                // terminal relaxations are never written again: their basis / x_B can leave on the second stream at once
+                B_TRY(hipMemcpyAsync(b.h_basic + (size_t)i * b.cap_ldu, b.d_basic + (size_t)i * b.cap_ldu, (size_t)lp.m * sizeof(int32_t), hipMemcpyDeviceToHost, copy_stream_));
+                B_TRY(hipMemcpyAsync(b.h_xb + (size_t)i * b.cap_ldu, b.d_xb + (size_t)i * b.cap_ldu, (size_t)lp.m * sizeof(double), hipMemcpyDeviceToHost, copy_stream_));
+                B_TRY(hipEventRecord(b.lp_ev[i], copy_stream_));
+                pending.push_back({i, o});
+            } else {
+                on_done(i, o, nullptr, nullptr);
+            }
+        }
+        return GOMILP_OK;
+    };
+    int active = nlp;
+    for (;;) {
+        const int prev_slot = step % kRing;
+        const bool last_possible = step + 1 >= kMaxSteps - 2;
+        // enqueue superstep step + 1 before waiting for the snapshot of superstep `step`: the GPU never idles for the host
+        const int nb = step < 2 ? 1 : (step < 4 ? 2 : 4);
+        step++;
+        blocks(nb);
+        control(true);
+        if ((rc = snapshot(step % kRing)) != GOMILP_OK) return rc;
+        S.supersteps++;
+        B_TRY(hipEventSynchronize(b.ev[prev_slot]));
+        B_TRY(hipGetLastError());
+        active = *b.h_active[prev_slot];
+        bound = std::max(active, 1);   // the count only falls: a safe grid size for everything enqueued from here on
+        if ((rc = harvest(prev_slot)) != GOMILP_OK) return rc;
+        flush_pending(false);
+        if (active == 0 || last_possible) break;
+    }
+    // the superstep enqueued behind the deciding snapshot: no-op launches when every relaxation was terminal
+    B_TRY(hipEventSynchronize(b.ev[step % kRing]));
+    if ((rc = harvest(step % kRing)) != GOMILP_OK) return rc;
+    for (int i = 0; i < nlp; i++)
+        if (!reported[i]) {   // superstep budget spent (never seen): the single-relaxation engine takes over
+            reported[i] = 1;
+            Outcome o;
+            o.stage = BS_HOST;
+            on_done(i, o, nullptr, nullptr);
+        }
+    flush_pending(true);
+    B_TRY(hipStreamSynchronize(stream_));
+    S.seconds_total = bnow() - t0;
+    return GOMILP_OK;
+}
+
+}  // namespace gomilp

@@ -1,0 +1,44 @@
+// Device-batched wave of LP relaxations: ONE stream, a fixed schedule of launches with grid.x / grid.z = relaxation
+// (batch_kernels.hip, bt_kernels.hip), O(1) host round trips per superstep for the WHOLE wave instead of a host thread +
+// stream per relaxation.  Replaces, for one FIFO level of the tree, the solveWorker goroutine pool of
+// /root/reference/tree.go:98-100,196-205 (each worker: subProblem.solve -> lp.Simplex, subproblem.go:141-159).
+#pragma once
+#include <functional>
+#include <vector>
+
+#include "engine.hpp"
+
+namespace gomilp {
+
+class BatchEngine {
+   public:
+    struct Outcome {
+        int stage = BS_HOST;       // BS_DONE: `status` is final (GOMILP_OK / ERR_BLAND: basis + x_B ready for the final solve);
+                                   // BS_HOST: the single-relaxation engine must solve this child
+        int status = 0, wrapped = 0, phase1_used = 0;
+        int64_t piv1 = 0, piv2 = 0, bland = 0;
+    };
+    struct Stats {
+        int64_t launches = 0, supersteps = 0, blocks = 0;
+        double seconds_setup = 0, seconds_total = 0;
+    };
+    // called on the thread that runs the wave as soon as child i is terminal; basic / xb (m_i entries, host memory, valid
+    // until the next run) are non-null for BS_DONE children whose status needs the final solve
+    using DoneFn = std::function<void(int64_t i, const Outcome &, const int32_t *basic, const double *xb)>;
+
+    explicit BatchEngine(int device);
+    ~BatchEngine();
+    // can children of this root with up to K_max branch rows take the batched path?
+    bool eligible(const Engine::RootView &R, int K_max) const;
+    int run(const Engine::RootView &R, int64_t count, const int64_t *koff, const int32_t *var, const double *sign,
+            const double *rhs, double tol, const DoneFn &on_done, Stats *stats);
+
+   private:
+    struct Buf;
+    int ensure(int nlp, int m_max, int n_max, int ldt1, int64_t ktot);
+    int device_;
+    hipStream_t stream_ = nullptr, copy_stream_ = nullptr;
+    Buf *b_;
+};
+
+}  // namespace gomilp

@@ -234,6 +234,13 @@ __device__ __forceinline__ double wave_dot_row(const double *__restrict__ row, c
     return wave_sum((a0 + a1) + (a2 + a3));
 }
 
+// element (i, j) of the tableau T in either layout: row-major, or the 4x4 tiles of the blocked pipeline (bt_kernels.hip:
+// tile (I, J) at ((I * ldt/4) + J) * 16, element (i&3)*4 + (j&3))
+__device__ __forceinline__ size_t tab_idx(int i, int j, int ldt, int tiled) {
+    return tiled ? ((size_t)(i >> 2) * (size_t)(ldt >> 2) + (size_t)(j >> 2)) * 16u + (size_t)(((i & 3) << 2) + (j & 3))
+                 : (size_t)i * ldt + j;
+}
+
 __device__ __forceinline__ void stage_vec(double2 *__restrict__ svec, const double *__restrict__ src, int ld2) {
     const double2 *s2 = reinterpret_cast<const double2 *>(src);
     for (int c = threadIdx.x; c < ld2; c += kBlock) svec[c] = s2[c];

@@ -219,11 +219,7 @@ __global__ __launch_bounds__(kBlock) void k_tableau_pivot(TabArgs a, int flags, 
 // ---- set-up kernels ---------------------------------------------------------------------------
 
 // T[pos, jp] = At[var(jp)][rho[pos]]  (B^-1 = permutation of the slack basis: row pos of T is row rho[pos] of A_N)
-// element (i, j) of T in either layout: row-major, or the 4x4 tiles of the blocked pipeline (bt_kernels.hip)
-__device__ __forceinline__ size_t tab_idx(int i, int j, int ldt, int tiled) {
-    return tiled ? ((size_t)(i >> 2) * (size_t)(ldt >> 2) + (size_t)(j >> 2)) * 16u + (size_t)(((i & 3) << 2) + (j & 3))
-                 : (size_t)i * ldt + j;
-}
+// (tab_idx: element (i, j) of T in either layout — kernels_common.h)
 
 __global__ void k_tab_gather(const double *__restrict__ At, int ld, int m, int nn, const int32_t *__restrict__ nonbasic,
                              const int32_t *__restrict__ rho, double *__restrict__ T, int ldt, int tiled) {

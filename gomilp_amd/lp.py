@@ -51,11 +51,12 @@ class FrontierStats(C.Structure):
     _fields_ = [("relaxations", C.c_int64), ("pivots_phase1", C.c_int64), ("pivots_phase2", C.c_int64),
                 ("bland_steps", C.c_int64), ("phase1_runs", C.c_int64), ("kernel_launches", C.c_int64),
                 ("workers", C.c_int32), ("device_id", C.c_int32), ("seconds_total", C.c_double),
-                ("seconds_busy_sum", C.c_double)]
+                ("seconds_busy_sum", C.c_double), ("batched_relaxations", C.c_int64), ("host_fallbacks", C.c_int64),
+                ("supersteps", C.c_int64), ("seconds_batch", C.c_double)]
 
 
 EXPORTS = [
-    "gomilp_lp_upload_child", "gomilp_pool_create", "gomilp_pool_destroy", "gomilp_pool_set_root", "gomilp_frontier_solve",
+    "gomilp_lp_upload_child", "gomilp_pool_create", "gomilp_pool_destroy", "gomilp_pool_set", "gomilp_pool_set_root", "gomilp_frontier_solve",
     "gomilp_lp_simplex", "gomilp_ctx_create", "gomilp_ctx_destroy", "gomilp_ctx_device", "gomilp_ctx_set",
     "gomilp_lp_upload", "gomilp_lp_free", "gomilp_lp_solve_resident", "gomilp_lp_last_trace", "gomilp_version",
     "gomilp_device_count", "gomilp_compiled_arch",
@@ -95,6 +96,7 @@ def lib():
     L.gomilp_pool_create.restype = C.c_void_p
     L.gomilp_pool_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.gomilp_pool_destroy.argtypes = [C.c_void_p]
+    L.gomilp_pool_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.gomilp_pool_set_root.argtypes = [C.c_void_p, dp, dp, C.c_int64, dp, C.c_int64, C.c_int64]
     L.gomilp_frontier_solve.argtypes = [C.c_void_p, C.c_int64, ip, i32p, dp, dp, C.c_double, dp, dp, i32p, i32p,
                                         C.POINTER(FrontierStats)]
@@ -255,12 +257,20 @@ class FrontierPool:
     """`workers` engine contexts on one GPU solving independent child relaxations of one root concurrently
     (the solveWorker pool of /root/reference/tree.go:98-100,196-205 for one FIFO level)."""
 
-    def __init__(self, device: int = -1, workers: int = 4):
+    def __init__(self, device: int = -1, workers: int = 4, **knobs):
         st = C.c_int(0)
         self._h = lib().gomilp_pool_create(int(device), int(workers), C.byref(st))
         if not self._h:
             raise RuntimeError("gomilp_pool_create failed: %s" % STATUS_NAMES.get(st.value, st.value))
         self.n0 = self.m0 = 0
+        for k, v in knobs.items():
+            self.set(k, v)
+
+    def set(self, key: str, value: int) -> None:
+        """"batched" (1: device-batched pivot loops, 0: one worker thread + stream per relaxation) or any Context knob."""
+        rc = lib().gomilp_pool_set(self._h, key.encode(), int(value))
+        if rc != OK:
+            raise ValueError("bad knob %s=%s" % (key, value))
 
     def set_root(self, c0, A0, b0) -> None:
         A0 = np.ascontiguousarray(A0, dtype=np.float64)

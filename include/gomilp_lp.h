@@ -144,10 +144,19 @@ typedef struct gomilp_frontier_stats {
     int32_t workers, device_id;
     double seconds_total;       /* host wall clock of the call */
     double seconds_busy_sum;    /* sum over workers of time spent inside solves */
+    int64_t batched_relaxations; /* relaxations whose pivot loops ran in the device-batched schedule (one launch per kernel type
+                                    for the whole wave) */
+    int64_t host_fallbacks;      /* relaxations the batched schedule handed to a worker's single-relaxation engine */
+    int64_t supersteps;          /* host round trips of the batched schedule for the WHOLE wave */
+    double seconds_batch;        /* wall clock of the batched schedule */
 } gomilp_frontier_stats;
 
 gomilp_pool *gomilp_pool_create(int device, int workers, int *status);
 void gomilp_pool_destroy(gomilp_pool *pool);
+/* knobs: "batched" (default 1: the pivot loops of a wave run device-batched — grid.x = relaxation, O(1) host round trips per
+ * superstep for the whole wave; 0: one host thread + stream per relaxation); any gomilp_ctx_set key is forwarded to the
+ * worker contexts. */
+int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value);
 /* Upload the root standard form (row-major A0, stride lda) to every worker context of the pool. */
 int gomilp_pool_set_root(gomilp_pool *pool, const double *c0, const double *A0, int64_t lda, const double *b0, int64_t m0,
                          int64_t n0);

@@ -1,0 +1,14 @@
+"""Developer tool: batched C5 waves only (for rocprofv3 --kernel-trace --stats)."""
+import sys, time, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gomilp_amd import lp, synth
+m, seed = synth.CONFIGS["C5"]
+c, A, b = synth.dense_lp_standard_form(m, seed)
+mask = synth.integrality_mask(m, m)
+cx = lp.Context(); root = cx.upload(c, A, b).solve(0.0); cx.close()
+children = synth.frontier_children(root.x, mask, 8)
+pool = lp.FrontierPool(workers=16, batched=1)
+pool.set_root(c, A, b)
+for r in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
+    t0 = time.perf_counter(); res = pool.solve(children); dt = time.perf_counter() - t0
+    print("wave %.2f ms batch %.2f ms supersteps %d fallbacks %d" % (1e3 * dt, 1e3 * res.stats["seconds_batch"], res.stats["supersteps"], res.stats["host_fallbacks"]), flush=True)
+pool.close()
