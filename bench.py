@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the LP-relaxation hot path (BASELINE.json `metric`).
-
-One "step" = one complete pass of the hot path over one synthetic input: a full dense-simplex solve of the
-metric workload (2048x4096 fp64 dense LP, SURVEY.md §8d generator, seed 2 + rank) from HBM-resident inputs
-(c, A, b uploaded before the timed region), through the C-ABI of include/gomilp_lp.h.
-value = simplex pivots per second, whole job (all ranks' pivots / max-over-ranks wall time).
+"""bench.py — headline benchmark of the LP-relaxation hot path (BASELINE.json `metric`:
+"simplex pivots/sec on 2048x4096 fp64 dense LP; relaxations/sec at 1/2/4/8 GPUs").
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload M|C2|C4|C3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    (python bench.py --gpus N without a torchrun environment starts that launcher itself.)
 
-Rank 0 prints ONE JSON line.  `roofline` prices the HBM-streaming kernel of the pipeline that ran (default: the rank-8
-update of the tableau, k_bt_update_tiled) against the HBM roof with HIP-event timings of sampled launches inside the
-timed region; `roofline.detail` gives the latency-bound single-workgroup kernel beside it; `cpu_baseline` times the
-CPU oracle (the reference algorithm: 3 fresh LU per pivot) on a bounded sample of the same workload on the host cores.
+N = 1: one "step" = one complete pass of the hot path over one synthetic input: a full dense-simplex solve of the metric
+workload (2048x4096 fp64 dense LP, SURVEY.md §8d generator, seed 2) from HBM-resident inputs through the C-ABI of
+include/gomilp_lp.h; value = simplex pivots per second.  The same line carries the 1-GPU figure of the frontier metric
+(`frontier.relaxations_per_s`) the N > 1 lines scale from.
+
+N > 1: one "step" = one 256-wide branch-and-bound wave of 512x1024 relaxations (BASELINE config 5) sharded over the N
+ranks (one process per GPU, device-batched pivot loops per rank), closed by ONE RCCL all-reduce(min) of the incumbent
+through the C-ABI (gomilp_incumbent_allreduce); value = relaxations per second of the whole job, scaling "strong".
+
+Rank 0 prints ONE JSON line.  `roofline` prices the kernel with the largest share of GPU time in the timed region — the
+single-workgroup block kernel k_bt_inner2 (latency-bound: `bound` says so) — by its algorithmic bytes per launch over its
+HIP-event launch duration against the HBM peak; `roofline.loop` does the same for the whole pivot loop (block kernel +
+streaming rank-8 update + boundaries) with the byte model of THIS pipeline, `roofline.streaming_kernel` for the
+HBM-streaming kernel alone.  `cpu_baseline` times the CPU oracle (the reference algorithm: 3 fresh LU per pivot) on a
+bounded sample of the same workload on the host cores.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,25 +38,66 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def main() -> int:
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="M")
+    ap.add_argument("--workload", default="M", help="N = 1 headline workload: M (metric), C2, C3, C4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pivots", type=int, default=32, help="Phase-II pivots timed on the CPU oracle (about 12 s at the metric size)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU oracle: a 1-GPU box owns 16 host cores; more "
                     "threads only add fork/join time to the 64-column panels (8: 2.8 pivots/s, 64: 1.2, 256: 0.09 at the metric size)")
     ap.add_argument("--sample-events", type=int, default=64, help="time the kernels of every k-th pivot (every k/K-th block) with HIP events")
     ap.add_argument("--chunk", type=int, default=64)
-    ap.add_argument("--refresh", type=int, default=0)
-    ap.add_argument("--frontier-vars", type=int, default=8, help="C5: 2^k children from the k highest fractional integer vars (0 = skip)")
-    ap.add_argument("--workers", type=int, default=16, help="engine contexts (HIP streams) per GPU for the frontier")
-    ap.add_argument("--frontier-cpu-children", type=int, default=8, help="children timed on the CPU oracle")
-    ap.add_argument("--concurrent", type=int, default=4, help="extra figure: independent 2048x4096 LPs solved concurrently on one GPU (0 = skip)")
+    ap.add_argument("--frontier-vars", type=int, default=8, help="C5: 2^k children from the k highest fractional integer vars (0 = skip at N = 1)")
+    ap.add_argument("--workers", type=int, default=16, help="worker contexts per GPU (final solves / fall-backs of the batched frontier)")
+    ap.add_argument("--frontier-cpu-children", type=int, default=8, help="children solved on the CPU oracle too (baseline + check)")
+    ap.add_argument("--concurrent", type=int, default=4, help="extra figure: independent LPs of the headline shape solved together on one GPU (0 = skip)")
     ap.add_argument("--milp-nodes", type=int, default=127, help="C3: node budget of the host B&B over GPU relaxations (0 = skip)")
-    args = ap.parse_args()
+    ap.add_argument("--debug-one-gpu", action="store_true", help="rehearsal of the N > 1 control flow on a one-GPU box: every rank uses GPU 0, "
+                    "torch.distributed over gloo, incumbent table over gloo + gomilp_incumbent_pick (RCCL refuses two ranks on one device)")
+    ap.add_argument("--c4", type=int, default=1, help="extra figure: one timed solve of the 4096x8192 LP (BASELINE config 4) (0 = skip)")
+    return ap.parse_args()
+
+
+def newest_pmc(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json, made by
+    tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this command).  Counters cannot be read from inside
+    the run they measure: this is the most recent committed measurement, named in `traffic_source`."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            doc = json.load(open(path))
+        except Exception:
+            continue
+        for ent in (doc if isinstance(doc, list) else [doc]):
+            if kernel_substr in ent.get("kernel", ""):
+                best = (ent.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT))
+    return best or (None, None)
+
+
+def main() -> int:
+    args = parse_args()
+    # ONE JSON line on stdout: libraries that print banners there (RCCL at communicator set-up) go to stderr instead
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher environment: start it (before anything touches the GPU) and hand back its exit code
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.dup2(real_stdout, 1)   # the launcher's rank 0 prints the line
+        return subprocess.call(cmd)
 
     import numpy as np
     import torch
@@ -55,27 +105,29 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world:
+        print("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world), file=sys.stderr)
+        return 2
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the product path has no CPU fallback", file=sys.stderr)
         return 2
+    one_gpu = args.debug_one_gpu
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist_mod.init_process_group(backend="gloo")
+        else:
+            dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_mod
+    red_dev = "cpu" if one_gpu else "cuda"
 
+    from gomilp_amd import frontier as fr
     from gomilp_amd import lp, synth
-
-    m, seed = synth.CONFIGS[args.workload]
-    seed = seed + rank  # weak scaling: every rank owns an independent relaxation of the same shape
-    c, A, b = synth.dense_lp_standard_form(m, seed)
-    n = A.shape[1]
-    ctx = lp.Context(device=local_rank, chunk=args.chunk, refresh=args.refresh, sample_events=args.sample_events)
-    prob = ctx.upload(c, A, b)  # inputs resident in HBM before the timed region
 
     def barrier():
         torch.cuda.synchronize()
@@ -83,16 +135,171 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
-    incumbent = torch.full((1,), float("inf"), dtype=torch.float64, device="cuda")
+    def allmax(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def allsum(vals):
+        if dist is None:
+            return list(vals)
+        t = torch.tensor(list(vals), dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t]
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # the frontier wave (BASELINE config 5): headline for N > 1, `frontier` object of the N = 1 line
+    # ------------------------------------------------------------------------------------------------------------------
+    def frontier_leg(steps, warmup):
+        m5, seed5 = synth.CONFIGS["C5"]
+        c5, A5, b5 = synth.dense_lp_standard_form(m5, seed5)
+        mask5 = synth.integrality_mask(m5, m5)
+        ctx5 = lp.Context(device=local_rank)
+        root5 = ctx5.upload(c5, A5, b5).solve(0.0)          # every rank solves the root (tree.go:72), outside the timing
+        ctx5.close()
+        children = synth.frontier_children(root5.x, mask5, args.frontier_vars)
+        pool = lp.FrontierPool(device=local_rank, workers=args.workers, sample_batch=1)
+        pool.set_root(c5, A5, b5)                            # root resident on every GPU before the timed region
+        # the incumbent exchange goes through the C-ABI (RCCL), also at N = 1 (a 1-rank communicator)
+        comm = None
+        if not (one_gpu and world > 1):
+            uid = [lp.comm_unique_id() if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(uid, src=0)
+            comm = lp.Comm(rank, world, uid[0], device=local_rank)
+        wave_dist = dist if comm is None else None   # rehearsal only: the table travels over gloo
+        holder = {}
+
+        def solve_shard(chs):
+            r = pool.solve(chs)
+            holder["stats"] = r.stats
+            return r.status, r.z, r.x, r.has_x
+
+        dev = None if comm is None else torch.device("cuda", local_rank)
+        for _ in range(max(3, warmup)):   # first-touch allocations and code loading of every worker end inside the first waves
+            wave = fr.solve_wave(solve_shard, children, mask5, rank, world, wave_dist, dev, comm=comm)
+        acc = dict(inner=0.0, update=0.0, blocks=0, blocks_sampled=0, batch=0.0, pivots=0, phase1=0, bland=0, fallbacks=0, batched=0)
+        per_wave = []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tw = time.perf_counter()
+            wave = fr.solve_wave(solve_shard, children, mask5, rank, world, wave_dist, dev, comm=comm)
+            per_wave.append(time.perf_counter() - tw)
+            st = holder["stats"]
+            acc["inner"] += st["seconds_inner_kernels"]; acc["update"] += st["seconds_update_kernels"]
+            acc["blocks"] += st["blocks"]; acc["blocks_sampled"] += st["blocks_sampled"]; acc["batch"] += st["seconds_batch"]
+            acc["pivots"] += st["pivots_phase1"] + st["pivots_phase2"]; acc["phase1"] += st["phase1_runs"]; acc["bland"] += st["bland_steps"]
+            acc["fallbacks"] += st["host_fallbacks"]; acc["batched"] += st["batched_relaxations"]
+        barrier()
+        dt = allmax(time.perf_counter() - t0)
+        tot = allsum([acc["pivots"], acc["phase1"], acc["bland"], acc["fallbacks"], acc["batched"],
+                      float(sum(1 for s in wave["status"] if s == lp.OK))])
+        # scaling bound: the heaviest child alone through the same batched path (a wave can never be faster than that)
+        solo = None
+        if rank == 0:
+            res_all = pool.solve(children)
+            t_best, heavy = 0.0, 0
+            for i in [i for i, st_ in enumerate(res_all.status) if st_ == lp.OK]:   # the feasible children are the long ones
+                t1 = time.perf_counter(); pool.solve([children[i]]); d1 = time.perf_counter() - t1
+                if d1 > t_best:
+                    t_best, heavy = d1, i
+            for _ in range(2):
+                t1 = time.perf_counter(); r1 = pool.solve([children[heavy]]); t_best = min(t_best, time.perf_counter() - t1)
+            solo = {"child": heavy, "pivots": int(r1.stats["pivots_phase1"] + r1.stats["pivots_phase2"]), "bland_steps": int(r1.stats["bland_steps"]),
+                    "seconds_alone": t_best}
+        m_c, n_c = m5 + args.frontier_vars, 2 * m5 + args.frontier_vars
+        nn_c = n_c - m_c
+        alg_bytes = 32.0 * (m_c + nn_c)     # per pivot: column + row of T read, u and v' written (8 B each)
+        inner_us = 1e6 * acc["inner"] / max(acc["blocks_sampled"], 1)
+        upd_us = 1e6 * acc["update"] / max(acc["blocks_sampled"], 1)
+        out = {
+            "workload": "C5: %d children of the %dx%d root (seed %d), %d bnb rows each, dealt round-robin over a fixed shuffle to %d rank(s)"
+                        % (len(children), m5, 2 * m5, seed5, args.frontier_vars, world),
+            "relaxations_per_s": steps * len(children) / dt, "wave_seconds": dt / steps, "waves_timed": steps, "n_gpus": world,
+            "wave_seconds_rank0": per_wave, "pivots_per_wave": int(tot[0] / steps), "phase1_runs_per_wave": int(tot[1] / steps),
+            "bland_steps_per_wave": int(tot[2] / steps), "host_fallbacks_per_wave": tot[3] / steps, "device_batched_per_wave": tot[4] / steps,
+            "feasible_children": int(tot[5]), "incumbent_z": wave["incumbent_z"], "incumbent_child": wave["incumbent_index"],
+            "collective": "gomilp_incumbent_allreduce: 1 x ncclAllReduce(min) of %d doubles per wave over %d rank(s) (RCCL, C-ABI)" % (2 * world, world),
+            "schedule": "device-batched: one launch per kernel type per block step for the whole shard (grid.x = relaxation), "
+                        "%d block steps and %.1f host round trips per wave on rank 0" % (acc["blocks"] // max(steps, 1), holder["stats"]["supersteps"]),
+            "kernels_rank0": {"inner": "k_bt_inner2_batch<512,2,2,8,0>", "inner_us_per_launch": inner_us, "update_us_per_launch": upd_us,
+                              "time_share_inner": acc["inner"] / max(acc["inner"] + acc["update"], 1e-30),
+                              "algorithmic_bytes_per_pivot": alg_bytes},
+        }
+        if solo is not None:
+            out["scaling_bound"] = {"heaviest_child": solo, "note": "a wave cannot finish before its heaviest child: relaxations/s at any GPU count "
+                                    "<= %d / %.2f ms; more GPUs only remove what the other children add to that" % (len(children), 1e3 * solo["seconds_alone"]),
+                                    "max_relaxations_per_s": len(children) / solo["seconds_alone"]}
+        roof = {"bound": "latency", "kernel": "k_bt_inner2_batch<512,2,2,8,0>", "achieved": acc["pivots"] * alg_bytes / max(acc["inner"], 1e-30) / 1e9 if acc["inner"] > 0 else 0.0,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                "note": "one workgroup per relaxation, two workgroup-wide argmins and two dependent tableau reads per pivot: bound by "
+                        "latency, not bandwidth; achieved = rank 0's pivots x algorithmic bytes per pivot / HIP-event time of its batched inner launches"}
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        cpu = None
+        if not args.no_cpu_baseline and world == 1 and args.frontier_cpu_children > 0:
+            from concurrent.futures import ThreadPoolExecutor
+            from oracle import oracle as O   # the checker, timed as the CPU baseline (never the product path)
+            O.set_threads(1)
+            # the first children are the heavy feasible ones, the rest infeasible: take both kinds
+            idx = list(range(args.frontier_cpu_children // 2)) + list(range(len(children) - (args.frontier_cpu_children - args.frontier_cpu_children // 2), len(children)))
+            res_all = pool.solve(children)
+
+            def cpu_child(i):
+                cc, AA, bb = O.child_standard_form(c5, A5, b5, children[i])
+                return O.simplex(cc, AA, bb, 0.0, None, fast_initial_basis=True)
+
+            tcb = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=len(idx)) as ex:
+                ores = list(ex.map(cpu_child, idx))
+            tcb = time.perf_counter() - tcb
+            same = all(o.status == res_all.status[i] and (o.x is None or (np.array_equal(o.x[: res_all.x.shape[1]], res_all.x[i]) and o.z == res_all.z[i]))
+                       for i, o in zip(idx, ores))
+            cpu = {"value": len(idx) / tcb, "unit": "relaxations/s", "cores": len(idx), "kind": "port",
+                   "sample": "children %s of the same wave, one oracle solve per host thread (mirrors Problem.SetWorkers), %.1f s wall" % (idx, tcb),
+                   "gpu_results_identical": bool(same)}
+        if comm is not None:
+            comm.close()
+        pool.close()
+        return out, roof, cpu
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # N > 1: the sharded frontier is the headline
+    # ------------------------------------------------------------------------------------------------------------------
+    if world > 1:
+        fout, roof, _ = frontier_leg(args.steps, args.warmup)
+        if rank == 0:
+            out = {
+                "metric": "LP relaxations/sec on the 256-wide B&B frontier of 512x1024 relaxations", "value": fout["relaxations_per_s"],
+                "unit": "relaxations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * fout["wave_seconds"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic",
+                "config": {"workload": fout["workload"], "parallelism": "frontier sharded over %d GPUs, device-batched pivot loops per GPU" % world,
+                           "scale_from": "frontier.relaxations_per_s of the --gpus 1 line"},
+                "roofline": roof, "frontier": fout,
+                "mfma": {"util": 0.0, "why": "no GEMM-shaped step on this path: every relaxation has its own tableau (no shared operand for a batched "
+                         "pricing GEMM) and the rank-8 update is HBM-bound at 1 flop/byte (f64 MFMA ridge ~10 flop/byte)"},
+            }
+            emit(out)
+        dist.barrier()
+        dist.destroy_process_group()
+        return 0
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # N = 1: pivots/s on the metric LP
+    # ------------------------------------------------------------------------------------------------------------------
+    m, seed = synth.CONFIGS[args.workload]
+    c, A, b = synth.dense_lp_standard_form(m, seed)
+    n = A.shape[1]
+    ctx = lp.Context(device=local_rank, chunk=args.chunk, sample_events=args.sample_events)
+    prob = ctx.upload(c, A, b)  # inputs resident in HBM before the timed region
 
     def step():
         r = prob.solve(0.0)
         if r.status != lp.OK:
             raise RuntimeError("solve failed: %s" % lp.STATUS_NAMES.get(r.status, r.status))
-        if dist is not None:
-            # the only exchange of the frontier-parallel path: incumbent bound, one all-reduce(min) over xGMI
-            incumbent[0] = min(float(incumbent[0]), r.z)
-            dist.all_reduce(incumbent, op=dist.ReduceOp.MIN)
         return r
 
     for _ in range(args.warmup):
@@ -114,24 +321,109 @@ def main() -> int:
         final_host += last.stats["seconds_final_host"]
     barrier()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt, float(pivots)], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        tmax = tt.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        dt_max, piv_all = float(tmax[0]), float(tt[1])
-    else:
-        dt_max, piv_all = dt, float(pivots)
+    value = pivots / dt
+    nn = n - m
+    pipeline = last.stats["pipeline"]
 
-    # ---- extra: B independent LPs of the metric shape solved concurrently on this GPU (one context = one stream each).
-    # The single-workgroup inner kernel of the blocked pipeline leaves most CUs idle, so independent relaxations overlap;
-    # `value` above stays the single-LP figure.
-    batched_out = None
-    if args.concurrent > 1 and rank == 0:
+    # ---- roofline: the kernel with the largest share of the timed region, then the loop, then the streaming kernel alone
+    tiled = m <= 2048 and nn <= 2048
+    bytes_pivot_survey = 8.0 * (m * nn + 3.0 * m * m)      # SURVEY.md §8d per-unit figure (explicit-inverse model)
+    if pipeline == "blocked":
+        nblocks = max(ksec[1], 1.0)
+        K = ksec[3] / nblocks if ksec[1] > 0 else 8.0
+        t_inner, t_upd = ksec[0] / nblocks, ksec[2] / nblocks
+        inner_name = "k_bt_inner2<1024,2,2,8,1>" if (tiled and m > 1024) else ("k_bt_inner2<512,2,2,8,0>" if tiled else "k_bt_inner<1024,%d,%d,0>" % ((m + 1023) // 1024, (nn + 1023) // 1024))
+        upd_name = "k_bt_update_tiled<8>" if tiled else "k_bt_update<16>"
+        # byte model of THIS pipeline, per block of K pivots: the inner kernel reads one column and one row of T per pivot and
+        # writes u_k, v_k' (8 B each) + loads / stores r, x_B and the index lists once per launch; the update reads and
+        # writes T once
+        bytes_inner = K * 16.0 * (m + nn) + 2 * 12.0 * (m + nn)
+        bytes_update = 16.0 * m * nn
+        block_s = loop_s / max(pivots / K, 1.0)   # wall time of the loop per block: kernels + boundaries + the host's chunk waits
+        share_inner = t_inner / max(t_inner + t_upd, 1e-30)
+        traffic, tsrc = newest_pmc("k_bt_inner2")
+        roofline = {
+            "bound": "latency", "kernel": inner_name, "time_share": share_inner * loop_s / dt,
+            "achieved": bytes_inner / t_inner / 1e9 if t_inner > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "traffic": traffic, "traffic_source": tsrc,
+            "bytes_per_launch": bytes_inner, "avg_launch_us": 1e6 * t_inner, "us_per_pivot": 1e6 * t_inner / K, "pivots_per_launch": K,
+            "note": "single-workgroup kernel (1 of 256 CUs): two workgroup-wide first-index argmins and two dependent tableau reads per "
+                    "pivot; its roof is the dependent-latency chain, not HBM bandwidth — `frac` is reported against the HBM peak all the same",
+            "loop": {"bytes_per_block": bytes_inner + bytes_update, "block_us": 1e6 * block_s,
+                     "kernel_us_per_block": 1e6 * (t_inner + t_upd), "achieved_GBs": (bytes_inner + bytes_update) / block_s / 1e9,
+                     "frac": (bytes_inner + bytes_update) / block_s / 1e9 / HBM_PEAK_GBS,
+                     "model": "per block of K pivots: 16*m*(n-m) (rank-K update: T read + written once) + K*16*(m+n-m) + 24*(m+n-m) (block kernel)"},
+            "streaming_kernel": {"bound": "hbm", "kernel": upd_name, "bytes_per_launch": bytes_update, "avg_launch_us": 1e6 * t_upd,
+                                 "achieved": bytes_update / t_upd / 1e9 if t_upd > 0 else 0.0, "frac": bytes_update / t_upd / 1e9 / HBM_PEAK_GBS if t_upd > 0 else 0.0,
+                                 "traffic": newest_pmc("k_bt_update_tiled")[0], "traffic_source": newest_pmc("k_bt_update_tiled")[1],
+                                 "time_share": (1 - share_inner) * loop_s / dt,
+                                 "note": "the %.1f MB tableau stays in the 256 MB Infinity Cache between launches: a MALL rate where it exceeds the ~6.3 TB/s HBM copy rate" % (8e-6 * m * nn)},
+            "sampled_blocks": int(ksec[1]), "sampled_pivots": int(ksec[3]),
+            "per_pivot_survey_model": {"bytes": bytes_pivot_survey, "achieved_GBs": value * bytes_pivot_survey / 1e9, "frac": value * bytes_pivot_survey / 1e9 / HBM_PEAK_GBS,
+                                       "note": "SURVEY §8d explicit-inverse model (134 MB per pivot at the metric size); the blocked tableau moves ~%.1f MB per pivot, so this ratio can exceed 1 and is not a roofline" % ((bytes_inner + bytes_update) / K / 1e6)},
+        }
+        roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+    else:
+        nsamp = max(ksec[3], 1.0)
+        t_upd = ksec[2] / nsamp
+        kname, bts = ("k_tableau_pivot", 16.0 * m * nn) if pipeline == "tableau" else ("k_update", 16.0 * m * m)
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": bts / t_upd / 1e9 if t_upd > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "traffic": None, "bytes_per_launch": bts, "avg_launch_us": 1e6 * t_upd}
+        roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+
+    out = {
+        "metric": "simplex pivots/sec on %dx%d fp64 dense LP" % (m, n), "value": value, "unit": "pivots/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: %dx%d dense LP, splitmix64 seed %d, one full solve per step" % (args.workload, m, n, seed),
+                   "pivots_per_solve": int(last.stats["pivots_phase2"]), "parallelism": "1 relaxation on 1 GPU", "pipeline": pipeline, "chunk": args.chunk},
+        "roofline": roofline,
+        "mfma": {"util": 0.0, "why": "nothing on this path is GEMM-shaped with a shared operand: pricing is one row update per pivot "
+                 "(tableau form), the rank-8 update of T does 16 flop per 16 bytes moved (1 flop/byte; the f64 MFMA ridge of gfx950 is ~10 flop/byte) "
+                 "and runs at the MALL/HBM rate; sibling relaxations do not share a matrix once their bases differ, so there is no batched pricing GEMM",
+                 "evidence": "profiles/README.md: SQ_INSTS_VALU_MFMA_* / SQ_VALU_MFMA_BUSY_CYCLES = 0 in the rocprofv3 --pmc pass"},
+        "breakdown": {"pivot_loop_s": loop_s, "final_solve_s": final_s, "final_device_s": final_dev, "final_host_s": final_host, "wall_s": dt,
+                      "drift_xb": last.stats["drift_xb"], "z": last.z},
+    }
+
+    # ---- CPU baseline (the oracle = the reference algorithm), bounded sample of the same workload
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O   # the checker, timed as the CPU baseline (never the product path)
+        cores = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+        O.set_threads(cores)
+        tcb = time.perf_counter()
+        ro = O.simplex(c, A, b, 0.0, None, fast_initial_basis=True, stop_after_pivots=args.cpu_pivots, trace=True)
+        tcb = time.perf_counter() - tcb
+        gtr = prob.solve(0.0, trace=True)
+        same_prefix = [(p[0], p[2], p[3], p[4], p[5]) for p in ro.pivots] == [(p[0], p[2], p[3], p[4], p[5]) for p in gtr.pivots[: len(ro.pivots)]]
+        out["cpu_baseline"] = {
+            "value": ro.pivots_phase2 / ro.seconds_loop if ro.seconds_loop > 0 else 0.0, "unit": "pivots/s", "cores": cores, "kind": "port",
+            "sample": "first %d Phase-II pivots of the same %dx%d LP from the slack basis (reference algorithm: 3 fresh LU + cond estimate "
+                      "per pivot, gonum order); unit-column initial-basis fast path; %.1f s wall" % (ro.pivots_phase2, m, n, tcb),
+            "gpu_pivots_identical_on_sample": bool(same_prefix)}
+        # a size where both engines finish the whole solve: the truncated sample above is not an artefact
+        c256, A256, b256 = synth.dense_lp_standard_form(256, 7)
+        O.set_threads(1)
+        t1 = time.perf_counter()
+        r256 = O.simplex(c256, A256, b256, 0.0, None, fast_initial_basis=True)
+        t_cpu = time.perf_counter() - t1
+        p256 = ctx.upload(c256, A256, b256)
+        p256.solve(0.0)
+        t1 = time.perf_counter()
+        g256 = p256.solve(0.0)
+        t_gpu = time.perf_counter() - t1
+        p256.free()
+        npv = r256.pivots_phase1 + r256.pivots_phase2
+        out["cpu_baseline"]["full_solve_256x512"] = {
+            "pivots": int(npv), "cpu_cores": 1, "cpu_seconds": t_cpu, "cpu_pivots_per_s": npv / t_cpu, "gpu_seconds": t_gpu,
+            "gpu_pivots_per_s": npv / t_gpu, "same_x_bits": bool(g256.status == 0 and r256.x is not None and np.array_equal(g256.x, r256.x))}
+
+    # ---- extra: B independent LPs of the headline shape on this GPU, one engine context + host thread each
+    if args.concurrent > 1:
         import threading
         cps = []
         for i in range(args.concurrent):
-            ci, Ai, bi = synth.dense_lp_standard_form(m, synth.CONFIGS[args.workload][1] + 100 + i)
+            ci, Ai, bi = synth.dense_lp_standard_form(m, seed + 100 + i)
             cxi = lp.Context(device=local_rank, chunk=args.chunk)
             cps.append((cxi, cxi.upload(ci, Ai, bi)))
         resb = [None] * len(cps)
@@ -139,6 +431,7 @@ def main() -> int:
         def solve_one(i):
             resb[i] = cps[i][1].solve(0.0)
 
+        tb = 0.0
         for rep in range(2):  # first round = warm-up
             ths = [threading.Thread(target=solve_one, args=(i,)) for i in range(len(cps))]
             torch.cuda.synchronize()
@@ -150,63 +443,45 @@ def main() -> int:
             torch.cuda.synchronize()
             tb = time.perf_counter() - tb0
         pb = sum(r.stats["pivots_phase1"] + r.stats["pivots_phase2"] for r in resb)
-        batched_out = {"concurrent_lps": len(cps), "pivots": int(pb), "seconds": tb, "pivots_per_s": pb / tb,
-                       "all_ok": all(r.status == lp.OK for r in resb),
-                       "note": "independent %dx%d LPs (seeds +100..), one engine context per LP on one GPU" % (m, n)}
+        out["batched"] = {"concurrent_lps": len(cps), "pivots": int(pb), "seconds": tb, "pivots_per_s": pb / tb, "vs_single": pb / tb / value,
+                          "all_ok": all(r.status == lp.OK for r in resb),
+                          "note": "independent %dx%d LPs (seeds +100..), one engine context (stream + host thread) per LP on one GPU" % (m, n)}
         for cxi, _ in cps:
             cxi.close()
 
-    # ---- C5: one 256-wide B&B wave of 512x1024 relaxations, sharded over the ranks ----
-    frontier_out = None
+    # ---- BASELINE config 4: one solve of the 4096x8192 LP
+    if args.c4 and args.workload != "C4":
+        m4, seed4 = synth.CONFIGS["C4"]
+        c4, A4, b4 = synth.dense_lp_standard_form(m4, seed4)
+        cx4 = lp.Context(device=local_rank, chunk=args.chunk, sample_events=args.sample_events)
+        p4 = cx4.upload(c4, A4, b4)
+        p4.solve(0.0)
+        t1 = time.perf_counter()
+        r4 = p4.solve(0.0)
+        t4 = time.perf_counter() - t1
+        k4 = r4.stats["pivot_kernel_seconds"]
+        nb4 = max(k4[1], 1.0)
+        out["c4"] = {"workload": "C4: %dx%d dense LP (seed %d), one full solve" % (m4, 2 * m4, seed4), "status": int(r4.status),
+                     "pivots": int(r4.stats["pivots_phase2"]), "seconds": t4, "pivots_per_s": r4.stats["pivots_phase2"] / t4,
+                     "inner_us_per_launch": 1e6 * k4[0] / nb4, "update_us_per_launch": 1e6 * k4[2] / nb4, "pivots_per_launch": k4[3] / nb4,
+                     "update_GBs": 16.0 * m4 * m4 / (k4[2] / nb4) / 1e9 if k4[2] > 0 else 0.0,
+                     "update_frac_of_hbm_peak": 16.0 * m4 * m4 / (k4[2] / nb4) / 1e9 / HBM_PEAK_GBS if k4[2] > 0 else 0.0,
+                     "note": "the 134 MB tableau (x2 with the second buffer) no longer fits the Infinity Cache with everything else: the update runs at the HBM rate; "
+                             "row-major k_bt_inner, K = 16 (the block terms of 4096 rows do not fit one CU's registers)"}
+        p4.free()
+        cx4.close()
+        del c4, A4, b4
+
+    # ---- BASELINE config 5 on one GPU (the figure the N > 1 lines scale from)
     if args.frontier_vars > 0:
-        from gomilp_amd import frontier as fr
-        m5, seed5 = synth.CONFIGS["C5"]
-        c5, A5, b5 = synth.dense_lp_standard_form(m5, seed5)
-        mask5 = synth.integrality_mask(m5, m5)
-        ctx5 = lp.Context(device=local_rank)
-        root5 = ctx5.upload(c5, A5, b5).solve(0.0)          # every rank solves the root (tree.go:72), outside the timing
-        ctx5.close()
-        children = synth.frontier_children(root5.x, mask5, args.frontier_vars)
-        pool = lp.FrontierPool(device=local_rank, workers=args.workers)
-        pool.set_root(c5, A5, b5)                            # root resident on every GPU before the timed region
-        holder = {}
+        fout, froof, fcpu = frontier_leg(5, 3)
+        fout["roofline"] = froof
+        if fcpu is not None:
+            fout["cpu_baseline"] = fcpu
+        out["frontier"] = fout
 
-        def solve_shard(chs):
-            r = pool.solve(chs)
-            holder["stats"] = r.stats
-            return r.status, r.z, r.x, r.has_x
-
-        dev = torch.device("cuda", local_rank)
-        fr.solve_wave(solve_shard, children, mask5, rank, world, dist, dev)  # warm-up: a full wave (first-touch allocations of every worker)
-        tfs = []
-        for _rep in range(3):   # median of three waves: a single wave occasionally catches a 2x outlier (host scheduling)
-            barrier()
-            tf0 = time.perf_counter()
-            wave = fr.solve_wave(solve_shard, children, mask5, rank, world, dist, dev)
-            barrier()
-            tfs.append(time.perf_counter() - tf0)
-        tf = sorted(tfs)[1]
-        tft = torch.tensor([tf], dtype=torch.float64, device="cuda")
-        st5 = holder["stats"]
-        agg = torch.tensor([float(st5["pivots_phase1"] + st5["pivots_phase2"]), float(st5["phase1_runs"]),
-                            float(st5["bland_steps"]), float(sum(1 for s in wave["status"] if s == lp.OK))],
-                           dtype=torch.float64, device="cuda")
-        if dist is not None:
-            dist.all_reduce(tft, op=dist.ReduceOp.MAX)
-            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        frontier_out = {
-            "workload": "C5: %d children of the %dx%d root (seed %d), %d bnb rows each, dealt round-robin over a fixed shuffle to %d rank(s)"
-                        % (len(children), m5, 2 * m5, seed5, args.frontier_vars, world),
-            "relaxations_per_s": len(children) / float(tft[0]), "wave_seconds": float(tft[0]), "waves_timed": 3, "n_gpus": world,
-            "workers_per_gpu": args.workers, "pivots": int(agg[0]), "phase1_runs": int(agg[1]), "bland_steps": int(agg[2]),
-            "feasible_children": int(agg[3]), "incumbent_z": wave["incumbent_z"], "incumbent_child": wave["incumbent_index"],
-            "collective": "2 x all_reduce(min) of one scalar per wave (RCCL)" if dist is not None else "none (1 rank)",
-        }
-        pool.close()
-
-    # ---- C3: host branch-and-bound (tree.go semantics, gomilp_amd/bnb.py) driving GPU relaxations, rank 0 only ----
-    milp_out = None
-    if args.milp_nodes > 0 and rank == 0:
+    # ---- BASELINE config 3: host branch-and-bound (tree.go semantics, gomilp_amd/bnb.py) driving GPU relaxations
+    if args.milp_nodes > 0:
         from gomilp_amd import bnb
         m3, seed3 = synth.CONFIGS["C3"]
         c3, G3, h3 = synth.dense_lp_inequality_form(m3, seed3)
@@ -215,138 +490,11 @@ def main() -> int:
         tm0 = time.perf_counter()
         mres = bnb.solve_milp(c3, None, None, G3, h3, int3, max_nodes=args.milp_nodes, workers=args.workers, device=local_rank)
         tm = time.perf_counter() - tm0
-        milp_out = {"workload": "C3: random MILP %dx%d (seed %d), 25%% integer vars, FIFO B&B, node budget %d"
-                                % (m3, 2 * m3, seed3, args.milp_nodes),
-                    "relaxations": mres.relaxations, "waves": mres.waves, "pivots": mres.pivots, "seconds": tm,
-                    "relaxations_per_s": mres.relaxations / tm, "result": mres.error or "optimal",
-                    "incumbent_z": None if mres.x is None else mres.z}
-    if dist is not None:
-        dist.barrier()
-
-    if rank == 0:
-        value = piv_all / dt_max
-        nn = n - m
-        bytes_pivot = 8.0 * (m * nn + 3.0 * m * m)      # pricing m(n-m) + FTRAN m^2 + update 2 m^2
-        pipeline = last.stats["pipeline"]
-        nsamp = max(ksec[3], 1.0)
-        extra = {}
-        if pipeline == "blocked":
-            # K pivots per k_bt_inner2 launch (one workgroup, latency-bound: no HBM roofline applies to it) followed by ONE
-            # streaming launch k_bt_update_tiled that reads and writes T = B^-1 A_N once: 16*m*(n-m) bytes, HBM-bound.
-            # (Shapes whose block terms do not fit in registers run k_bt_inner / k_bt_update on row-major T instead.)
-            nblocks = max(ksec[1], 1.0)
-            kernel_name, bytes_update, bytes_moved = ("k_bt_update_tiled" if m <= 2048 and nn <= 2048 else "k_bt_update"), 16.0 * m * nn, 16.0 * m * nn
-            t_upd = ksec[2] / nblocks
-            t_inner = ksec[0] / nblocks
-            extra = {"block_pivots": nsamp / nblocks, "k_bt_inner_us_per_launch": 1e6 * t_inner,
-                     "k_bt_inner_us_per_pivot": 1e6 * ksec[0] / nsamp, "k_bt_update_us_per_pivot": 1e6 * ksec[2] / nsamp,
-                     "time_share_inner": ksec[0] / max(ksec[0] + ksec[2], 1e-30),
-                     "note": "k_bt_inner is a single-workgroup latency-bound kernel (it touches one column and one row of T "
-                             "per pivot); the roofline entry prices the streaming kernel"}
-        elif pipeline == "tableau":
-            # one launch = one whole pivot: the launch is credited with the SURVEY per-pivot figure; what the
-            # single-kernel formulation really moves is 16*m*(n-m) bytes (read + write T = B^-1 A_N)
-            kernel_name, bytes_update, bytes_moved = "k_tableau_pivot", bytes_pivot, 16.0 * m * nn
-            t_upd = ksec[2] / nsamp
-        else:
-            kernel_name, bytes_update, bytes_moved = "k_update", 16.0 * m * m, 16.0 * m * m   # read + write B^-1
-            t_upd = ksec[2] / nsamp
-        achieved = bytes_update / t_upd / 1e9 if t_upd > 0 else 0.0
-        # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), collected
-        # with rocprofv3 --pmc in separate passes on the same command and committed under profiles/
-        traffic = None
-        if args.workload == "M":
-            import glob
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):   # newest tag last
-                try:
-                    pmc = json.load(open(path))
-                except Exception:
-                    continue
-                if pmc.get("kernel") == kernel_name:
-                    traffic = pmc["traffic_bytes_per_launch"]
-        out = {
-            "metric": "simplex pivots/sec on %dx%d fp64 dense LP" % (m, n),
-            "value": value,
-            "unit": "pivots/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt_max / max(args.steps, 1),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": "%s: %dx%d dense LP, splitmix64 seed %d (+rank), one full solve per step"
-                                   % (args.workload, m, n, synth.CONFIGS[args.workload][1]),
-                       "pivots_per_solve": int(last.stats["pivots_phase2"]), "parallelism": "1 relaxation per GPU", "pipeline": last.stats["pipeline"],
-                       "chunk": args.chunk, "refresh": args.refresh},
-            "roofline": {"bound": "hbm", "kernel": kernel_name, "pipeline": pipeline, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_launch": bytes_update, "avg_launch_us": 1e6 * t_upd,
-                         "bytes_moved_model": bytes_moved, "moved_GBs": bytes_moved / t_upd / 1e9 if t_upd > 0 else 0.0,
-                         "sampled_pivots": int(ksec[3]), "detail": extra,
-                         "per_pivot": {"bytes": bytes_pivot, "achieved_GBs": value / world * bytes_pivot / 1e9,
-                                       "frac": value / world * bytes_pivot / 1e9 / HBM_PEAK_GBS}},
-            "breakdown": {"pivot_loop_s": loop_s, "final_solve_s": final_s, "final_device_s": final_dev, "final_host_s": final_host, "wall_s": dt, "drift_xb": last.stats["drift_xb"],
-                          "z": last.z},
-        }
-        if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
-            from oracle import oracle as O   # the checker, timed as the CPU baseline (never the product path)
-            cores = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-            O.set_threads(cores)
-            tcb = time.perf_counter()
-            ro = O.simplex(c, A, b, 0.0, None, fast_initial_basis=True, stop_after_pivots=args.cpu_pivots)
-            tcb = time.perf_counter() - tcb
-            out["cpu_baseline"] = {
-                "value": ro.pivots_phase2 / ro.seconds_loop if ro.seconds_loop > 0 else 0.0,
-                "unit": "pivots/s", "cores": cores, "kind": "port",
-                "sample": "first %d Phase-II pivots of the same %dx%d LP from the slack basis (reference algorithm: "
-                          "3 fresh LU + cond estimate per pivot, gonum order); unit-column initial-basis fast path; "
-                          "%.1f s wall" % (ro.pivots_phase2, m, n, tcb)}
-            # a size where both engines finish the whole solve: the truncated sample above is not an artefact
-            c256, A256, b256 = synth.dense_lp_standard_form(256, 7)
-            O.set_threads(1)   # 256 OpenMP threads on 256x256 panels only add fork/join time
-            t1 = time.perf_counter()
-            r256 = O.simplex(c256, A256, b256, 0.0, None, fast_initial_basis=True)
-            t_cpu = time.perf_counter() - t1
-            p256 = ctx.upload(c256, A256, b256)
-            p256.solve(0.0)
-            t1 = time.perf_counter()
-            g256 = p256.solve(0.0)
-            t_gpu = time.perf_counter() - t1
-            p256.free()
-            npv = r256.pivots_phase1 + r256.pivots_phase2
-            out["cpu_baseline"]["full_solve_256x512"] = {
-                "pivots": int(npv), "cpu_cores": 1, "cpu_seconds": t_cpu, "cpu_pivots_per_s": npv / t_cpu, "gpu_seconds": t_gpu,
-                "gpu_pivots_per_s": npv / t_gpu, "same_x_bits": bool(g256.status == 0 and r256.x is not None and np.array_equal(g256.x, r256.x))}
-        if frontier_out is not None:
-            if not args.no_cpu_baseline and world == 1 and args.frontier_cpu_children > 0:
-                from concurrent.futures import ThreadPoolExecutor
-                from oracle import oracle as O
-                O.set_threads(1)
-                sample = children[: args.frontier_cpu_children]
-
-                def cpu_child(cons):
-                    cc, AA, bb = O.child_standard_form(c5, A5, b5, cons)
-                    return O.simplex(cc, AA, bb, 0.0, None, fast_initial_basis=True).status
-
-                tcb = time.perf_counter()
-                with ThreadPoolExecutor(max_workers=len(sample)) as ex:
-                    list(ex.map(cpu_child, sample))
-                tcb = time.perf_counter() - tcb
-                frontier_out["cpu_baseline"] = {"value": len(sample) / tcb, "unit": "relaxations/s", "cores": len(sample),
-                                                "kind": "port", "sample": "first %d children of the same wave, one oracle "
-                                                "solve per host thread (mirrors Problem.SetWorkers), %.1f s wall" % (len(sample), tcb)}
-            out["frontier"] = frontier_out
-        if milp_out is not None:
-            out["milp_c3"] = milp_out
-        if batched_out is not None:
-            out["batched"] = batched_out
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        out["milp_c3"] = {"workload": "C3: random MILP %dx%d (seed %d), 25%% integer vars, FIFO B&B, node budget %d" % (m3, 2 * m3, seed3, args.milp_nodes),
+                          "relaxations": mres.relaxations, "waves": mres.waves, "pivots": mres.pivots, "seconds": tm,
+                          "relaxations_per_s": mres.relaxations / tm, "result": mres.error or "optimal",
+                          "incumbent_z": None if mres.x is None else mres.z}
+    emit(out)
     prob.free()
     ctx.close()
     return 0

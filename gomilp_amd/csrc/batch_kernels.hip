@@ -14,7 +14,7 @@
 //   k_b_tab_r     reduced costs r = c_N - c_B^T T in the fixed chunk order of the single path (same bits)
 // Anything outside the common path (a zero-level artificial that needs the exchange of simplex.go:581-606, the guard band
 // around phaseIZeroTol, a zero artificial column) sets BS_HOST: the host solves that relaxation through the
-// single-relaxation engine, whose parity with the oracle the test-suite pins.
+// single-relaxation engine (the path the parity tests pin pivot by pivot).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

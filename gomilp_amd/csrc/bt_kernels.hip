@@ -1011,26 +1011,30 @@ bool bt_batch_supported(int m_max, int ldt_max) {
     return c.ri == 2 || (c.ri == 4 && c.nt == 512);
 }
 template <int NT, int RI, int VL>
-static void bt_inner_batch_nt(const BatchLP *lps, const int *ids, const int *count, int nlp, hipStream_t s) {
+static void bt_inner_batch_nt(const BatchLP *lps, const int *ids, const int *count, int nlp, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const size_t lds = (size_t)(RI + RI) * NT * (sizeof(double) + sizeof(int)) + (size_t)VL * 8 * NT * sizeof(double);
     static bool attr = false;
     if (!attr && lds > 64 * 1024) { hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner2_batch<NT, RI, RI, 8, VL>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); attr = true; }
-    hipLaunchKernelGGL((k_bt_inner2_batch<NT, RI, RI, 8, VL>), dim3(nlp), dim3(NT), lds, s, lps, ids, count);
+    hipExtLaunchKernelGGL((k_bt_inner2_batch<NT, RI, RI, 8, VL>), dim3(nlp), dim3(NT), lds, s, e0, e1, 0, lps, ids, count);
 }
 // ids / count: the active list of the previous control step (device); nlp: an upper bound of *count the host knows
-void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s) {
+void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const BtCfg c = bt_cfg(m_max, ldt_max, 0);
-    if (c.ri == 2) { if (c.nt == 512) bt_inner_batch_nt<512, 2, 0>(lps, ids, count, nlp, s); else bt_inner_batch_nt<1024, 2, 1>(lps, ids, count, nlp, s); }
-    else bt_inner_batch_nt<512, 4, 0>(lps, ids, count, nlp, s);
+    if (c.ri == 2) { if (c.nt == 512) bt_inner_batch_nt<512, 2, 0>(lps, ids, count, nlp, s, e0, e1); else bt_inner_batch_nt<1024, 2, 1>(lps, ids, count, nlp, s, e0, e1); }
+    else bt_inner_batch_nt<512, 4, 0>(lps, ids, count, nlp, s, e0, e1);
 }
-void launch_bt_update_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s) {
+const char *bt_batch_kernel_name(int m_max, int ldt_max) {
+    const BtCfg c = bt_cfg(m_max, ldt_max, 0);
+    return c.ri == 2 ? (c.nt == 512 ? "k_bt_inner2_batch<512,2,2,8,0>" : "k_bt_inner2_batch<1024,2,2,8,1>") : "k_bt_inner2_batch<512,4,4,8,0>";
+}
+void launch_bt_update_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const int gx = (2 * ldt_max + kBlock - 1) / kBlock;
     const int ntr = (m_max + 3) / 4;
     int tr = 16;   // tile rows per workgroup; at least 32 workgroups per relaxation (the CUs of one XCD)
     while (tr > 4 && gx * ((ntr + tr - 1) / tr) < 32) tr >>= 1;
     const int gy = (ntr + tr - 1) / tr;
     const int nlp_pad = (nlp + 7) & ~7;
-    hipLaunchKernelGGL((k_bt_update_tiled_batch<8>), dim3((unsigned int)(gx * gy * nlp_pad)), dim3(kBlock), 0, s, lps, ids, count, nlp_pad, gx, tr);
+    hipExtLaunchKernelGGL((k_bt_update_tiled_batch<8>), dim3((unsigned int)(gx * gy * nlp_pad)), dim3(kBlock), 0, s, e0, e1, 0, lps, ids, count, nlp_pad, gx, tr);
 }
 
 void launch_bt_tile(const double *src, double *dst, int m, int ldt, bool to_tiles, hipStream_t s) {

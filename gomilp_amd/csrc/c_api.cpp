@@ -1,6 +1,8 @@
 // extern "C" surface declared in include/gomilp_lp.h.  Each entry point names the reference
 // interface it replaces; see INTEGRATION.md for the cgo binding.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <atomic>
 #include <chrono>
@@ -140,6 +142,7 @@ int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value) {
     if (!pool || !key) return GOMILP_ERR_BAD_SHAPE;
     std::lock_guard<std::mutex> g(pool->call_mu);
     if (std::string(key) == "batched") { pool->batched = value ? 1 : 0; return GOMILP_OK; }
+    if (std::string(key) == "sample_batch") { pool->batch->set_sampling(value != 0); return GOMILP_OK; }
     int rc = GOMILP_OK;
     for (auto &e : pool->eng) { const int r = e->set(key, value); if (r != GOMILP_OK) rc = r; }
     return rc;
@@ -157,6 +160,30 @@ int gomilp_pool_set_root(gomilp_pool *pool, const double *c0, const double *A0, 
     }
     pool->m0 = m0; pool->n0 = n0;
     if (!pool->eng[0]->root_view(pool->root[0], &pool->view)) return GOMILP_ERR_DEVICE;
+    // first-touch allocations of every worker (work buffers, child slot, final-solve workspace) happen here, not inside the
+    // first waves: each worker finishes one dummy child (8 slack rows x_0 <= 1e30) from its slack basis
+    if (pool->view.unit_basis && pool->view.verify_status == GOMILP_OK) {
+        const int W = (int)pool->eng.size(), K = 8;
+        std::atomic<int> started(0);
+        for (int t = 0; t < W; t++)
+            pool->submit([pool, W, K, &started](int w) {
+                started.fetch_add(1);
+                while (started.load() < W) std::this_thread::yield();   // every worker takes exactly one of the W tasks
+                Engine &E = *pool->eng[w];
+                std::vector<int32_t> var(K, 0);
+                std::vector<double> sign(K, 1.0), rhs(K, 1e30);
+                const int64_t id = E.upload_child(pool->root[w], K, var.data(), sign.data(), rhs.data());
+                if (id < 0) return;
+                const int m = pool->view.m + K, n = pool->view.n + K;
+                std::vector<int32_t> basic(m);
+                for (int pos = 0; pos < m; pos++) basic[pos] = n - 1 - pos;
+                std::vector<double> xb(m, 0.0), x(n, 0.0);
+                double z = 0; int32_t hx = 0;
+                E.finish_from_basis(id, basic.data(), xb.data(), GOMILP_OK, &z, x.data(), &hx, nullptr, nullptr);
+                E.free_problem(id);
+            });
+        pool->drain();
+    }
     return GOMILP_OK;
 }
 
@@ -205,8 +232,12 @@ int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff,
         gomilp_lp_stats st;
         int32_t hx = 0;
         double z = NAN;
+        const double t_up = busy_since(s0);
         const int rc = E.finish_from_basis(id, basic, xb, loop_rc, &z, x.data(), &hx, nullptr, &st);
         E.free_problem(id);
+        if (getenv("GOMILP_DEBUG_TASKS") && busy_since(s0) > 5e-3)
+            fprintf(stderr, "slow finish: worker %d child %lld upload %.2f ms finish %.2f ms (device %.2f host %.2f) rounds %lld dense %lld\n", w, (long long)i, 1e3 * t_up,
+                    1e3 * st.seconds_total, 1e3 * st.seconds_final_device, 1e3 * st.seconds_final_host, (long long)st.lu_rounds, (long long)st.lu_dense_steps);
         status_out[i] = rc; z_out[i] = z; has_x_out[i] = hx;
         if (hx) for (int64_t j = 0; j < n0; j++) x_out[i * n0 + j] = x[j];
         S.kernel_launches += st.kernel_launches;
@@ -250,6 +281,8 @@ int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff,
         }
         stats->kernel_launches += bs.launches;
         stats->supersteps = bs.supersteps; stats->seconds_batch = bs.seconds_total;
+        stats->blocks = bs.blocks; stats->blocks_sampled = bs.blocks_sampled;
+        stats->seconds_inner_kernels = bs.seconds_inner; stats->seconds_update_kernels = bs.seconds_update;
         stats->workers = W; stats->device_id = pool->device;
         stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }

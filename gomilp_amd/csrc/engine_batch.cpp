@@ -47,6 +47,7 @@ struct BatchEngine::Buf {
     int32_t *h_basic = nullptr;                            // pinned result arenas
     double *h_xb = nullptr;
     std::vector<hipEvent_t> lp_ev;
+    std::vector<hipEvent_t> samp_ev;   // 4 per sampled block: inner start / stop, update start / stop
 
     void free_lp_buffers() {
         for (void *p : {(void *)d_lps, (void *)d_T, (void *)d_R, (void *)d_xb, (void *)d_U, (void *)d_V, (void *)d_scratch, (void *)d_art,
@@ -66,6 +67,8 @@ struct BatchEngine::Buf {
         for (auto &e : ev) { if (e) hipEventDestroy(e); e = nullptr; }
         for (auto &e : lp_ev) hipEventDestroy(e);
         lp_ev.clear();
+        for (auto &e : samp_ev) hipEventDestroy(e);
+        samp_ev.clear();
         cap_k = 0;
     }
 };
@@ -107,8 +110,8 @@ int BatchEngine::ensure(int nlp, int m_max, int n_max, int ldt1, int64_t ktot) {
     if (nlp > b.cap_lp || m4 > b.cap_m4 || ldt1 > b.cap_ldt || ldu > b.cap_ldu || n_max > b.cap_n) {
         B_TRY(hipStreamSynchronize(stream_));
         B_TRY(hipStreamSynchronize(copy_stream_));
-        const int clp = std::max(nlp, b.cap_lp), cm4 = std::max(m4 + 8, b.cap_m4), cldt = std::max(ldt1, b.cap_ldt),
-                  cldu = std::max(ldu + 8, b.cap_ldu), cn = std::max(n_max + 8, b.cap_n);   // head-room: deeper children add a row each
+        const int clp = std::max(nlp, b.cap_lp), cm4 = std::max(m4 + 64, b.cap_m4), cldt = std::max(ldt1, b.cap_ldt),
+                  cldu = std::max(ldu + 64, b.cap_ldu), cn = std::max(n_max + 64, b.cap_n);   // head-room: deeper children add a row each
         b.free_lp_buffers();
         const size_t L = (size_t)clp;
         B_TRY(bmalloc(&b.d_lps, L));
@@ -192,6 +195,8 @@ int BatchEngine::run(const Engine::RootView &R, int64_t count, const int64_t *ko
         B_TRY(hipMemcpyAsync(b.d_sr + b.cap_k, b.h_sr + b.cap_k, (size_t)ktot * sizeof(double), hipMemcpyHostToDevice, stream_));
     }
     int step = 0;
+    int nsamp = 0;
+    S.inner_kernel = bt_batch_kernel_name(m_max, ldt1);
     int bound = nlp;   // upper bound of the active relaxations the host knows (from the last snapshot it has seen)
     launch_b_init_ids(b.d_ids[1], b.d_active + (kMaxSteps - 1), nlp, stream_);   // list of "superstep -1": everybody
     auto snapshot = [&](int slot) -> int {
@@ -205,8 +210,13 @@ int BatchEngine::run(const Engine::RootView &R, int64_t count, const int64_t *ko
         const int *ids = b.d_ids[(step + 1) & 1];
         const int *cnt = step == 0 ? b.d_active + (kMaxSteps - 1) : b.d_active + (step - 1);
         for (int t = 0; t < nb; t++) {
-            launch_bt_inner_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_);
-            launch_bt_update_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_);
+            hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+            if (sampling_) {
+                while (b.samp_ev.size() < (size_t)(nsamp + 1) * 4) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) break; b.samp_ev.push_back(ev); }
+                if (b.samp_ev.size() >= (size_t)(nsamp + 1) * 4) { for (int q = 0; q < 4; q++) e[q] = b.samp_ev[(size_t)nsamp * 4 + q]; nsamp++; }
+            }
+            launch_bt_inner_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_, e[0], e[1]);
+            launch_bt_update_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_, e[2], e[3]);
         }
         S.launches += 2 * nb; S.blocks += nb;
     };
@@ -291,6 +301,12 @@ int BatchEngine::run(const Engine::RootView &R, int64_t count, const int64_t *ko
         }
     flush_pending(true);
     B_TRY(hipStreamSynchronize(stream_));
+    for (int k = 0; k < nsamp; k++) {
+        float a = 0, u = 0;
+        if (hipEventElapsedTime(&a, b.samp_ev[(size_t)k * 4], b.samp_ev[(size_t)k * 4 + 1]) != hipSuccess) continue;
+        if (hipEventElapsedTime(&u, b.samp_ev[(size_t)k * 4 + 2], b.samp_ev[(size_t)k * 4 + 3]) != hipSuccess) continue;
+        S.seconds_inner += a * 1e-3; S.seconds_update += u * 1e-3; S.blocks_sampled++;
+    }
     S.seconds_total = bnow() - t0;
     return GOMILP_OK;
 }

@@ -21,7 +21,11 @@ class BatchEngine {
     struct Stats {
         int64_t launches = 0, supersteps = 0, blocks = 0;
         double seconds_setup = 0, seconds_total = 0;
+        double seconds_inner = 0, seconds_update = 0;   // HIP-event time of the sampled block launches (set_sampling)
+        int64_t blocks_sampled = 0;
+        const char *inner_kernel = "";
     };
+    void set_sampling(bool on) { sampling_ = on; }
     // called on the thread that runs the wave as soon as child i is terminal; basic / xb (m_i entries, host memory, valid
     // until the next run) are non-null for BS_DONE children whose status needs the final solve
     using DoneFn = std::function<void(int64_t i, const Outcome &, const int32_t *basic, const double *xb)>;
@@ -37,6 +41,7 @@ class BatchEngine {
     struct Buf;
     int ensure(int nlp, int m_max, int n_max, int ldt1, int64_t ktot);
     int device_;
+    bool sampling_ = false;
     hipStream_t stream_ = nullptr, copy_stream_ = nullptr;
     Buf *b_;
 };

@@ -15,7 +15,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-BIG_INDEX = 2 ** 62
+BIG_INDEX = 1 << 52   # == GOMILP_NO_INCUMBENT (include/gomilp_lp.h): exact in a double
 
 
 def _mix(i: int) -> int:
@@ -64,10 +64,25 @@ def local_incumbent(indices: Sequence[int], status, z, x, has_x, integrality) ->
     return best_z, best_i
 
 
-def allreduce_incumbent(z_local: float, idx_local: int, dist=None, device=None) -> Tuple[float, int]:
-    """Global (min z, then min index).  Two scalar all-reduce(min): 8 bytes each, latency-bound."""
+def allreduce_incumbent(z_local: float, idx_local: int, dist=None, device=None, comm=None) -> Tuple[float, int]:
+    """Global (min z, then min index).
+
+    `comm` (gomilp_amd.lp.Comm): the product path — gomilp_incumbent_allreduce of the C-ABI, ONE RCCL all-reduce(min) of a
+    2 * world table per wave.  Without it (CPU tests under gloo): the same table through torch.distributed, picked by the
+    same C function (gomilp_incumbent_pick)."""
+    if comm is not None:
+        return comm.incumbent_allreduce(z_local, idx_local)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return z_local, idx_local
+    if device is None or str(device) == "cpu":
+        import torch
+        from . import lp as _lp
+        w, r = dist.get_world_size(), dist.get_rank()
+        tab = torch.full((w, 2), math.inf, dtype=torch.float64)
+        if z_local < math.inf and idx_local < BIG_INDEX:
+            tab[r, 0], tab[r, 1] = z_local, float(idx_local)
+        dist.all_reduce(tab, op=dist.ReduceOp.MIN)
+        return _lp.incumbent_pick(tab.numpy())
     import torch
     tz = torch.tensor([z_local], dtype=torch.float64, device=device)
     dist.all_reduce(tz, op=dist.ReduceOp.MIN)
@@ -78,7 +93,7 @@ def allreduce_incumbent(z_local: float, idx_local: int, dist=None, device=None) 
 
 
 def solve_wave(solve_shard: Callable[[List[list]], tuple], children: List[list], integrality: Sequence[bool],
-               rank: int = 0, world: int = 1, dist=None, device=None) -> dict:
+               rank: int = 0, world: int = 1, dist=None, device=None, comm=None) -> dict:
     """One wave: shard -> solve the shard -> incumbent all-reduce.
 
     `solve_shard(list_of_children)` returns (status, z, x, has_x) arrays for that list (FrontierPool.solve on
@@ -86,6 +101,6 @@ def solve_wave(solve_shard: Callable[[List[list]], tuple], children: List[list],
     mine = shard_indices(len(children), rank, world)
     status, z, x, has_x = solve_shard([children[i] for i in mine])
     zl, il = local_incumbent(mine, status, z, x, has_x, integrality)
-    zg, ig = allreduce_incumbent(zl, il, dist, device)
+    zg, ig = allreduce_incumbent(zl, il, dist, device, comm)
     return {"indices": mine, "status": status, "z": z, "x": x, "has_x": has_x, "incumbent_z": zg, "incumbent_index": ig,
             "local_incumbent_z": zl}

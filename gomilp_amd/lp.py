@@ -52,14 +52,16 @@ class FrontierStats(C.Structure):
                 ("bland_steps", C.c_int64), ("phase1_runs", C.c_int64), ("kernel_launches", C.c_int64),
                 ("workers", C.c_int32), ("device_id", C.c_int32), ("seconds_total", C.c_double),
                 ("seconds_busy_sum", C.c_double), ("batched_relaxations", C.c_int64), ("host_fallbacks", C.c_int64),
-                ("supersteps", C.c_int64), ("seconds_batch", C.c_double)]
+                ("supersteps", C.c_int64), ("seconds_batch", C.c_double), ("blocks", C.c_int64), ("blocks_sampled", C.c_int64),
+                ("seconds_inner_kernels", C.c_double), ("seconds_update_kernels", C.c_double)]
 
 
 EXPORTS = [
     "gomilp_lp_upload_child", "gomilp_pool_create", "gomilp_pool_destroy", "gomilp_pool_set", "gomilp_pool_set_root", "gomilp_frontier_solve",
     "gomilp_lp_simplex", "gomilp_ctx_create", "gomilp_ctx_destroy", "gomilp_ctx_device", "gomilp_ctx_set",
     "gomilp_lp_upload", "gomilp_lp_free", "gomilp_lp_solve_resident", "gomilp_lp_last_trace", "gomilp_version",
-    "gomilp_device_count", "gomilp_compiled_arch",
+    "gomilp_device_count", "gomilp_compiled_arch", "gomilp_comm_unique_id", "gomilp_comm_create", "gomilp_comm_destroy",
+    "gomilp_comm_rank", "gomilp_comm_world", "gomilp_incumbent_allreduce", "gomilp_incumbent_pick",
 ]
 
 _lib = None
@@ -100,6 +102,15 @@ def lib():
     L.gomilp_pool_set_root.argtypes = [C.c_void_p, dp, dp, C.c_int64, dp, C.c_int64, C.c_int64]
     L.gomilp_frontier_solve.argtypes = [C.c_void_p, C.c_int64, ip, i32p, dp, dp, C.c_double, dp, dp, i32p, i32p,
                                         C.POINTER(FrontierStats)]
+    L.gomilp_comm_unique_id.argtypes = [C.c_char_p]
+    L.gomilp_comm_create.restype = C.c_void_p
+    L.gomilp_comm_create.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    L.gomilp_comm_destroy.argtypes = [C.c_void_p]
+    L.gomilp_comm_rank.argtypes = [C.c_void_p]
+    L.gomilp_comm_world.argtypes = [C.c_void_p]
+    L.gomilp_incumbent_allreduce.argtypes = [C.c_void_p, C.c_double, C.c_int64, dp, ip]
+    L.gomilp_incumbent_pick.restype = None
+    L.gomilp_incumbent_pick.argtypes = [dp, C.c_int, dp, ip]
     _lib = L
     return L
 
@@ -313,6 +324,58 @@ class FrontierPool:
     def close(self) -> None:
         if self._h:
             lib().gomilp_pool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+NO_INCUMBENT = 1 << 52   # include/gomilp_lp.h: GOMILP_NO_INCUMBENT
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """Rank 0: the 128-byte RCCL id every rank needs for Comm()."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().gomilp_comm_unique_id(buf)
+    if rc != OK:
+        raise RuntimeError("gomilp_comm_unique_id failed: %s" % STATUS_NAMES.get(rc, rc))
+    return buf.raw
+
+
+def incumbent_pick(table) -> tuple:
+    """Host logic of the exchange: lexicographic minimum of a (world, 2) table of (z, index), +inf = no candidate."""
+    t = np.ascontiguousarray(table, dtype=np.float64).reshape(-1, 2)
+    z = C.c_double(math.inf)
+    i = C.c_int64(NO_INCUMBENT)
+    lib().gomilp_incumbent_pick(_dp(t), t.shape[0], C.byref(z), C.byref(i))
+    return z.value, i.value
+
+
+class Comm:
+    """RCCL communicator of the sharded frontier (one process per GPU): gomilp_incumbent_allreduce through the C-ABI."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes, device: int = -1):
+        st = C.c_int(0)
+        self._h = lib().gomilp_comm_create(int(rank), int(world), unique_id, int(device), C.byref(st))
+        if not self._h:
+            raise RuntimeError("gomilp_comm_create failed: %s" % STATUS_NAMES.get(st.value, st.value))
+        self.rank, self.world = rank, world
+
+    def incumbent_allreduce(self, z_local: float, index_local: int) -> tuple:
+        z = C.c_double(math.inf)
+        i = C.c_int64(NO_INCUMBENT)
+        rc = lib().gomilp_incumbent_allreduce(self._h, float(z_local), int(index_local), C.byref(z), C.byref(i))
+        if rc != OK:
+            raise RuntimeError("gomilp_incumbent_allreduce failed: %s" % STATUS_NAMES.get(rc, rc))
+        return z.value, i.value
+
+    def close(self) -> None:
+        if self._h:
+            lib().gomilp_comm_destroy(self._h)
             self._h = None
 
     def __del__(self):

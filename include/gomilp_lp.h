@@ -149,11 +149,15 @@ typedef struct gomilp_frontier_stats {
     int64_t host_fallbacks;      /* relaxations the batched schedule handed to a worker's single-relaxation engine */
     int64_t supersteps;          /* host round trips of the batched schedule for the WHOLE wave */
     double seconds_batch;        /* wall clock of the batched schedule */
+    int64_t blocks;              /* block steps of the batched schedule (one batched inner launch + one batched update launch each) */
+    int64_t blocks_sampled;      /* of which timed with HIP events (pool knob "sample_batch") */
+    double seconds_inner_kernels;  /* HIP-event time of the sampled batched inner launches (k_bt_inner2_batch) */
+    double seconds_update_kernels; /* ... of the sampled batched update launches (k_bt_update_tiled_batch) */
 } gomilp_frontier_stats;
 
 gomilp_pool *gomilp_pool_create(int device, int workers, int *status);
 void gomilp_pool_destroy(gomilp_pool *pool);
-/* knobs: "batched" (default 1: the pivot loops of a wave run device-batched — grid.x = relaxation, O(1) host round trips per
+/* knobs: "sample_batch" (1: time every batched block launch with HIP events), "batched" (default 1: the pivot loops of a wave run device-batched — grid.x = relaxation, O(1) host round trips per
  * superstep for the whole wave; 0: one host thread + stream per relaxation); any gomilp_ctx_set key is forwarded to the
  * worker contexts. */
 int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value);
@@ -166,6 +170,30 @@ int gomilp_pool_set_root(gomilp_pool *pool, const double *c0, const double *A0, 
 int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff, const int32_t *var, const double *sign,
                           const double *rhs, double tol, double *z_out, double *x_out, int32_t *status_out,
                           int32_t *has_x_out, gomilp_frontier_stats *stats);
+
+/* ------------------------------------------------------------------------------------------
+ * Incumbent exchange of a frontier sharded over GPUs, one process per GPU: the only state the
+ * reference's workers share is the incumbent (/root/reference/tree.go:207-263; pruning at :228-230).  One RCCL
+ * all-reduce(min) of 2 * world doubles per wave over xGMI.  The caller ships the 128-byte id from rank 0 to the
+ * other ranks by whatever transport it has (the Go host: its own RPC; bench.py: torch.distributed).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gomilp_comm gomilp_comm;
+#define GOMILP_COMM_ID_BYTES 128
+#define GOMILP_NO_INCUMBENT ((int64_t)1 << 52)   /* index meaning "this rank has no integer-feasible candidate" */
+/* rank 0: fill id_out[GOMILP_COMM_ID_BYTES] (ncclGetUniqueId). */
+int gomilp_comm_unique_id(char *id_out);
+/* every rank, with rank 0's id; collective (ncclCommInitRank).  device < 0: current HIP device. */
+gomilp_comm *gomilp_comm_create(int rank, int world, const char *id, int device, int *status);
+void gomilp_comm_destroy(gomilp_comm *comm);
+int gomilp_comm_rank(const gomilp_comm *comm);
+int gomilp_comm_world(const gomilp_comm *comm);
+/* global_z = min over ranks of local_z, global_index = the smallest child index among the ranks that attain it
+ * (ties resolved like the reference's FIFO order would); a rank without a candidate passes (+Inf, GOMILP_NO_INCUMBENT).
+ * Collective: every rank of the communicator calls it once per wave. */
+int gomilp_incumbent_allreduce(gomilp_comm *comm, double local_z, int64_t local_index, double *global_z,
+                               int64_t *global_index);
+/* the host logic of the exchange (no GPU): lexicographic minimum of a table of `world` (z, index) pairs, +Inf = none */
+void gomilp_incumbent_pick(const double *table, int world, double *global_z, int64_t *global_index);
 
 /* Library / device probes (no compute): used by the loader checks and by __graft_entry__. */
 const char *gomilp_version(void);

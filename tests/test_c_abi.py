@@ -66,3 +66,23 @@ def test_product_does_not_import_the_oracle():
 def test_bad_shapes_are_rejected_before_touching_the_device():
     r = lp.simplex([1.0], [[1.0, 1.0]], [1.0])
     assert r.status == lp.ERR_BAD_SHAPE
+
+
+def test_incumbent_pick_host_logic():
+    """gomilp_incumbent_pick: the host logic behind gomilp_incumbent_allreduce (lexicographic minimum of the (z, index)
+    table every rank receives from ONE all-reduce(min)) — no GPU needed."""
+    import math
+    inf = math.inf
+    assert lp.incumbent_pick([[inf, inf], [inf, inf]]) == (inf, lp.NO_INCUMBENT)
+    assert lp.incumbent_pick([[-3.5, 7.0], [inf, inf], [-3.5, 2.0]]) == (-3.5, 2)       # tie on z: smaller child index
+    assert lp.incumbent_pick([[-1.0, 0.0], [-2.0, 9.0]]) == (-2.0, 9)
+    assert lp.incumbent_pick([[1.0, inf], [2.0, 5.0]]) == (2.0, 5)                      # a z without an index is no candidate
+
+
+def test_comm_needs_a_device():
+    """No CPU fallback for the collective either: without a GPU the communicator cannot be created."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        lp.comm_unique_id()
