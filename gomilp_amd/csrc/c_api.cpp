@@ -294,35 +294,64 @@ int64_t gomilp_lp_last_trace(gomilp_ctx *ctx, gomilp_pivot *out, int64_t cap) {
     return ctx->eng->last_trace(out, cap);
 }
 
-// lp.Simplex drop-in (simplex.go:88): one shared context per device, created on first use; the call
-// uploads, solves and frees, so nothing of the caller's memory is retained (cgo rules).
+// lp.Simplex drop-in (simplex.go:88).  The reference's solveWorker goroutines (tree.go:98-100,196-205) call it concurrently:
+// every call checks a context (engine + stream + recycled buffers) out of a per-device free list and puts it back, so N
+// callers run on N streams; a context is created when the list is empty (at most kFlatMaxCtx per device, then callers
+// wait).  The call uploads, solves and releases: nothing of the caller's memory is retained (cgo rules).
+namespace {
+constexpr int kFlatMaxCtx = 32;
+struct FlatPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<gomilp_ctx *> free_list;
+    int created = 0;
+};
+FlatPool &flat_pool(int dev) {
+    static std::mutex mu;
+    static std::map<int, FlatPool *> pools;   // never destroyed: contexts live as long as the process (HIP tears down at exit)
+    std::lock_guard<std::mutex> g(mu);
+    auto it = pools.find(dev);
+    if (it == pools.end()) it = pools.emplace(dev, new FlatPool).first;
+    return *it->second;
+}
+}  // namespace
+
 int gomilp_lp_simplex(const double *c, const double *A, int64_t lda, const double *b, int64_t m, int64_t n, double tol,
                       const int64_t *initial_basic, double *opt_f, double *opt_x, int32_t *has_x, int64_t *basis_out,
                       gomilp_lp_stats *stats) {
-    static std::mutex mu;
-    static std::map<int, gomilp_ctx *> ctxs;
     if (has_x) *has_x = 0;
     if (opt_f) *opt_f = NAN;
     if (!c || !A || !b || !opt_f || !opt_x || !has_x || m <= 0 || n <= 0 || lda < n) return GOMILP_ERR_BAD_SHAPE;
     int dev = 0;
     if (gomilp::device_count() <= 0 || hipGetDevice(&dev) != hipSuccess) return GOMILP_ERR_DEVICE;
-    gomilp_ctx *ctx;
+    FlatPool &fp = flat_pool(dev);
+    gomilp_ctx *ctx = nullptr;
     {
-        std::lock_guard<std::mutex> g(mu);
-        auto it = ctxs.find(dev);
-        if (it == ctxs.end()) {
-            int st = 0;
-            ctx = gomilp_ctx_create(dev, &st);
-            if (!ctx) return st;
-            ctxs[dev] = ctx;
-        } else {
-            ctx = it->second;
+        std::unique_lock<std::mutex> lk(fp.mu);
+        for (;;) {
+            if (!fp.free_list.empty()) { ctx = fp.free_list.back(); fp.free_list.pop_back(); break; }
+            if (fp.created < kFlatMaxCtx) { fp.created++; break; }   // create outside the lock
+            fp.cv.wait(lk);
         }
     }
+    if (!ctx) {
+        int st = 0;
+        ctx = gomilp_ctx_create(dev, &st);
+        if (!ctx) {
+            { std::lock_guard<std::mutex> lk(fp.mu); fp.created--; }
+            fp.cv.notify_one();
+            return st;
+        }
+    }
+    int rc;
     int64_t id = gomilp_lp_upload(ctx, c, A, lda, b, m, n);
-    if (id < 0) return (int)-id;
-    int rc = gomilp_lp_solve_resident(ctx, id, tol, initial_basic, opt_f, opt_x, has_x, basis_out, stats);
-    gomilp_lp_free(ctx, id);
+    if (id < 0) rc = (int)-id;
+    else {
+        rc = gomilp_lp_solve_resident(ctx, id, tol, initial_basic, opt_f, opt_x, has_x, basis_out, stats);
+        gomilp_lp_free(ctx, id);
+    }
+    { std::lock_guard<std::mutex> lk(fp.mu); fp.free_list.push_back(ctx); }
+    fp.cv.notify_one();
     return rc;
 }
 

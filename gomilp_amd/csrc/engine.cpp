@@ -18,7 +18,9 @@ Engine::Engine(int device) : device_(device), w_(new Work) {}
 
 Engine::~Engine() {
     hipSetDevice(device_);
-    for (auto *vec : {&problems_, &child_pool_})
+    if (up_dA_) hipFree(up_dA_);
+    if (up_stats_) hipFree(up_stats_);
+    for (auto *vec : {&problems_, &child_pool_, &root_pool_})
         for (auto &p : *vec) {
             if (!p) continue;
             hipFree(p->dAt); hipFree(p->db);
@@ -120,13 +122,22 @@ int64_t Engine::upload(const double *c, const double *A, int64_t lda, const doub
     if (hipSetDevice(device_) != hipSuccess) return -GOMILP_ERR_DEVICE;
     if (!stream_ && hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) return -GOMILP_ERR_DEVICE;
     const double t0 = now_s();
-    std::unique_ptr<Problem> P(new Problem);
+    const size_t need_at = (size_t)(n + 1) * ld, need_c = (size_t)n + 1, need_b = (size_t)ld;
+    std::unique_ptr<Problem> P;
+    for (size_t i = 0; i < root_pool_.size(); i++) {   // a released root whose buffers fit
+        Problem &q = *root_pool_[i];
+        if (q.cap_at >= need_at && q.cap_c >= need_c && q.cap_b >= need_b) {
+            P = std::move(root_pool_[i]);
+            root_pool_.erase(root_pool_.begin() + i);
+            break;
+        }
+    }
+    const bool recycled = (bool)P;
+    if (!P) P.reset(new Problem);
     P->m = m; P->n = n; P->ld = ld;
     double *dA = nullptr;
     int32_t *dstats = nullptr;
     auto fail = [&](int code) -> int64_t {
-        if (dA) hipFree(dA);
-        if (dstats) hipFree(dstats);
         if (P->dAt) hipFree(P->dAt);
         if (P->dc) hipFree(P->dc);
         if (P->dc1) hipFree(P->dc1);
@@ -134,12 +145,26 @@ int64_t Engine::upload(const double *c, const double *A, int64_t lda, const doub
         return -code;
     };
 #define UP_TRY(expr) do { if ((expr) != hipSuccess) return fail(GOMILP_ERR_DEVICE); } while (0)
-    UP_TRY(dmalloc(&dA, (size_t)m * n));
-    UP_TRY(dmalloc(&P->dAt, (size_t)(n + 1) * ld));
-    UP_TRY(dmalloc(&P->dc, (size_t)n + 1));
-    UP_TRY(dmalloc(&P->dc1, (size_t)n + 1));
-    UP_TRY(dmalloc(&P->db, (size_t)ld));
-    UP_TRY(dmalloc(&dstats, (size_t)3 * n + m));
+    if (up_dA_cap_ < (size_t)m * n) {
+        if (up_dA_) hipFree(up_dA_);
+        up_dA_ = nullptr; up_dA_cap_ = 0;
+        UP_TRY(dmalloc(&up_dA_, (size_t)m * n));
+        up_dA_cap_ = (size_t)m * n;
+    }
+    if (up_stats_cap_ < (size_t)3 * n + m) {
+        if (up_stats_) hipFree(up_stats_);
+        up_stats_ = nullptr; up_stats_cap_ = 0;
+        UP_TRY(dmalloc(&up_stats_, (size_t)3 * n + m));
+        up_stats_cap_ = (size_t)3 * n + m;
+    }
+    dA = up_dA_; dstats = up_stats_;
+    if (!recycled) {
+        UP_TRY(dmalloc(&P->dAt, need_at));
+        UP_TRY(dmalloc(&P->dc, need_c));
+        UP_TRY(dmalloc(&P->dc1, need_c));
+        UP_TRY(dmalloc(&P->db, need_b));
+        P->cap_at = need_at; P->cap_c = need_c; P->cap_b = need_b;
+    }
     UP_TRY(hipMemcpy2DAsync(dA, (size_t)n * sizeof(double), A, (size_t)lda * sizeof(double), (size_t)n * sizeof(double), m,
                             hipMemcpyHostToDevice, stream_));
     UP_TRY(hipMemsetAsync(P->dAt, 0, (size_t)(n + 1) * ld * sizeof(double), stream_));
@@ -158,8 +183,6 @@ int64_t Engine::upload(const double *c, const double *A, int64_t lda, const doub
     UP_TRY(sync_stream());
     UP_TRY(hipGetLastError());
 #undef UP_TRY
-    hipFree(dA); dA = nullptr;
-    hipFree(dstats); dstats = nullptr;
     P->nnz.assign(hs.begin(), hs.begin() + n);
     P->lastrow.assign(hs.begin() + n, hs.begin() + 2 * n);
     P->allone.assign(hs.begin() + 2 * n, hs.begin() + 3 * n);
@@ -278,9 +301,15 @@ int Engine::free_problem(int64_t id) {
         problems_[id].reset();
         return GOMILP_OK;
     }
-    Problem &P = *problems_[id];
-    hipFree(P.dAt); hipFree(P.dc); hipFree(P.dc1); hipFree(P.db);
+    // a root's buffers are kept for the next upload of a fitting shape (at most 4: two shapes in rotation + slack)
+    problems_[id]->hA.clear(); problems_[id]->hA.shrink_to_fit();
+    root_pool_.push_back(std::move(problems_[id]));
     problems_[id].reset();
+    while (root_pool_.size() > 4) {
+        Problem &P = *root_pool_.front();
+        hipFree(P.dAt); hipFree(P.dc); hipFree(P.dc1); hipFree(P.db);
+        root_pool_.erase(root_pool_.begin());
+    }
     return GOMILP_OK;
 }
 

@@ -105,6 +105,12 @@ class Engine {
     std::mutex mu_;
     std::vector<std::unique_ptr<Problem>> problems_;
     std::vector<std::unique_ptr<Problem>> child_pool_;  // released children, buffers kept
+    // released root problems and the staging buffers of upload(), kept for the next upload of a fitting shape: the flat
+    // lp.Simplex drop-in uploads and frees once per call, and hipFree synchronises the whole device (it would serialise
+    // the concurrent callers of the drop-in)
+    std::vector<std::unique_ptr<Problem>> root_pool_;
+    double *up_dA_ = nullptr; size_t up_dA_cap_ = 0;
+    int32_t *up_stats_ = nullptr; size_t up_stats_cap_ = 0;
     std::unique_ptr<Work> w_;
     // knobs
     int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 2, tableau_ = 1, blocked_ = 1, block_k_ = 0,  // block_k_ 0 = auto
