@@ -418,36 +418,26 @@ def main() -> int:
             "pivots": int(npv), "cpu_cores": 1, "cpu_seconds": t_cpu, "cpu_pivots_per_s": npv / t_cpu, "gpu_seconds": t_gpu,
             "gpu_pivots_per_s": npv / t_gpu, "same_x_bits": bool(g256.status == 0 and r256.x is not None and np.array_equal(g256.x, r256.x))}
 
-    # ---- extra: B independent LPs of the headline shape on this GPU, one engine context + host thread each
+    # ---- extra: B independent LPs of the headline shape on this GPU, advancing TOGETHER through the device-batched schedule
+    # (children with no branch rows of B roots in one pool: one launch per kernel type per block step for all of them)
     if args.concurrent > 1:
-        import threading
-        cps = []
-        for i in range(args.concurrent):
-            ci, Ai, bi = synth.dense_lp_standard_form(m, seed + 100 + i)
-            cxi = lp.Context(device=local_rank, chunk=args.chunk)
-            cps.append((cxi, cxi.upload(ci, Ai, bi)))
-        resb = [None] * len(cps)
-
-        def solve_one(i):
-            resb[i] = cps[i][1].solve(0.0)
-
-        tb = 0.0
-        for rep in range(2):  # first round = warm-up
-            ths = [threading.Thread(target=solve_one, args=(i,)) for i in range(len(cps))]
+        poolb = lp.FrontierPool(device=local_rank, workers=min(args.workers, args.concurrent))
+        lps = [synth.dense_lp_standard_form(m, seed + 100 + i) for i in range(args.concurrent)]
+        poolb.set_root(*lps[0])
+        roots = [0] + [poolb.add_root(*q) for q in lps[1:]]
+        tb, resb = 0.0, None
+        for rep in range(3):  # first rounds = warm-up
             torch.cuda.synchronize()
             tb0 = time.perf_counter()
-            for t_ in ths:
-                t_.start()
-            for t_ in ths:
-                t_.join()
+            resb = poolb.solve([[] for _ in roots], roots=roots)
             torch.cuda.synchronize()
             tb = time.perf_counter() - tb0
-        pb = sum(r.stats["pivots_phase1"] + r.stats["pivots_phase2"] for r in resb)
-        out["batched"] = {"concurrent_lps": len(cps), "pivots": int(pb), "seconds": tb, "pivots_per_s": pb / tb, "vs_single": pb / tb / value,
-                          "all_ok": all(r.status == lp.OK for r in resb),
-                          "note": "independent %dx%d LPs (seeds +100..), one engine context (stream + host thread) per LP on one GPU" % (m, n)}
-        for cxi, _ in cps:
-            cxi.close()
+        pb = resb.stats["pivots_phase1"] + resb.stats["pivots_phase2"]
+        out["batched"] = {"concurrent_lps": len(roots), "pivots": int(pb), "seconds": tb, "pivots_per_s": pb / tb, "vs_single": pb / tb / value,
+                          "all_ok": bool((resb.status == lp.OK).all()), "device_batched": int(resb.stats["batched_relaxations"]),
+                          "host_round_trips": int(resb.stats["supersteps"]),
+                          "note": "independent %dx%d LPs (seeds +100..) in one device-batched schedule on one GPU (gomilp_frontier_solve_roots)" % (m, n)}
+        poolb.close()
 
     # ---- BASELINE config 4: one solve of the 4096x8192 LP
     if args.c4 and args.workload != "C4":

@@ -906,9 +906,12 @@ __global__ __launch_bounds__(kBlock) void k_bt_update_tiled(BTArgs a, int tilero
 // depends on the placement; the list is rebuilt once per superstep).
 template <int KMAX>
 __global__ __launch_bounds__(kBlock) void k_bt_update_tiled_batch(const BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count,
-                                                                  int nlp_pad, int gx, int tilerows_per_wg) {
+                                                                  int nlp_pad, int gx, int ntiles, int tilerows_per_wg, int xcd_local) {
     const unsigned int L = blockIdx.x;
-    const unsigned int li = L % (unsigned int)nlp_pad, tile = L / (unsigned int)nlp_pad;
+    // xcd_local (small tableaus, many relaxations): relaxation-minor order keeps one relaxation on one XCD (see above);
+    // otherwise tile-minor: the tiles of a large tableau spread over all 8 XCDs (one XCD's 32 CUs would stream it 8x slower)
+    const unsigned int li = xcd_local ? L % (unsigned int)nlp_pad : L / (unsigned int)ntiles;
+    const unsigned int tile = xcd_local ? L / (unsigned int)nlp_pad : L % (unsigned int)ntiles;
     if ((int)li >= *count) return;
     const BatchLP &lp = lps[ids[li]];
     const int stage = lp.stage;
@@ -1030,11 +1033,13 @@ const char *bt_batch_kernel_name(int m_max, int ldt_max) {
 void launch_bt_update_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const int gx = (2 * ldt_max + kBlock - 1) / kBlock;
     const int ntr = (m_max + 3) / 4;
-    int tr = 16;   // tile rows per workgroup; at least 32 workgroups per relaxation (the CUs of one XCD)
-    while (tr > 4 && gx * ((ntr + tr - 1) / tr) < 32) tr >>= 1;
+    const bool xcd_local = (size_t)m_max * (size_t)ldt_max * sizeof(double) <= ((size_t)3 << 20);   // fits one XCD's 4 MB L2
+    int tr = 16;   // tile rows per workgroup; at least 32 workgroups per relaxation (the CUs of one XCD), 512 for a large one
+    while (tr > 4 && gx * ((ntr + tr - 1) / tr) < (xcd_local ? 32 : 512)) tr >>= 1;
     const int gy = (ntr + tr - 1) / tr;
     const int nlp_pad = (nlp + 7) & ~7;
-    hipExtLaunchKernelGGL((k_bt_update_tiled_batch<8>), dim3((unsigned int)(gx * gy * nlp_pad)), dim3(kBlock), 0, s, e0, e1, 0, lps, ids, count, nlp_pad, gx, tr);
+    hipExtLaunchKernelGGL((k_bt_update_tiled_batch<8>), dim3((unsigned int)(gx * gy * nlp_pad)), dim3(kBlock), 0, s, e0, e1, 0, lps, ids, count, nlp_pad, gx,
+                          gx * gy, tr, xcd_local ? 1 : 0);
 }
 
 void launch_bt_tile(const double *src, double *dst, int m, int ldt, bool to_tiles, hipStream_t s) {

@@ -38,6 +38,9 @@ struct gomilp_pool {
     int batched = 1;            // knob: 0 = every relaxation through a worker's single-relaxation engine (round-1 path)
     std::unique_ptr<BatchEngine> batch;
     Engine::RootView view;      // of eng[0]'s root (all workers hold the same data)
+    // further roots (gomilp_pool_add_root): resident in worker 0's engine only, read in place by the others
+    std::vector<int64_t> extra_root;
+    std::vector<std::unique_ptr<Engine::RootView>> extra_view;
     std::mutex call_mu;         // one wave at a time per pool
     // persistent workers
     std::vector<std::thread> threads;
@@ -152,6 +155,8 @@ int gomilp_pool_set_root(gomilp_pool *pool, const double *c0, const double *A0, 
                          int64_t n0) {
     if (!pool) return GOMILP_ERR_BAD_SHAPE;
     std::lock_guard<std::mutex> g(pool->call_mu);
+    for (auto id : pool->extra_root) pool->eng[0]->free_problem(id);
+    pool->extra_root.clear(); pool->extra_view.clear();
     for (size_t w = 0; w < pool->eng.size(); w++) {
         if (pool->root[w] >= 0) pool->eng[w]->free_problem(pool->root[w]);
         int64_t id = pool->eng[w]->upload(c0, A0, lda, b0, m0, n0);
@@ -187,14 +192,30 @@ int gomilp_pool_set_root(gomilp_pool *pool, const double *c0, const double *A0, 
     return GOMILP_OK;
 }
 
-int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff, const int32_t *var, const double *sign,
-                          const double *rhs, double tol, double *z_out, double *x_out, int32_t *status_out,
-                          int32_t *has_x_out, gomilp_frontier_stats *stats) {
+int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t *root_of, const int64_t *koff, const int32_t *var,
+                                const double *sign, const double *rhs, double tol, double *z_out, double *x_out, int64_t ldx,
+                                int32_t *status_out, int32_t *has_x_out, gomilp_frontier_stats *stats) {
     if (!pool || count < 0 || !koff || !z_out || !x_out || !status_out || !has_x_out) return GOMILP_ERR_BAD_SHAPE;
     for (auto r : pool->root) if (r < 0) return GOMILP_ERR_BAD_SHAPE;
     std::lock_guard<std::mutex> call_guard(pool->call_mu);
     const auto t0 = std::chrono::steady_clock::now();
-    const int64_t n0 = pool->n0;
+    const int nroots = 1 + (int)pool->extra_root.size();
+    std::vector<const Engine::RootView *> views(nroots);
+    views[0] = &pool->view;
+    for (int r = 1; r < nroots; r++) views[r] = pool->extra_view[r - 1].get();
+    for (int64_t i = 0; i < count; i++) {
+        const int ri = root_of ? root_of[i] : 0;
+        if (ri < 0 || ri >= nroots || views[ri]->n > ldx) return GOMILP_ERR_BAD_SHAPE;
+    }
+    auto rootn = [&](int64_t i) -> int64_t { return views[root_of ? root_of[i] : 0]->n; };
+    // child i of root r on worker w: root 0 lives in every worker's engine, the others in worker 0's
+    auto upload_child = [&](int w, int64_t i) -> int64_t {
+        const int ri = root_of ? root_of[i] : 0;
+        const int64_t k0 = koff[i], K = koff[i + 1] - koff[i];
+        Engine &E = *pool->eng[w];
+        if (ri == 0) return E.upload_child(pool->root[w], (int)K, var + k0, sign + k0, rhs + k0);
+        return E.upload_child_of(*pool->eng[0], pool->extra_root[ri - 1], (int)K, var + k0, sign + k0, rhs + k0);
+    };
     const int W = (int)pool->eng.size();
     std::vector<gomilp_frontier_stats> ws(W);
     for (auto &S : ws) S = gomilp_frontier_stats();
@@ -205,8 +226,8 @@ int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff,
         const auto s0 = std::chrono::steady_clock::now();
         Engine &E = *pool->eng[w];
         gomilp_frontier_stats &S = ws[w];
-        const int64_t k0 = koff[i], K = koff[i + 1] - koff[i];
-        int64_t id = E.upload_child(pool->root[w], (int)K, var + k0, sign + k0, rhs + k0);
+        const int64_t K = koff[i + 1] - koff[i], n0 = rootn(i);
+        int64_t id = upload_child(w, i);
         if (id < 0) { status_out[i] = (int32_t)-id; return; }
         std::vector<double> x((size_t)(n0 + K), 0.0);
         gomilp_lp_stats st;
@@ -215,7 +236,7 @@ int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff,
         const int rc = E.solve(id, tol, nullptr, &z, x.data(), &hx, nullptr, &st);
         E.free_problem(id);
         status_out[i] = rc; z_out[i] = z; has_x_out[i] = hx;
-        if (hx) for (int64_t j = 0; j < n0; j++) x_out[i * n0 + j] = x[j];  // subproblem.go:157-159
+        if (hx) for (int64_t j = 0; j < n0; j++) x_out[i * ldx + j] = x[j];  // subproblem.go:157-159
         S.relaxations++; S.pivots_phase1 += st.pivots_phase1; S.pivots_phase2 += st.pivots_phase2;
         S.bland_steps += st.bland_steps; S.phase1_runs += st.phase1_used; S.kernel_launches += st.kernel_launches;
         S.seconds_busy_sum += busy_since(s0);
@@ -225,8 +246,8 @@ int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff,
         const auto s0 = std::chrono::steady_clock::now();
         Engine &E = *pool->eng[w];
         gomilp_frontier_stats &S = ws[w];
-        const int64_t k0 = koff[i], K = koff[i + 1] - koff[i];
-        int64_t id = E.upload_child(pool->root[w], (int)K, var + k0, sign + k0, rhs + k0);
+        const int64_t K = koff[i + 1] - koff[i], n0 = rootn(i);
+        int64_t id = upload_child(w, i);
         if (id < 0) { status_out[i] = (int32_t)-id; return; }
         std::vector<double> x((size_t)(n0 + K), 0.0);
         gomilp_lp_stats st;
@@ -239,7 +260,7 @@ int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff,
             fprintf(stderr, "slow finish: worker %d child %lld upload %.2f ms finish %.2f ms (device %.2f host %.2f) rounds %lld dense %lld\n", w, (long long)i, 1e3 * t_up,
                     1e3 * st.seconds_total, 1e3 * st.seconds_final_device, 1e3 * st.seconds_final_host, (long long)st.lu_rounds, (long long)st.lu_dense_steps);
         status_out[i] = rc; z_out[i] = z; has_x_out[i] = hx;
-        if (hx) for (int64_t j = 0; j < n0; j++) x_out[i * n0 + j] = x[j];
+        if (hx) for (int64_t j = 0; j < n0; j++) x_out[i * ldx + j] = x[j];
         S.kernel_launches += st.kernel_launches;
         S.seconds_busy_sum += busy_since(s0);
     };
@@ -247,9 +268,15 @@ int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff,
     for (int64_t i = 0; i < count; i++) K_max = std::max<int>(K_max, (int)(koff[i + 1] - koff[i]));
     gomilp_frontier_stats agg = gomilp_frontier_stats();
     BatchEngine::Stats bs;
-    const bool use_batch = pool->batched && count > 0 && pool->batch->eligible(pool->view, K_max);
+    bool use_batch = pool->batched && count > 0;
+    bool any_p1 = false;
+    for (int r = 0; r < nroots && !any_p1; r++) for (double v : views[r]->hb) if (v < -1e-13) { any_p1 = true; break; }
+    for (int64_t k = koff[0]; k < koff[count] && !any_p1; k++) if (rhs[k] < -1e-13) any_p1 = true;
+    for (int r = 0; r < nroots && use_batch; r++) use_batch = pool->batch->eligible(*views[r], K_max, any_p1);
     if (use_batch) {
-        auto on_done = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) {
+        std::mutex agg_mu;
+        auto on_done_at = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) {
+            std::lock_guard<std::mutex> lk(agg_mu);
             if (o.stage != gomilp::BS_DONE) {   // a path the device schedule does not cover
                 agg.host_fallbacks++;
                 pool->submit([&full_solve, i](int w) { full_solve(w, i); });
@@ -265,7 +292,8 @@ int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff,
                 if (o.status == GOMILP_ERR_UNBOUNDED) z_out[i] = -INFINITY;   // simplex.go:261-263
             }
         };
-        const int rc = pool->batch->run(pool->view, count, koff, var, sign, rhs, tol, on_done, &bs);
+        auto on_done = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) { on_done_at(i, o, basic, xb); };
+        const int rc = pool->batch->run_roots(views.data(), nroots, root_of, count, koff, var, sign, rhs, tol, on_done, &bs);
         pool->drain();
         if (rc != GOMILP_OK) return rc;
     } else {
@@ -287,6 +315,26 @@ int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff,
         stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     return GOMILP_OK;
+}
+
+int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff, const int32_t *var, const double *sign,
+                          const double *rhs, double tol, double *z_out, double *x_out, int32_t *status_out,
+                          int32_t *has_x_out, gomilp_frontier_stats *stats) {
+    if (!pool) return GOMILP_ERR_BAD_SHAPE;
+    return gomilp_frontier_solve_roots(pool, count, nullptr, koff, var, sign, rhs, tol, z_out, x_out, pool->n0, status_out, has_x_out, stats);
+}
+
+int gomilp_pool_add_root(gomilp_pool *pool, const double *c, const double *A, int64_t lda, const double *b, int64_t m, int64_t n) {
+    if (!pool) return -GOMILP_ERR_BAD_SHAPE;
+    std::lock_guard<std::mutex> g(pool->call_mu);
+    if (pool->root[0] < 0) return -GOMILP_ERR_BAD_SHAPE;   // gomilp_pool_set_root first
+    const int64_t id = pool->eng[0]->upload(c, A, lda, b, m, n);
+    if (id < 0) return (int)id;
+    std::unique_ptr<Engine::RootView> v(new Engine::RootView);
+    if (!pool->eng[0]->root_view(id, v.get())) return -GOMILP_ERR_DEVICE;
+    pool->extra_root.push_back(id);
+    pool->extra_view.push_back(std::move(v));
+    return (int)pool->extra_root.size();
 }
 
 int64_t gomilp_lp_last_trace(gomilp_ctx *ctx, gomilp_pivot *out, int64_t cap) {

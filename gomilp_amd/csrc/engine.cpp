@@ -4,6 +4,8 @@
 // surfaces as GOMILP_ERR_DEVICE.
 #include "engine_work.hpp"
 
+#include <atomic>
+
 namespace gomilp {
 
 int device_count() {
@@ -199,17 +201,36 @@ int64_t Engine::upload(const double *c, const double *A, int64_t lda, const doub
     for (int j = 0; j < n && P->verify_status == GOMILP_OK; j++)
         if (P->nnz[j] == 0) P->verify_status = (c[j] < 0) ? GOMILP_ERR_UNBOUNDED : GOMILP_ERR_ZERO_COLUMN;
     P->seconds_upload = now_s() - t0;
+    { static std::atomic<uint64_t> next_serial(1); P->serial = next_serial.fetch_add(1); }
     for (size_t i = 0; i < problems_.size(); i++)
         if (!problems_[i]) { problems_[i] = std::move(P); return (int64_t)i; }
     problems_.push_back(std::move(P));
     return (int64_t)problems_.size() - 1;
 }
 
+const Problem *Engine::problem_ptr(int64_t id) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (id < 0 || (size_t)id >= problems_.size() || !problems_[id]) return nullptr;
+    return problems_[id].get();
+}
+
 int64_t Engine::upload_child(int64_t root, int K, const int32_t *var, const double *sign, const double *rhs) {
     std::lock_guard<std::mutex> g(mu_);
-    if (root < 0 || (size_t)root >= problems_.size() || !problems_[root] || K < 0 || (K > 0 && (!var || !sign || !rhs)))
-        return -GOMILP_ERR_BAD_SHAPE;
-    const Problem &R = *problems_[root];
+    if (root < 0 || (size_t)root >= problems_.size() || !problems_[root]) return -GOMILP_ERR_BAD_SHAPE;
+    return upload_child_impl(*problems_[root], root, K, var, sign, rhs);
+}
+
+int64_t Engine::upload_child_of(Engine &owner, int64_t root, int K, const int32_t *var, const double *sign, const double *rhs) {
+    if (&owner == this) return upload_child(root, K, var, sign, rhs);
+    if (owner.device_ != device_) return -GOMILP_ERR_BAD_SHAPE;
+    const Problem *R = owner.problem_ptr(root);
+    if (!R) return -GOMILP_ERR_BAD_SHAPE;
+    std::lock_guard<std::mutex> g(mu_);
+    return upload_child_impl(*R, -1, K, var, sign, rhs);   // no root link: the host copy of A (general-basis path) is not reachable
+}
+
+int64_t Engine::upload_child_impl(const Problem &R, int64_t root, int K, const int32_t *var, const double *sign, const double *rhs) {
+    if (K < 0 || (K > 0 && (!var || !sign || !rhs))) return -GOMILP_ERR_BAD_SHAPE;
     const int m0 = R.m, n0 = R.n, m = m0 + K, n = n0 + K;
     const int ld = (m + 1) & ~1;
     for (int k = 0; k < K; k++) if (var[k] < 0 || var[k] >= n0) return -GOMILP_ERR_BAD_SHAPE;
@@ -1187,7 +1208,7 @@ bool Engine::root_view(int64_t id, RootView *out) {
     if (id < 0 || (size_t)id >= problems_.size() || !problems_[id]) return false;
     const Problem &P = *problems_[id];
     out->m = P.m; out->n = P.n; out->ld = P.ld; out->dAt = P.dAt; out->dc = P.dc; out->db = P.db;
-    out->verify_status = P.verify_status;
+    out->verify_status = P.verify_status; out->serial = P.serial; out->hb = P.hb; out->hc = P.hc;
     out->rho0.assign(P.m, 0);
     out->unit_basis = P.m < P.n;
     std::vector<char> used(P.m, 0);

@@ -28,6 +28,7 @@ struct Problem {
     std::vector<int32_t> nnz, lastrow, allone;  // per column of A
     int verify_status = GOMILP_OK;              // verifyInputs, simplex.go:385-439
     double seconds_upload = 0;
+    uint64_t serial = 0;      // unique per upload (device buffers are recycled: a pointer does not identify a problem)
     // children are recycled: their device buffers go back to a per-engine pool instead of hipFree (which synchronises
     // the whole device and would serialise the worker streams of a frontier pool)
     bool is_child = false;
@@ -51,6 +52,9 @@ class Engine {
     int free_problem(int64_t id);
     // child of a resident root: K branch-and-bound rows (var, sign, rhs) appended on the device (subproblem.go:141-159)
     int64_t upload_child(int64_t root, int K, const int32_t *var, const double *sign, const double *rhs);
+    // the same with the root resident in ANOTHER engine of the same device (read in place: device buffers are immutable
+    // after upload); the owner must not free the root before the child is freed
+    int64_t upload_child_of(Engine &owner, int64_t root, int K, const int32_t *var, const double *sign, const double *rhs);
     int solve(int64_t id, double tol, const int64_t *initial_basic, double *opt_f, double *opt_x, int32_t *has_x,
               int64_t *basis_out, gomilp_lp_stats *stats);
     int64_t last_trace(gomilp_pivot *out, int64_t cap);
@@ -63,6 +67,8 @@ class Engine {
         bool unit_basis = false;          // the descending scan of simplex.go:618-635 meets m distinct unit columns
         std::vector<int32_t> rho0;        // their rows, by basis position
         int verify_status = GOMILP_OK;
+        uint64_t serial = 0;              // identifies the upload (device buffers are recycled)
+        std::vector<double> hb, hc;       // host copies of b and c (final solves on another engine's behalf)
     };
     bool root_view(int64_t id, RootView *out);
     // epilogue of simplex() (simplex.go:296-301) for a relaxation whose pivot loop ran elsewhere: final basis positions
@@ -73,6 +79,8 @@ class Engine {
    private:
     struct Work;  // device work buffers, sized for the largest problem seen
     int ensure_work(int m, int ncols);
+    const Problem *problem_ptr(int64_t id);
+    int64_t upload_child_impl(const Problem &R, int64_t root_id, int K, const int32_t *var, const double *sign, const double *rhs);
     LPArgs make_args(const Problem &P, int phase, double tol, int nn, const double *cost);
     int run_loop(const Problem &P, int phase, double tol, int nn, const double *cost, gomilp_lp_stats *st);
     int run_loop_fused(const Problem &P, int phase, double tol, int nn, const double *cost, gomilp_lp_stats *st);

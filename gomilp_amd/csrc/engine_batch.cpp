@@ -40,8 +40,8 @@ struct BatchEngine::Buf {
     DevState *d_st = nullptr;
     int32_t *d_var = nullptr, *h_var = nullptr;
     double *d_sr = nullptr, *h_sr = nullptr;               // sign | rhs
-    int32_t *d_rho0 = nullptr;
-    const double *rho_key = nullptr; int rho_m0 = 0, rho_n0 = 0;
+    struct Rho { uint64_t serial; int32_t *d; };
+    std::vector<Rho> rho;   // unit-column rows of the roots seen (device), keyed by the upload's serial number
     int *d_active = nullptr;
     int *d_ids[2] = {nullptr, nullptr};   // active lists, double buffered by superstep parity
     int32_t *h_basic = nullptr;                            // pinned result arenas
@@ -61,9 +61,11 @@ struct BatchEngine::Buf {
     }
     void free_all() {
         free_lp_buffers();
-        for (void *p : {(void *)d_var, (void *)d_sr, (void *)d_rho0, (void *)d_active}) if (p) hipFree(p);
+        for (void *p : {(void *)d_var, (void *)d_sr, (void *)d_active}) if (p) hipFree(p);
+        for (auto &r : rho) hipFree(r.d);
+        rho.clear();
         for (void *p : {(void *)h_var, (void *)h_sr, (void *)h_active[0], (void *)h_active[1]}) if (p) hipHostFree(p);
-        d_var = nullptr; d_sr = nullptr; d_rho0 = nullptr; d_active = nullptr; h_var = nullptr; h_sr = nullptr; h_active[0] = h_active[1] = nullptr;
+        d_var = nullptr; d_sr = nullptr; d_active = nullptr; h_var = nullptr; h_sr = nullptr; h_active[0] = h_active[1] = nullptr;
         for (auto &e : ev) { if (e) hipEventDestroy(e); e = nullptr; }
         for (auto &e : lp_ev) hipEventDestroy(e);
         lp_ev.clear();
@@ -85,12 +87,12 @@ BatchEngine::~BatchEngine() {
     if (copy_stream_) hipStreamDestroy(copy_stream_);
 }
 
-bool BatchEngine::eligible(const Engine::RootView &R, int K_max) const {
+bool BatchEngine::eligible(const Engine::RootView &R, int K_max, bool phase1) const {
     if (R.verify_status != GOMILP_OK || !R.unit_basis) return false;
     const int m = R.m + K_max, n = R.n + K_max;
     if (m >= n || !((n - m) < 2 * m)) return false;              // the tableau formulation (engine.cpp: use_tab)
     if (n + 2 > 8000) return false;                              // k_b_ctrl keeps two int lists of n in (default-limit) LDS
-    const int ldt1 = batch_ldt(n - m + 1);
+    const int ldt1 = batch_ldt(n - m + (phase1 ? 1 : 0));
     return bt_batch_supported(m, ldt1);
 }
 
@@ -141,31 +143,50 @@ int BatchEngine::ensure(int nlp, int m_max, int n_max, int ldt1, int64_t ktot) {
     return GOMILP_OK;
 }
 
-int BatchEngine::run(const Engine::RootView &R, int64_t count, const int64_t *koff, const int32_t *var, const double *sign,
-                     const double *rhs, double tol, const DoneFn &on_done, Stats *stats) {
+int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, const int32_t *root_of, int64_t count, const int64_t *koff,
+                           const int32_t *var, const double *sign, const double *rhs, double tol, const DoneFn &on_done, Stats *stats) {
     const double t0 = bnow();
     Stats local;
     Stats &S = stats ? *stats : local;
     S = Stats();
     if (count <= 0) return GOMILP_OK;
-    if (count > 65535) return GOMILP_ERR_UNSUPPORTED;
+    if (count > 65535 || nroots < 1) return GOMILP_ERR_UNSUPPORTED;
     const int nlp = (int)count;
-    int K_max = 0;
-    for (int i = 0; i < nlp; i++) K_max = std::max<int>(K_max, (int)(koff[i + 1] - koff[i]));
+    int m_max = 0, n_max = 0, ldt1 = 0;
+    for (int i = 0; i < nlp; i++) {
+        const int ri = root_of ? root_of[i] : 0;
+        if (ri < 0 || ri >= nroots) return GOMILP_ERR_BAD_SHAPE;
+        const Engine::RootView &Ri = *roots[ri];
+        const int K = (int)(koff[i + 1] - koff[i]);
+        m_max = std::max(m_max, Ri.m + K); n_max = std::max(n_max, Ri.n + K);
+        bool p1 = false;   // does this relaxation start infeasible?  (initPosTol; the set-up kernel decides the same way)
+        for (double v : Ri.hb) if (v < -1e-13) { p1 = true; break; }
+        for (int64_t k = koff[i]; k < koff[i + 1] && !p1; k++) if (rhs[k] < -1e-13) p1 = true;
+        ldt1 = std::max(ldt1, batch_ldt(Ri.n - Ri.m + (p1 ? 1 : 0)));   // Phase-I tableau: one column more (the artificial)
+    }
     const int64_t ktot = koff[nlp] - koff[0];
-    const int m_max = R.m + K_max, n_max = R.n + K_max;
-    const int ldt1 = batch_ldt(R.n - R.m + 1);   // Phase-I tableau: one column more (the artificial); the same for every child
     int rc = ensure(nlp, m_max, n_max, ldt1, ktot);
     if (rc != GOMILP_OK) return rc;
     Buf &b = *b_;
-    // ---- root data the kernels read in place + the unit-column rows of the root's slack basis
-    if (b.rho_key != R.dAt || b.rho_m0 != R.m || b.rho_n0 != R.n) {
-        B_TRY(hipStreamSynchronize(stream_));
-        if (b.d_rho0) hipFree(b.d_rho0);
-        b.d_rho0 = nullptr;
-        B_TRY(bmalloc(&b.d_rho0, (size_t)R.m));
-        B_TRY(hipMemcpy(b.d_rho0, R.rho0.data(), (size_t)R.m * sizeof(int32_t), hipMemcpyHostToDevice));
-        b.rho_key = R.dAt; b.rho_m0 = R.m; b.rho_n0 = R.n;
+    // ---- root data the kernels read in place + the unit-column rows of each root's slack basis
+    std::vector<const int32_t *> rho_of(nroots, nullptr);
+    for (int r = 0; r < nroots; r++) {
+        const Engine::RootView &R = *roots[r];
+        for (auto &e : b.rho) if (e.serial == R.serial) rho_of[r] = e.d;
+        if (rho_of[r]) continue;
+        if (b.rho.size() >= 64) {   // roots come and go (B&B restarts): forget the old ones
+            B_TRY(hipStreamSynchronize(stream_));
+            for (auto &e : b.rho) hipFree(e.d);
+            b.rho.clear();
+            for (int q = 0; q < r; q++) rho_of[q] = nullptr;
+            r = -1;
+            continue;
+        }
+        Buf::Rho e{R.serial, nullptr};
+        B_TRY(bmalloc(&e.d, (size_t)R.m));
+        B_TRY(hipMemcpy(e.d, R.rho0.data(), (size_t)R.m * sizeof(int32_t), hipMemcpyHostToDevice));
+        b.rho.push_back(e);
+        rho_of[r] = e.d;
     }
     // ---- per-relaxation argument blocks
     const size_t sT = (size_t)b.cap_m4 * b.cap_ldt;
@@ -175,7 +196,9 @@ int BatchEngine::run(const Engine::RootView &R, int64_t count, const int64_t *ko
         memset(&lp, 0, sizeof(lp));
         const int K = (int)(koff[i + 1] - koff[i]);
         const int64_t k0 = koff[i] - koff[0];
-        lp.At0 = R.dAt; lp.c0 = R.dc; lp.b0 = R.db; lp.rho0 = b.d_rho0;
+        const int ri = root_of ? root_of[i] : 0;
+        const Engine::RootView &R = *roots[ri];
+        lp.At0 = R.dAt; lp.c0 = R.dc; lp.b0 = R.db; lp.rho0 = rho_of[ri];
         lp.var = b.d_var + k0; lp.sign = b.d_sr + k0; lp.rhs = b.d_sr + b.cap_k + k0;
         lp.ld0 = R.ld; lp.m0 = R.m; lp.n0 = R.n; lp.K = K; lp.m = R.m + K; lp.n = R.n + K;
         lp.ldu = (lp.m + 1) & ~1; lp.cap_ldt = b.cap_ldt;

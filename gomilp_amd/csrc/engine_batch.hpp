@@ -33,9 +33,17 @@ class BatchEngine {
     explicit BatchEngine(int device);
     ~BatchEngine();
     // can children of this root with up to K_max branch rows take the batched path?
-    bool eligible(const Engine::RootView &R, int K_max) const;
+    // (phase1: some relaxation of the wave starts infeasible — the Phase-I tableau is one column wider)
+    bool eligible(const Engine::RootView &R, int K_max, bool phase1) const;
     int run(const Engine::RootView &R, int64_t count, const int64_t *koff, const int32_t *var, const double *sign,
-            const double *rhs, double tol, const DoneFn &on_done, Stats *stats);
+            const double *rhs, double tol, const DoneFn &on_done, Stats *stats) {
+        const Engine::RootView *one = &R;
+        return run_roots(&one, 1, nullptr, count, koff, var, sign, rhs, tol, on_done, stats);
+    }
+    // relaxation i is a child (K_i >= 0 rows) of roots[root_of[i]] (root_of == nullptr: all of roots[0]); the wave is
+    // ONE batch: independent LPs of similar shape are children with K = 0 of different roots
+    int run_roots(const Engine::RootView *const *roots, int nroots, const int32_t *root_of, int64_t count, const int64_t *koff,
+                  const int32_t *var, const double *sign, const double *rhs, double tol, const DoneFn &on_done, Stats *stats);
 
    private:
     struct Buf;

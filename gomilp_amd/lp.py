@@ -57,7 +57,7 @@ class FrontierStats(C.Structure):
 
 
 EXPORTS = [
-    "gomilp_lp_upload_child", "gomilp_pool_create", "gomilp_pool_destroy", "gomilp_pool_set", "gomilp_pool_set_root", "gomilp_frontier_solve",
+    "gomilp_lp_upload_child", "gomilp_pool_create", "gomilp_pool_destroy", "gomilp_pool_set", "gomilp_pool_set_root", "gomilp_frontier_solve", "gomilp_pool_add_root", "gomilp_frontier_solve_roots",
     "gomilp_lp_simplex", "gomilp_ctx_create", "gomilp_ctx_destroy", "gomilp_ctx_device", "gomilp_ctx_set",
     "gomilp_lp_upload", "gomilp_lp_free", "gomilp_lp_solve_resident", "gomilp_lp_last_trace", "gomilp_version",
     "gomilp_device_count", "gomilp_compiled_arch", "gomilp_comm_unique_id", "gomilp_comm_create", "gomilp_comm_destroy",
@@ -102,6 +102,9 @@ def lib():
     L.gomilp_pool_set_root.argtypes = [C.c_void_p, dp, dp, C.c_int64, dp, C.c_int64, C.c_int64]
     L.gomilp_frontier_solve.argtypes = [C.c_void_p, C.c_int64, ip, i32p, dp, dp, C.c_double, dp, dp, i32p, i32p,
                                         C.POINTER(FrontierStats)]
+    L.gomilp_pool_add_root.argtypes = [C.c_void_p, dp, dp, C.c_int64, dp, C.c_int64, C.c_int64]
+    L.gomilp_frontier_solve_roots.argtypes = [C.c_void_p, C.c_int64, i32p, ip, i32p, dp, dp, C.c_double, dp, dp, C.c_int64, i32p, i32p,
+                                              C.POINTER(FrontierStats)]
     L.gomilp_comm_unique_id.argtypes = [C.c_char_p]
     L.gomilp_comm_create.restype = C.c_void_p
     L.gomilp_comm_create.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
@@ -292,9 +295,23 @@ class FrontierPool:
         if rc != OK:
             raise RuntimeError("gomilp_pool_set_root failed: %s" % STATUS_NAMES.get(rc, rc))
         self.m0, self.n0 = m0, n0
+        self._widths = [n0]
 
-    def solve(self, children, tol: float = 0.0) -> FrontierResult:
-        """children: list of constraint lists [(var, sign, rhs), ...]."""
+    def add_root(self, c, A, b) -> int:
+        """Another root in the same pool (resident once, on the pool's first worker): returns its index (>= 1)."""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        c = np.ascontiguousarray(c, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        m, n = A.shape
+        r = lib().gomilp_pool_add_root(self._h, _dp(c), _dp(A), n, _dp(b), m, n)
+        if r < 0:
+            raise RuntimeError("gomilp_pool_add_root failed: %s" % STATUS_NAMES.get(-r, -r))
+        self._widths = getattr(self, "_widths", [self.n0]) + [n]
+        return r
+
+    def solve(self, children, tol: float = 0.0, roots=None) -> FrontierResult:
+        """children: list of constraint lists [(var, sign, rhs), ...]; roots: per child the index of its root
+        (default: all children of the set_root problem).  Independent LPs: children [] of different roots."""
         count = len(children)
         koff = np.zeros(count + 1, dtype=np.int64)
         for i, ch in enumerate(children):
@@ -309,14 +326,16 @@ class FrontierPool:
                 var[k], sign[k], rhs[k] = v, s, r
                 k += 1
         z = np.full(count, math.nan)
-        x = np.zeros((count, self.n0))
+        ldx = max(getattr(self, "_widths", [self.n0]))
+        x = np.zeros((count, ldx))
         status = np.zeros(count, dtype=np.int32)
         has_x = np.zeros(count, dtype=np.int32)
         st = FrontierStats()
         i32p = C.POINTER(C.c_int32)
-        rc = lib().gomilp_frontier_solve(self._h, count, _ip(koff), var.ctypes.data_as(i32p), _dp(sign), _dp(rhs),
-                                         float(tol), _dp(z), _dp(x), status.ctypes.data_as(i32p),
-                                         has_x.ctypes.data_as(i32p), C.byref(st))
+        rof = None if roots is None else np.ascontiguousarray(roots, dtype=np.int32)
+        rc = lib().gomilp_frontier_solve_roots(self._h, count, None if rof is None else rof.ctypes.data_as(i32p), _ip(koff),
+                                               var.ctypes.data_as(i32p), _dp(sign), _dp(rhs), float(tol), _dp(z), _dp(x), ldx,
+                                               status.ctypes.data_as(i32p), has_x.ctypes.data_as(i32p), C.byref(st))
         if rc != OK:
             raise RuntimeError("gomilp_frontier_solve failed: %s" % STATUS_NAMES.get(rc, rc))
         return FrontierResult(status, z, x, has_x, {k: getattr(st, k) for k, _ in FrontierStats._fields_})

@@ -195,6 +195,15 @@ int gomilp_incumbent_allreduce(gomilp_comm *comm, double local_z, int64_t local_
 /* the host logic of the exchange (no GPU): lexicographic minimum of a table of `world` (z, index) pairs, +Inf = none */
 void gomilp_incumbent_pick(const double *table, int world, double *global_z, int64_t *global_index);
 
+/* Several roots in one pool: relaxation i of a wave is a child (K_i >= 0 rows) of root root_of[i]; index 0 is the root of
+ * gomilp_pool_set_root, gomilp_pool_add_root returns 1, 2, ... (or -(gomilp_status)).  Independent LPs of similar shape
+ * are children with K = 0 of different roots: they advance together through the device-batched schedule (one launch per
+ * kernel type for all of them).  x_out has row stride ldx >= the widest root; gomilp_pool_set_root drops the added roots. */
+int gomilp_pool_add_root(gomilp_pool *pool, const double *c, const double *A, int64_t lda, const double *b, int64_t m, int64_t n);
+int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t *root_of, const int64_t *koff, const int32_t *var,
+                                const double *sign, const double *rhs, double tol, double *z_out, double *x_out, int64_t ldx,
+                                int32_t *status_out, int32_t *has_x_out, gomilp_frontier_stats *stats);
+
 /* Library / device probes (no compute): used by the loader checks and by __graft_entry__. */
 const char *gomilp_version(void);
 int gomilp_device_count(void);
