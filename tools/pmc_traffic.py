@@ -1,7 +1,10 @@
-"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, see profiles/README.md) into
-profiles/<tag>_pmc_traffic.json + a merged per-kernel CSV.   python tools/pmc_traffic.py <fetch_csv> <write_csv> <tag>"""
+"""Turn the rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs, see profiles/README.md; optionally an MFMA pass)
+into profiles/<tag>_pmc_traffic.json (one entry per kernel of interest) + a merged per-kernel CSV.
+    python tools/pmc_traffic.py <fetch_csv> <write_csv> <tag> [<mfma_csv>]"""
 import csv, json, sys, collections
 fetch_csv, write_csv, tag = sys.argv[1:4]
+mfma_csv = sys.argv[4] if len(sys.argv) > 4 else None
+
 def per_kernel(path, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
@@ -10,26 +13,42 @@ def per_kernel(path, counter):
     out = {}
     for k, v in acc.items():
         big = [x for x in v if x > 0.5 * max(v)] or v   # launches behind the device's `done` flag exit at once: not samples
-        out[k] = (sum(big) / len(big), len(big))
+        out[k] = (sum(big) / len(big), len(big), sum(v), len(v))
     return out
+
 f = per_kernel(fetch_csv, "FETCH_SIZE"); w = per_kernel(write_csv, "WRITE_SIZE")
 rows = []
 for k in sorted(set(f) | set(w)):
-    rows.append((k, f.get(k, (0, 0))[1], f.get(k, (0, 0))[0], w.get(k, (0, 0))[0]))
+    rows.append((k, f.get(k, (0, 0, 0, 0))[1], f.get(k, (0, 0, 0, 0))[0], w.get(k, (0, 0, 0, 0))[0]))
 with open("profiles/%s_pmc_counters.csv" % tag, "w") as out:
     out.write("kernel,launches,FETCH_SIZE_mean_KB_raw,WRITE_SIZE_mean_KB\n")
     for k, n, fk, wk in rows: out.write('"%s",%d,%.3f,%.3f\n' % (k, n, fk, wk))
-upd = [r for r in rows if "k_bt_update_tiled" in r[0]][0]
-cal = [r for r in rows if "k_transpose_in" in r[0]]
 m, nn = 2048, 2048
-doc = {"workload": "M: 2048x4096 dense LP seed 2, pipeline blocked (K=8), T in 4x4 tiles",
-       "kernel": "k_bt_update_tiled",
-       "launches": upd[1],
-       "FETCH_SIZE_mean_KB_raw": upd[2], "WRITE_SIZE_mean_KB": upd[3],
-       "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE exact; separate --pmc passes",
-       "traffic_bytes_per_launch": (2 * upd[2] + upd[3]) * 1024.0,
-       "algorithmic_bytes_per_launch": 16.0 * m * nn}
-if cal:
-    doc["calibration"] = "k_transpose_in reads the 67.1 MB A once: FETCH_SIZE %.0f KB raw -> %.1f MB doubled" % (cal[0][2], 2 * cal[0][2] * 1024 / 1e6)
-json.dump(doc, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
-print(json.dumps(doc, indent=1))
+alg = {"k_bt_update_tiled<8>": 16.0 * m * nn, "k_bt_inner2<1024": 8 * 16.0 * (m + nn) + 24.0 * (m + nn)}
+docs = []
+for key, note in (("k_bt_update_tiled<8>", "streaming rank-8 update: 16-byte coalesced loads and stores, the calibrated shape"),
+                  ("k_bt_inner2<1024", "single-workgroup block kernel: 8-byte reads of 128-byte tile lines (one column + one row of T per pivot); FETCH_SIZE is "
+                                       "UNCALIBRATED for this shape (MI355X_MICROARCH.md: only wide coalesced reads are known to report 1/2) — the x2 figure is an upper bound"),
+                  ("k_bt_inner2_batch", "batched block kernel (C5 wave): mean over launches with 1..256 active relaxations"),
+                  ("k_bt_update_tiled_batch", "batched rank-8 update (C5 wave): mean over launches with 1..256 active relaxations")):
+    hit = [r for r in rows if key in r[0] and "batch" not in r[0].replace(key, "")] if "batch" not in key else [r for r in rows if key in r[0]]
+    if not hit:
+        continue
+    r = hit[0]
+    d = {"kernel": r[0], "launches": r[1], "FETCH_SIZE_mean_KB_raw": r[2], "WRITE_SIZE_mean_KB": r[3],
+         "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE exact; separate --pmc passes",
+         "traffic_bytes_per_launch": (2 * r[2] + r[3]) * 1024.0, "note": note}
+    if key in alg:
+        d["algorithmic_bytes_per_launch"] = alg[key]
+    docs.append(d)
+cal = [r for r in rows if "k_transpose_in" in r[0]]
+if cal and docs:
+    docs[0]["calibration"] = "k_transpose_in reads the 67.1 MB A of the metric LP once: FETCH_SIZE %.0f KB raw -> %.1f MB doubled" % (cal[0][2], 2 * cal[0][2] * 1024 / 1e6)
+if mfma_csv:
+    tot = collections.defaultdict(float)
+    for r in csv.DictReader(open(mfma_csv)):
+        tot[r["Counter_Name"]] += float(r["Counter_Value"])
+    docs.append({"kernel": "(all kernels of the run)", "mfma_counters_sum": dict(tot),
+                 "note": "no MFMA instruction is issued anywhere on the path: SQ_INSTS_MFMA = SQ_INSTS_VALU_MFMA_F64 = SQ_VALU_MFMA_BUSY_CYCLES = 0"})
+json.dump(docs, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
+print(json.dumps(docs, indent=1))
