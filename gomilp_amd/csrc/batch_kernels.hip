@@ -138,12 +138,14 @@ __global__ void k_b_gather(const BatchLP *__restrict__ lps) {
 
 // ---- the stage machine ----------------------------------------------------------------------------------------------
 // dynamic LDS: 2 * (n_max + 2) ints (flags, old positions)
-__global__ __launch_bounds__(kBlock) void k_b_ctrl(BatchLP *__restrict__ lps) {
+__global__ __launch_bounds__(kBlock) void k_b_ctrl(BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count, BatchOut *__restrict__ outs) {
     extern __shared__ __attribute__((aligned(16))) int sh_ctrl[];
     __shared__ int s_scan[kBlock];
     __shared__ double s_red[kBlock];
     __shared__ int s_added;
-    BatchLP &lp = lps[blockIdx.x];
+    if ((int)blockIdx.x >= *count) return;   // the grid is sized from an older (larger) count
+    const int li = ids[blockIdx.x];
+    BatchLP &lp = lps[li];
     const int tid = threadIdx.x;
     const int m = lp.m, n = lp.n;
     const int stage = lp.stage;
@@ -299,16 +301,24 @@ __global__ __launch_bounds__(kBlock) void k_b_ctrl(BatchLP *__restrict__ lps) {
             lp.stage = BS_P2;
         }
     }
+    __syncthreads();
+    if (tid == 0) {
+        BatchOut &o = outs[li];
+        o.stage = lp.stage; o.status = lp.status; o.wrapped = lp.wrapped; o.phase1_used = lp.phase1_used;
+        o.piv1 = lp.piv1; o.piv2 = lp.piv2; o.bland = lp.bland;
+    }
 }
 
-// the active list for the launches of the next superstep, in relaxation order (one workgroup; nlp <= 65535)
-__global__ __launch_bounds__(kBlock) void k_b_compact(const BatchLP *__restrict__ lps, int nlp, int *__restrict__ ids, int *__restrict__ count) {
+// the active list for the launches of the next superstep: the still-active members of the previous list, in order
+__global__ __launch_bounds__(kBlock) void k_b_compact(const BatchLP *__restrict__ lps, const int *__restrict__ ids_in, const int *__restrict__ count_in,
+                                                      int *__restrict__ ids, int *__restrict__ count) {
     __shared__ int s_cnt[kBlock];
     const int tid = threadIdx.x;
-    const int chunk = (nlp + kBlock - 1) / kBlock;
-    const int lo = min(nlp, tid * chunk), hi = min(nlp, lo + chunk);
+    const int nin = *count_in;
+    const int chunk = (nin + kBlock - 1) / kBlock;
+    const int lo = min(nin, tid * chunk), hi = min(nin, lo + chunk);
     int cnt = 0;
-    for (int i = lo; i < hi; i++) { const int sg = lps[i].stage; cnt += (sg != BS_DONE && sg != BS_HOST); }
+    for (int i = lo; i < hi; i++) { const int sg = lps[ids_in[i]].stage; cnt += (sg != BS_DONE && sg != BS_HOST); }
     s_cnt[tid] = cnt;
     __syncthreads();
     if (tid == 0) {
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(kBlock) void k_b_compact(const BatchLP *__restrict_
     }
     __syncthreads();
     int at = s_cnt[tid];
-    for (int i = lo; i < hi; i++) { const int sg = lps[i].stage; if (sg != BS_DONE && sg != BS_HOST) ids[at++] = i; }
+    for (int i = lo; i < hi; i++) { const int li = ids_in[i]; const int sg = lps[li].stage; if (sg != BS_DONE && sg != BS_HOST) ids[at++] = li; }
 }
 __global__ void k_b_init_ids(int *__restrict__ ids, int *__restrict__ count, int nlp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -328,8 +338,9 @@ __global__ void k_b_init_ids(int *__restrict__ ids, int *__restrict__ count, int
 
 // T_out[:, jp] = T_in[:, srcpos[jp]] (both 4x4-tiled); the control kernel already made T_out the current buffer.
 // One workgroup = 16 rows of one relaxation (a launch without work orders is nlp * m/16 empty workgroups, not m * nlp).
-__global__ __launch_bounds__(kBlock) void k_b_permute(const BatchLP *__restrict__ lps) {
-    const BatchLP &lp = lps[blockIdx.y];
+__global__ __launch_bounds__(kBlock) void k_b_permute(const BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count) {
+    if ((int)blockIdx.y >= *count) return;
+    const BatchLP &lp = lps[ids[blockIdx.y]];
     if (!lp.do_permute) return;
     const int m = lp.m, m4 = (m + 3) & ~3, ld_out = lp.bt.ldt;
     const int i0 = blockIdx.x * 16;
@@ -349,8 +360,9 @@ __global__ __launch_bounds__(kBlock) void k_b_permute(const BatchLP *__restrict_
 // k_tab_r_partial / k_tab_r_reduce (tableau_kernels.hip), so the batched and the single path see the same bits
 __host__ __device__ __forceinline__ int b_r_chunks(int m) { int c = (m + 63) / 64; return c > 64 ? 64 : c; }
 
-__global__ __launch_bounds__(kBlock) void k_b_tab_r_partial(const BatchLP *__restrict__ lps) {
-    const BatchLP &lp = lps[blockIdx.z];
+__global__ __launch_bounds__(kBlock) void k_b_tab_r_partial(const BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count) {
+    if ((int)blockIdx.z >= *count) return;
+    const BatchLP &lp = lps[ids[blockIdx.z]];
     if (!lp.do_r) return;
     const int m = lp.m, ldt = lp.bt.ldt, phase = lp.r_phase;
     const int nchunks = b_r_chunks(m), rpc = (m + nchunks - 1) / nchunks;
@@ -365,8 +377,9 @@ __global__ __launch_bounds__(kBlock) void k_b_tab_r_partial(const BatchLP *__res
     }
     lp.scratch[(size_t)chunk * ldt + j] = acc;
 }
-__global__ void k_b_tab_r_reduce(const BatchLP *__restrict__ lps) {
-    const BatchLP &lp = lps[blockIdx.z];
+__global__ void k_b_tab_r_reduce(const BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count) {
+    if ((int)blockIdx.z >= *count) return;
+    const BatchLP &lp = lps[ids[blockIdx.z]];
     if (!lp.do_r) return;
     const int ldt = lp.bt.ldt, nn = lp.bt.nn, phase = lp.r_phase;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -385,22 +398,23 @@ void launch_b_gather(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStr
     dim3 grid(((m_max + 3) / 4 * 4 + 31) / 32, (ldt_max + 31) / 32, nlp), block(32, 8);
     hipLaunchKernelGGL(k_b_gather, grid, block, 0, s, lps);
 }
-void launch_b_ctrl(BatchLP *lps, int nlp, int n_max, int *ids_out, int *active_slot, hipStream_t s) {
+// ids_in / count_in: the active list the previous control step left (everybody at the start); bound >= *count_in on the host
+void launch_b_ctrl(BatchLP *lps, const int *ids_in, const int *count_in, int bound, int n_max, BatchOut *outs, int *ids_out, int *count_out, hipStream_t s) {
     const size_t lds = (size_t)2 * (n_max + 2) * sizeof(int);
-    hipLaunchKernelGGL(k_b_ctrl, dim3(nlp), dim3(kBlock), lds, s, lps);
-    hipLaunchKernelGGL(k_b_compact, dim3(1), dim3(kBlock), 0, s, lps, nlp, ids_out, active_slot);
+    hipLaunchKernelGGL(k_b_ctrl, dim3(bound), dim3(kBlock), lds, s, lps, ids_in, count_in, outs);
+    hipLaunchKernelGGL(k_b_compact, dim3(1), dim3(kBlock), 0, s, lps, ids_in, count_in, ids_out, count_out);
 }
 void launch_b_init_ids(int *ids, int *count, int nlp, hipStream_t s) {
     hipLaunchKernelGGL(k_b_init_ids, dim3((nlp + 255) / 256), dim3(256), 0, s, ids, count, nlp);
 }
-void launch_b_permute(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s) {
-    dim3 grid(((m_max + 3) / 4 * 4 + 15) / 16, nlp);
-    hipLaunchKernelGGL(k_b_permute, grid, dim3(kBlock), 0, s, lps);
+void launch_b_permute(const BatchLP *lps, const int *ids, const int *count, int bound, int m_max, int ldt_max, hipStream_t s) {
+    dim3 grid(((m_max + 3) / 4 * 4 + 15) / 16, bound);
+    hipLaunchKernelGGL(k_b_permute, grid, dim3(kBlock), 0, s, lps, ids, count);
 }
-void launch_b_tab_r(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s) {
-    dim3 grid((ldt_max + kBlock - 1) / kBlock, b_r_chunks(m_max), nlp);
-    hipLaunchKernelGGL(k_b_tab_r_partial, grid, dim3(kBlock), 0, s, lps);
-    hipLaunchKernelGGL(k_b_tab_r_reduce, dim3((ldt_max + 255) / 256, 1, nlp), dim3(256), 0, s, lps);
+void launch_b_tab_r(const BatchLP *lps, const int *ids, const int *count, int bound, int m_max, int ldt_max, hipStream_t s) {
+    dim3 grid((ldt_max + kBlock - 1) / kBlock, b_r_chunks(m_max), bound);
+    hipLaunchKernelGGL(k_b_tab_r_partial, grid, dim3(kBlock), 0, s, lps, ids, count);
+    hipLaunchKernelGGL(k_b_tab_r_reduce, dim3((ldt_max + 255) / 256, 1, bound), dim3(256), 0, s, lps, ids, count);
 }
 
 }  // namespace gomilp

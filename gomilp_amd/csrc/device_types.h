@@ -170,6 +170,12 @@ struct BatchLP {
     int64_t piv1, piv2, bland;
 };
 
+// What the host needs to see of a relaxation after every control step (one small D2H copy per superstep for the whole wave)
+struct BatchOut {
+    int32_t stage, status, wrapped, phase1_used;
+    int64_t piv1, piv2, bland;
+};
+
 // Control block of the compressed LU schedule (lu_compressed.hip): written by the panel kernel of a round, read by the
 // U-solve / trailing kernels of the same round and by the host between batches of rounds.
 struct LUCtl {

@@ -185,10 +185,10 @@ const char *bt_batch_kernel_name(int m_max, int ldt_max);
 int batch_ldt(int nn);
 void launch_b_setup(BatchLP *lps, int nlp, hipStream_t s);
 void launch_b_gather(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s);
-void launch_b_ctrl(BatchLP *lps, int nlp, int n_max, int *ids_out, int *active_slot, hipStream_t s);
+void launch_b_ctrl(BatchLP *lps, const int *ids_in, const int *count_in, int bound, int n_max, BatchOut *outs, int *ids_out, int *count_out, hipStream_t s);
 void launch_b_init_ids(int *ids, int *count, int nlp, hipStream_t s);
-void launch_b_permute(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s);
-void launch_b_tab_r(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s);
+void launch_b_permute(const BatchLP *lps, const int *ids, const int *count, int bound, int m_max, int ldt_max, hipStream_t s);
+void launch_b_tab_r(const BatchLP *lps, const int *ids, const int *count, int bound, int m_max, int ldt_max, hipStream_t s);
 void launch_transpose_in(const double *A, int64_t lda, int m, int n, double *At, int ld, hipStream_t s);
 void launch_col_stats(const double *At, int ld, int m, int n, int32_t *nnz, int32_t *lastrow, int32_t *allone,
                       int32_t *rowflag, hipStream_t s);

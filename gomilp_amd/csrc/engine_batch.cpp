@@ -32,7 +32,8 @@ struct BatchEngine::Buf {
     int cap_lp = 0, cap_m4 = 0, cap_ldt = 0, cap_ldu = 0, cap_n = 0;
     int64_t cap_k = 0;
     BatchLP *d_lps = nullptr, *h_lps = nullptr;            // device array, pinned build area
-    BatchLP *h_snap[kRing] = {nullptr, nullptr};           // pinned snapshots of the device array, one per superstep in flight
+    BatchOut *d_out = nullptr;                             // per relaxation: what the host needs to see (written by the control kernel)
+    BatchOut *h_snap[kRing] = {nullptr, nullptr};          // pinned snapshots of d_out, one per superstep in flight
     int *h_active[kRing] = {nullptr, nullptr};
     hipEvent_t ev[kRing] = {nullptr, nullptr};
     double *d_T = nullptr, *d_R = nullptr, *d_xb = nullptr, *d_U = nullptr, *d_V = nullptr, *d_scratch = nullptr, *d_art = nullptr;
@@ -51,12 +52,12 @@ struct BatchEngine::Buf {
 
     void free_lp_buffers() {
         for (void *p : {(void *)d_lps, (void *)d_T, (void *)d_R, (void *)d_xb, (void *)d_U, (void *)d_V, (void *)d_scratch, (void *)d_art,
-                        (void *)d_basic, (void *)d_nonbasic, (void *)d_srcpos, (void *)d_st, (void *)d_ids[0], (void *)d_ids[1]})
+                        (void *)d_basic, (void *)d_nonbasic, (void *)d_srcpos, (void *)d_st, (void *)d_ids[0], (void *)d_ids[1], (void *)d_out})
             if (p) hipFree(p);
-        d_lps = nullptr; d_T = d_R = d_xb = d_U = d_V = d_scratch = d_art = nullptr; d_basic = d_nonbasic = d_srcpos = nullptr; d_st = nullptr; d_ids[0] = d_ids[1] = nullptr;
+        d_lps = nullptr; d_T = d_R = d_xb = d_U = d_V = d_scratch = d_art = nullptr; d_basic = d_nonbasic = d_srcpos = nullptr; d_st = nullptr; d_ids[0] = d_ids[1] = nullptr; d_out = nullptr;
         for (void *p : {(void *)h_lps, (void *)h_snap[0], (void *)h_snap[1], (void *)h_basic, (void *)h_xb})
             if (p) hipHostFree(p);
-        h_lps = h_snap[0] = h_snap[1] = nullptr; h_basic = nullptr; h_xb = nullptr;
+        h_lps = nullptr; h_snap[0] = h_snap[1] = nullptr; h_basic = nullptr; h_xb = nullptr;
         cap_lp = cap_m4 = cap_ldt = cap_ldu = cap_n = 0;
     }
     void free_all() {
@@ -117,6 +118,7 @@ int BatchEngine::ensure(int nlp, int m_max, int n_max, int ldt1, int64_t ktot) {
         b.free_lp_buffers();
         const size_t L = (size_t)clp;
         B_TRY(bmalloc(&b.d_lps, L));
+        B_TRY(bmalloc(&b.d_out, L));
         B_TRY(bhost(&b.h_lps, L));
         for (int r = 0; r < kRing; r++) B_TRY(bhost(&b.h_snap[r], L));
         B_TRY(bmalloc(&b.d_T, L * 2 * (size_t)cm4 * cldt));
@@ -211,6 +213,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         lp.tol_user = tol; lp.kblock = kBlockK; lp.stage = BS_HOST;
     }
     B_TRY(hipMemsetAsync(b.d_active, 0, kMaxSteps * sizeof(int), stream_));
+    B_TRY(hipMemsetAsync(b.d_out, 0, (size_t)nlp * sizeof(BatchOut), stream_));   // stage 0 = not terminal
     B_TRY(hipMemcpyAsync(b.d_lps, b.h_lps, (size_t)nlp * sizeof(BatchLP), hipMemcpyHostToDevice, stream_));
     if (ktot) {
         B_TRY(hipMemcpyAsync(b.d_var, b.h_var, (size_t)ktot * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
@@ -223,7 +226,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
     int bound = nlp;   // upper bound of the active relaxations the host knows (from the last snapshot it has seen)
     launch_b_init_ids(b.d_ids[1], b.d_active + (kMaxSteps - 1), nlp, stream_);   // list of "superstep -1": everybody
     auto snapshot = [&](int slot) -> int {
-        B_TRY(hipMemcpyAsync(b.h_snap[slot], b.d_lps, (size_t)nlp * sizeof(BatchLP), hipMemcpyDeviceToHost, stream_));
+        B_TRY(hipMemcpyAsync(b.h_snap[slot], b.d_out, (size_t)nlp * sizeof(BatchOut), hipMemcpyDeviceToHost, stream_));
         B_TRY(hipMemcpyAsync(b.h_active[slot], b.d_active + step, sizeof(int), hipMemcpyDeviceToHost, stream_));
         B_TRY(hipEventRecord(b.ev[slot], stream_));
         return GOMILP_OK;
@@ -243,10 +246,13 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         }
         S.launches += 2 * nb; S.blocks += nb;
     };
+    // the control step of superstep `step` visits the relaxations of the previous active list and leaves the next one
     auto control = [&](bool permute) {
-        launch_b_ctrl(b.d_lps, nlp, n_max, b.d_ids[step & 1], b.d_active + step, stream_);
-        if (permute) launch_b_permute(b.d_lps, nlp, m_max, ldt1, stream_);
-        launch_b_tab_r(b.d_lps, nlp, m_max, ldt1, stream_);
+        const int *ids = b.d_ids[(step + 1) & 1];
+        const int *cnt = step == 0 ? b.d_active + (kMaxSteps - 1) : b.d_active + (step - 1);
+        launch_b_ctrl(b.d_lps, ids, cnt, bound, n_max, b.d_out, b.d_ids[step & 1], b.d_active + step, stream_);
+        if (permute) launch_b_permute(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_);
+        launch_b_tab_r(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_);
         S.launches += permute ? 5 : 4;
     };
     // ---- prologue: set-up, T, the forced Phase-I pivots, first reduced costs
@@ -275,16 +281,17 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
     auto harvest = [&](int slot) -> int {   // look at a completed snapshot
         for (int i = 0; i < nlp; i++) {
             if (reported[i]) continue;
-            const BatchLP &lp = b.h_snap[slot][i];
+            const BatchOut &lp = b.h_snap[slot][i];
             if (lp.stage != BS_DONE && lp.stage != BS_HOST) continue;
+            const int m_i = b.h_lps[i].m;
             reported[i] = 1;
             Outcome o;
             o.stage = lp.stage; o.status = lp.status; o.wrapped = lp.wrapped; o.phase1_used = lp.phase1_used;
             o.piv1 = lp.piv1; o.piv2 = lp.piv2; o.bland = lp.bland;
             if (lp.stage == BS_DONE && (lp.status == GOMILP_OK || lp.status == GOMILP_ERR_BLAND)) {
                 // terminal relaxations are never written again: their basis / x_B can leave on the second stream at once
-                B_TRY(hipMemcpyAsync(b.h_basic + (size_t)i * b.cap_ldu, b.d_basic + (size_t)i * b.cap_ldu, (size_t)lp.m * sizeof(int32_t), hipMemcpyDeviceToHost, copy_stream_));
-                B_TRY(hipMemcpyAsync(b.h_xb + (size_t)i * b.cap_ldu, b.d_xb + (size_t)i * b.cap_ldu, (size_t)lp.m * sizeof(double), hipMemcpyDeviceToHost, copy_stream_));
+                B_TRY(hipMemcpyAsync(b.h_basic + (size_t)i * b.cap_ldu, b.d_basic + (size_t)i * b.cap_ldu, (size_t)m_i * sizeof(int32_t), hipMemcpyDeviceToHost, copy_stream_));
+                B_TRY(hipMemcpyAsync(b.h_xb + (size_t)i * b.cap_ldu, b.d_xb + (size_t)i * b.cap_ldu, (size_t)m_i * sizeof(double), hipMemcpyDeviceToHost, copy_stream_));
                 B_TRY(hipEventRecord(b.lp_ev[i], copy_stream_));
                 pending.push_back({i, o});
             } else {
@@ -298,7 +305,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         const int prev_slot = step % kRing;
         const bool last_possible = step + 1 >= kMaxSteps - 2;
         // enqueue superstep step + 1 before waiting for the snapshot of superstep `step`: the GPU never idles for the host
-        const int nb = step < 2 ? 1 : (step < 4 ? 2 : 4);
+        const int nb = step < 2 ? 1 : (step < 4 ? 2 : (step < 8 ? 4 : 8));
         step++;
         blocks(nb);
         control(true);
