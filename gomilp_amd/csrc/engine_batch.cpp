@@ -99,7 +99,13 @@ bool BatchEngine::eligible(const Engine::RootView &R, int K_max, bool phase1) co
 
 int BatchEngine::ensure(int nlp, int m_max, int n_max, int ldt1, int64_t ktot) {
     B_TRY(hipSetDevice(device_));
-    if (!stream_) B_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    if (!stream_) {
+        // a hardware queue of its own: streams of one priority share a small round-robin pool of queues (4 per process), and a
+        // worker's final-solve launches that land in the schedule's queue would wait behind a whole superstep every time
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) B_TRY(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
+        else B_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    }
     if (!copy_stream_) B_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
     Buf &b = *b_;
     if (!b.d_active) {
