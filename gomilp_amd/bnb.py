@@ -76,7 +76,8 @@ def max_fun_branch_point(c, integrality) -> int:
     return cur
 
 
-def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int = 8, device: int = -1) -> Result:
+def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int = 8, device: int = -1,
+               warm_start: bool = False) -> Result:
     """milpProblem.solve (ilp.go:75-116) with every relaxation on the GPU.  `max_nodes` stands in for the context
     deadline of the reference (its tree does not terminate on many inputs: SURVEY.md §3.4)."""
     c = np.asarray(c, dtype=np.float64)
@@ -91,19 +92,21 @@ def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int
     out = Result(None, None, math.nan)
     root = Node(0, 0, [])
     out.nodes.append(root)
-    ctx = lp.Context(device=device)
-    try:
-        r = ctx.upload(c0, A0, b0).solve(0.0)            # subproblem.go:172
-    finally:
-        ctx.close()
+    pool = lp.FrontierPool(device=device, workers=workers)
+    pool.set_root(c0, A0, b0)
+    if warm_start:
+        pool.set("warm_start", 1)   # opt-in: children start from the root's optimal basis (dual simplex), not the reference's path
+    r = pool.solve_root(0.0)                             # subproblem.go:172
     root.status, root.z, root.x = r.status, r.z, r.x
     out.relaxations, out.pivots = 1, r.stats["pivots_phase1"] + r.stats["pivots_phase2"]
     if r.status != lp.OK:
         out.error = "panic:" + lp.STATUS_NAMES.get(r.status, str(r.status))   # subproblem.go:173-176
+        pool.close()
         return out
     if feasible_for_ip(int0, r.x):
         root.decision = "INITIAL_RX_FEASIBLE_FOR_IP"
         out.x, out.z = r.x[: len(c)].copy(), r.z
+        pool.close()
         return out
     incumbent: Optional[Node] = None
     queue: List[Node] = []
@@ -141,10 +144,9 @@ def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int
     err = check(root)
     if err:
         out.error = err
+        pool.close()
         return out
-    pool = lp.FrontierPool(device=device, workers=workers)
     try:
-        pool.set_root(c0, A0, b0)
         solved = 0
         while queue:
             budget = max_nodes - solved

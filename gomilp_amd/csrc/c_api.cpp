@@ -36,6 +36,8 @@ struct gomilp_pool {
     std::vector<int64_t> root;  // root problem id inside each engine
     int64_t m0 = 0, n0 = 0;
     int batched = 1;            // knob: 0 = every relaxation through a worker's single-relaxation engine (round-1 path)
+    int warm_start = 0;         // knob: 1 = children start from the solved root's optimal basis (gomilp_pool_solve_root), dual simplex
+    Engine::RootOpt opt;        // final state of the root after gomilp_pool_solve_root
     std::unique_ptr<BatchEngine> batch;
     Engine::RootView view;      // of eng[0]'s root (all workers hold the same data)
     // further roots (gomilp_pool_add_root): resident in worker 0's engine only, read in place by the others
@@ -78,6 +80,7 @@ struct gomilp_pool {
         cv_idle.wait(lk, [&] { return queue.empty() && busy == 0; });
     }
     ~gomilp_pool() {
+        Engine::free_optimum(&opt);
         { std::lock_guard<std::mutex> lk(mu); stop = true; }
         cv.notify_all();
         for (auto &t : threads) t.join();
@@ -145,6 +148,7 @@ int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value) {
     if (!pool || !key) return GOMILP_ERR_BAD_SHAPE;
     std::lock_guard<std::mutex> g(pool->call_mu);
     if (std::string(key) == "batched") { pool->batched = value ? 1 : 0; return GOMILP_OK; }
+    if (std::string(key) == "warm_start") { pool->warm_start = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "sample_batch") { pool->batch->set_sampling(value != 0); return GOMILP_OK; }
     int rc = GOMILP_OK;
     for (auto &e : pool->eng) { const int r = e->set(key, value); if (r != GOMILP_OK) rc = r; }
@@ -157,6 +161,7 @@ int gomilp_pool_set_root(gomilp_pool *pool, const double *c0, const double *A0, 
     std::lock_guard<std::mutex> g(pool->call_mu);
     for (auto id : pool->extra_root) pool->eng[0]->free_problem(id);
     pool->extra_root.clear(); pool->extra_view.clear();
+    Engine::free_optimum(&pool->opt);
     for (size_t w = 0; w < pool->eng.size(); w++) {
         if (pool->root[w] >= 0) pool->eng[w]->free_problem(pool->root[w]);
         int64_t id = pool->eng[w]->upload(c0, A0, lda, b0, m0, n0);
@@ -272,7 +277,8 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
     bool any_p1 = false;
     for (int r = 0; r < nroots && !any_p1; r++) for (double v : views[r]->hb) if (v < -1e-13) { any_p1 = true; break; }
     for (int64_t k = koff[0]; k < koff[count] && !any_p1; k++) if (rhs[k] < -1e-13) any_p1 = true;
-    for (int r = 0; r < nroots && use_batch; r++) use_batch = pool->batch->eligible(*views[r], K_max, any_p1);
+    const Engine::RootOpt *warm = (pool->warm_start && pool->opt.valid && nroots == 1) ? &pool->opt : nullptr;
+    for (int r = 0; r < nroots && use_batch; r++) use_batch = pool->batch->eligible(*views[r], K_max, any_p1 && !warm);
     if (use_batch) {
         std::mutex agg_mu;
         auto on_done_at = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) {
@@ -293,7 +299,7 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
             }
         };
         auto on_done = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) { on_done_at(i, o, basic, xb); };
-        const int rc = pool->batch->run_roots(views.data(), nroots, root_of, count, koff, var, sign, rhs, tol, on_done, &bs);
+        const int rc = pool->batch->run_roots(views.data(), nroots, root_of, count, koff, var, sign, rhs, tol, on_done, &bs, warm);
         pool->drain();
         if (rc != GOMILP_OK) return rc;
     } else {
@@ -322,6 +328,17 @@ int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff,
                           int32_t *has_x_out, gomilp_frontier_stats *stats) {
     if (!pool) return GOMILP_ERR_BAD_SHAPE;
     return gomilp_frontier_solve_roots(pool, count, nullptr, koff, var, sign, rhs, tol, z_out, x_out, pool->n0, status_out, has_x_out, stats);
+}
+
+// The root relaxation (subproblem.go:172) on the pool's first worker; its final tableau, reduced costs, x_B and lists are
+// kept as the warm-start point of the children (used when the knob "warm_start" is 1).
+int gomilp_pool_solve_root(gomilp_pool *pool, double tol, double *opt_f, double *opt_x, int32_t *has_x, gomilp_lp_stats *stats) {
+    if (!pool || pool->root[0] < 0) return GOMILP_ERR_BAD_SHAPE;
+    std::lock_guard<std::mutex> g(pool->call_mu);
+    Engine::free_optimum(&pool->opt);
+    const int rc = pool->eng[0]->solve(pool->root[0], tol, nullptr, opt_f, opt_x, has_x, nullptr, stats);
+    if (rc == GOMILP_OK) pool->eng[0]->export_optimum(pool->root[0], &pool->opt);   // (not valid on another pipeline: the children start cold)
+    return rc;
 }
 
 int gomilp_pool_add_root(gomilp_pool *pool, const double *c, const double *A, int64_t lda, const double *b, int64_t m, int64_t n) {

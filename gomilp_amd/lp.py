@@ -57,7 +57,7 @@ class FrontierStats(C.Structure):
 
 
 EXPORTS = [
-    "gomilp_lp_upload_child", "gomilp_pool_create", "gomilp_pool_destroy", "gomilp_pool_set", "gomilp_pool_set_root", "gomilp_frontier_solve", "gomilp_pool_add_root", "gomilp_frontier_solve_roots",
+    "gomilp_lp_upload_child", "gomilp_pool_create", "gomilp_pool_destroy", "gomilp_pool_set", "gomilp_pool_set_root", "gomilp_frontier_solve", "gomilp_pool_add_root", "gomilp_frontier_solve_roots", "gomilp_pool_solve_root",
     "gomilp_lp_simplex", "gomilp_ctx_create", "gomilp_ctx_destroy", "gomilp_ctx_device", "gomilp_ctx_set",
     "gomilp_lp_upload", "gomilp_lp_free", "gomilp_lp_solve_resident", "gomilp_lp_last_trace", "gomilp_version",
     "gomilp_device_count", "gomilp_compiled_arch", "gomilp_comm_unique_id", "gomilp_comm_create", "gomilp_comm_destroy",
@@ -102,6 +102,7 @@ def lib():
     L.gomilp_pool_set_root.argtypes = [C.c_void_p, dp, dp, C.c_int64, dp, C.c_int64, C.c_int64]
     L.gomilp_frontier_solve.argtypes = [C.c_void_p, C.c_int64, ip, i32p, dp, dp, C.c_double, dp, dp, i32p, i32p,
                                         C.POINTER(FrontierStats)]
+    L.gomilp_pool_solve_root.argtypes = [C.c_void_p, C.c_double, dp, dp, i32p, C.POINTER(Stats)]
     L.gomilp_pool_add_root.argtypes = [C.c_void_p, dp, dp, C.c_int64, dp, C.c_int64, C.c_int64]
     L.gomilp_frontier_solve_roots.argtypes = [C.c_void_p, C.c_int64, i32p, ip, i32p, dp, dp, C.c_double, dp, dp, C.c_int64, i32p, i32p,
                                               C.POINTER(FrontierStats)]
@@ -296,6 +297,16 @@ class FrontierPool:
             raise RuntimeError("gomilp_pool_set_root failed: %s" % STATUS_NAMES.get(rc, rc))
         self.m0, self.n0 = m0, n0
         self._widths = [n0]
+
+    def solve_root(self, tol: float = 0.0) -> LPResult:
+        """The root relaxation on the pool's first worker; keeps its optimal tableau as the warm-start point
+        (used by solve() when the pool knob warm_start is 1)."""
+        x = np.zeros(self.n0)
+        z = C.c_double(math.nan)
+        has_x = C.c_int32(0)
+        st = Stats()
+        rc = lib().gomilp_pool_solve_root(self._h, float(tol), C.byref(z), _dp(x), C.byref(has_x), C.byref(st))
+        return LPResult(rc, z.value, x if has_x.value else None, None, _stats_dict(st))
 
     def add_root(self, c, A, b) -> int:
         """Another root in the same pool (resident once, on the pool's first worker): returns its index (>= 1)."""

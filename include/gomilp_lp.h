@@ -195,6 +195,13 @@ int gomilp_incumbent_allreduce(gomilp_comm *comm, double local_z, int64_t local_
 /* the host logic of the exchange (no GPU): lexicographic minimum of a table of `world` (z, index) pairs, +Inf = none */
 void gomilp_incumbent_pick(const double *table, int world, double *global_z, int64_t *global_index);
 
+/* Warm start (opt-in; the reference's hook is initialBasic, simplex.go:147-161, its README lists "initiate the
+ * simplex at solution of parent?" as a TODO): gomilp_pool_solve_root solves the root relaxation (subproblem.go:172) and keeps its
+ * optimal tableau resident; with gomilp_pool_set(pool, "warm_start", 1) every child of that root then starts from the root's
+ * optimal basis + its own branch slacks and restores feasibility with the dual simplex (a few pivots instead of a Phase I).
+ * This mode does not follow the reference's pivot path: z and every branching decision agree, x / z bits need not. */
+int gomilp_pool_solve_root(gomilp_pool *pool, double tol, double *opt_f, double *opt_x, int32_t *has_x, gomilp_lp_stats *stats);
+
 /* Several roots in one pool: relaxation i of a wave is a child (K_i >= 0 rows) of root root_of[i]; index 0 is the root of
  * gomilp_pool_set_root, gomilp_pool_add_root returns 1, 2, ... (or -(gomilp_status)).  Independent LPs of similar shape
  * are children with K = 0 of different roots: they advance together through the device-batched schedule (one launch per
