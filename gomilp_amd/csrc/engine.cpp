@@ -50,6 +50,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "bt_nt") { if (v != 0 && v != 256 && v != 512 && v != 1024) return GOMILP_ERR_BAD_SHAPE; bt_nt_ = v; }
     else if (key == "bt_old") bt_old_ = v ? 1 : 0;
     else if (key == "bt_stamps") bt_stamps_ = v ? 1 : 0;
+    else if (key == "cond_guard") cond_guard_ = v ? 1 : 0;
     else if (key == "block_k") { if (v < 0 || v > bt_max_k()) return GOMILP_ERR_BAD_SHAPE; block_k_ = v; }
     else return GOMILP_ERR_BAD_SHAPE;
     return GOMILP_OK;
@@ -941,6 +942,11 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
         if ((rc = final_solve(P, n, xb_exact, &singular)) != GOMILP_OK) return finish(rc);
         st->seconds_final_solve = now_s() - t1;
         if (singular) return finish(GOMILP_ERR_SINGULAR);
+        if (cond_guard_ && !P.hA.empty() && n <= 1024) {   // cond > 1e16 is a Condition too: lp.ErrSingular (simplex.go:109-112)
+            st->cond_fallbacks++;
+            const double kinf = general_cond_inf(P.hA, n);
+            if (kinf > 1e16 || kinf != kinf) return finish(GOMILP_ERR_SINGULAR);
+        }
         for (int j = 0; j < n; j++)
             if (xb_exact[j] < 0) return finish(GOMILP_ERR_INFEASIBLE);
         *opt_f = dot_unitary(xb_exact.data(), P.hc.data(), n);
@@ -998,6 +1004,9 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
         else { xb = xb_exact; for (int pos = 0; pos < m; pos++) if (xb[pos] < -1e-13) feasible = false; }
         if (initial_basic && !feasible) return finish(GOMILP_ERR_PANIC);  // initializeFromBasic errors panic (:156-158)
     }
+    // small bases starting feasible: record the pivots for the host replay of the reference's condition guards
+    shadow_trace_ = cond_guard_ && use_tab && feasible && m <= 64 && !initial_basic && ensure_host_A(P);
+    const std::vector<int32_t> basic_start = basic;
     cur_ = 0;
     if (unit_basis && !use_tab) {
         HIP_TRY(hipMemsetAsync(w.binv[0], 0, (size_t)m * P.ld * sizeof(double), stream_));
@@ -1150,13 +1159,47 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
     loop_rc = run_loop(P, 2, tol, (int)nonbasic.size(), P.dc, st);
     }  // revised-simplex pipelines
     if (loop_rc == GOMILP_ERR_DEVICE) return finish(loop_rc);
-    if (loop_rc == GOMILP_ERR_UNBOUNDED) { *opt_f = -inf; return finish(loop_rc); }  // :261-263, :272-274
+    const bool loop_unbounded = loop_rc == GOMILP_ERR_UNBOUNDED;   // :261-263, :272-274 — after the condition guards below
+    if (loop_unbounded && !shadow_trace_) { *opt_f = -inf; return finish(loop_rc); }
 
     // ---- epilogue (simplex.go:296-301): x_B from a fresh gonum-order solve on the final basis ----
     HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(w.h_vec, w.xb, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(sync_stream());
     for (int i = 0; i < m; i++) { basic[i] = w.h_idx[i]; xb[i] = w.h_vec[i]; }
+    if (shadow_trace_ && (loop_rc == GOMILP_OK || loop_rc == GOMILP_ERR_BLAND || loop_unbounded)) {
+        // ---- the reference's LU.Solve guards (mat/lu.go:301,321), replayed on the host with exact condition numbers
+        HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(sync_stream());
+        const int64_t cnt = std::min<int64_t>(w.st_host->trace_len, w.trace_cap);
+        std::vector<DevPivot> tr((size_t)cnt);
+        if (cnt) HIP_TRY(hipMemcpy(tr.data(), w.trace, (size_t)cnt * sizeof(DevPivot), hipMemcpyDeviceToHost));
+        std::vector<std::pair<int, int>> piv;
+        for (auto &e : tr) piv.emplace_back((int)e.replace, (int)e.entering);
+        std::vector<int32_t> bas = basic_start;
+        int cst = GOMILP_OK;
+        int64_t evals = 0;
+        const int stop = general_condition_replay(P.hA, m, n, bas, piv, loop_unbounded, &cst, &evals);
+        st->cond_fallbacks += evals;
+        if (cst != GOMILP_OK) {
+            // the reference left its loop here with the point of that basis (simplex.go:296-301)
+            std::vector<double> xs;
+            if (general_solve_basis(P.hA, m, n, bas, P.hb, xs)) {
+                std::vector<double> cb(m);
+                for (int i = 0; i < m; i++) cb[i] = P.hc[bas[i]];
+                *opt_f = dot_unitary(cb.data(), xs.data(), m);
+                for (int j = 0; j < n; j++) opt_x[j] = 0;
+                for (int i = 0; i < m; i++) opt_x[bas[i]] = xs[i];
+                *has_x = 1;
+                if (basis_out) for (int i = 0; i < m; i++) basis_out[i] = bas[i];
+                st->pivots_phase2 = stop;
+                shadow_trace_ = false;
+                return finish(cst);
+            }
+        }
+    }
+    shadow_trace_ = false;
+    if (loop_unbounded) { *opt_f = -inf; return finish(loop_rc); }
     rc = epilogue(P, basic, xb, loop_rc, opt_f, opt_x, has_x, basis_out, st);
     if (rc == GOMILP_ERR_DEVICE) return finish(rc);
     if (rc == GOMILP_OK && use_tab && use_bt_) { last_solved_ = id; last_nn_ = n - m; }

@@ -133,7 +133,9 @@ class Engine {
     std::unique_ptr<Work> w_;
     // knobs
     int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 2, tableau_ = 1, blocked_ = 1, block_k_ = 0,  // block_k_ 0 = auto
-            bt_nt_ = 0, bt_old_ = 0, bt_stamps_ = 0;   // developer knobs of the block kernels (per context: tests force the 1024-thread instance)
+            bt_nt_ = 0, bt_old_ = 0, bt_stamps_ = 0,
+            cond_guard_ = 1;   // replay the condition guards of the reference on the host for bases of up to 64 rows
+    bool shadow_trace_ = false;   // this solve records its pivots for the replay even when the caller did not ask for a trace   // developer knobs of the block kernels (per context: tests force the 1024-thread instance)
     // per-solve state
     int cur_ = 0;   // which Binv buffer is current
     int ycur_ = 0;  // which y buffer is current
@@ -154,6 +156,11 @@ class Engine {
 int general_find_linearly_independent(const std::vector<double> &A, int m, int n, std::vector<int32_t> &idxs);
 bool general_basis_inverse(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, int ncols_with_art,
                            const std::vector<double> &art, std::vector<double> &binv);
+
+int general_condition_replay(const std::vector<double> &A, int m, int n, std::vector<int32_t> &basic, const std::vector<std::pair<int, int>> &pivots,
+                             bool ended_in_compute_move, int *status_out, int64_t *evaluations);
+double general_cond_inf(const std::vector<double> &A, int n);
+bool general_solve_basis(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, const std::vector<double> &b, std::vector<double> &x);
 
 int device_count();
 const char *compiled_arch();

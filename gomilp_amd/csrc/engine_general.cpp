@@ -119,4 +119,68 @@ bool general_basis_inverse(const std::vector<double> &A, int m, int n, const std
     return invert(B, m, binv);
 }
 
+// ---- condition guards of gonum's LU.Solve (mat/lu.go:301,321) for SMALL bases, by replaying the pivot sequence on the host
+// The reference factorises the basis three times per pivot and leaves its loop with the current point when a solve reports
+// mat.Condition (cond > 1e16 or Det() == 0: simplex.go:236-239, :289-292) or lp.ErrLinSolve (computeMove, :316-318).  The
+// device loop never forms those factorizations; for bases of up to 64 rows the host re-walks the recorded pivots with the EXACT
+// condition numbers (kappa_1 for the solve with ab^T, kappa_inf for the two solves with ab — the Hager / Higham estimate the
+// reference uses is a lower bound within a small factor of these) and reports where the reference would have
+// stopped.  Returns the number of pivots the reference would have performed (== npiv: no guard fired) and, when a guard
+// fired, the status and the basis whose x_B the reference returns.
+static double norm_inf(const std::vector<double> &M, int n) {
+    double best = 0;
+    for (int i = 0; i < n; i++) {
+        double s2 = 0;
+        for (int j = 0; j < n; j++) s2 += fabs(M[(size_t)i * n + j]);
+        if (s2 != s2) return s2;
+        best = std::max(best, s2);
+    }
+    return best;
+}
+static void basis_matrix(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, std::vector<double> &B) {
+    B.resize((size_t)m * m);
+    for (int i = 0; i < m; i++) for (int p = 0; p < m; p++) B[(size_t)i * m + p] = A[(size_t)i * n + basic[p]];
+}
+int general_condition_replay(const std::vector<double> &A, int m, int n, std::vector<int32_t> &basic, const std::vector<std::pair<int, int>> &pivots,
+                             bool ended_in_compute_move, int *status_out, int64_t *evaluations) {
+    *status_out = GOMILP_OK;
+    std::vector<double> B, inv;
+    const double lim = 1e16;   // mat.ConditionTolerance (mat/errors.go:33)
+    auto conds = [&](double &k1, double &kinf) {
+        basis_matrix(A, m, n, basic, B);
+        (*evaluations)++;
+        if (!invert(B, m, inv)) { k1 = kinf = std::numeric_limits<double>::infinity(); return; }
+        k1 = norm1(B, m, m, m) * norm1(inv, m, m, m);
+        kinf = norm_inf(B, m) * norm_inf(inv, m);
+    };
+    double k1, kinf;
+    conds(k1, kinf);
+    for (size_t t = 0;; t++) {
+        if (k1 > lim || k1 != k1) { *status_out = GOMILP_ERR_CONDITION; return (int)t; }          // duals: SolveVec(ab^T, cb), :236-239
+        if (t == pivots.size() && !ended_in_compute_move) return (int)t;                          // (the optimality test ended the loop)
+        if (kinf > lim || kinf != kinf) { *status_out = GOMILP_ERR_LINSOLVE; return (int)t; }     // computeMove, :316-318 (before its unbounded test)
+        if (t == pivots.size()) return (int)t;
+        basic[pivots[t].first] = pivots[t].second;                                                // the swap of :280
+        conds(k1, kinf);
+        if (kinf > lim || kinf != kinf) { *status_out = GOMILP_ERR_CONDITION; return (int)t + 1; } // x_B of the new basis, :289-292
+    }
+}
+
+// exact kappa_inf of a square matrix (m == n path: any Condition of the single solve becomes lp.ErrSingular, simplex.go:109-112)
+double general_cond_inf(const std::vector<double> &A, int n) {
+    std::vector<double> inv;
+    if (!invert(A, n, inv)) return std::numeric_limits<double>::infinity();
+    return norm_inf(A, n) * norm_inf(inv, n);
+}
+
+// plain LU solve B x = b for the point the reference returns with a mid-loop error (small bases)
+bool general_solve_basis(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, const std::vector<double> &b, std::vector<double> &x) {
+    std::vector<double> B, inv;
+    basis_matrix(A, m, n, basic, B);
+    if (!invert(B, m, inv)) return false;
+    x.assign(m, 0.0);
+    for (int i = 0; i < m; i++) { double s2 = 0; for (int j = 0; j < m; j++) s2 += inv[(size_t)i * m + j] * b[j]; x[i] = s2; }
+    return true;
+}
+
 }  // namespace gomilp

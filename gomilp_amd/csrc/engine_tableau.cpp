@@ -20,7 +20,7 @@ TabArgs Engine::make_tab_args(const Problem &P, int phase, double tol, int nn) {
     a.basic = w.basic; a.nonbasic = w.nonbasic;
     a.pk_ratio = w.pk_ratio; a.pi_ratio = w.pi_ratio; a.pb_ratio = w.pb_ratio; a.pd_ratio = w.pd_ratio; a.px_ratio = w.px_ratio;
     a.st = w.st;
-    a.trace = trace_on_ ? w.trace : nullptr;
+    a.trace = (trace_on_ || shadow_trace_) ? w.trace : nullptr;
     a.trace_cap = w.trace_cap;
     return a;
 }
@@ -204,7 +204,7 @@ BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int
     a.m = P.m; a.nn = nn; a.ldt = ldt_; a.ldu = P.ld; a.phase = phase; a.kmax = kmax; a.tol = tol;
     a.T = w.T[tcur_]; a.U = w.btU; a.V = w.btV; a.r = w.R[rcur_]; a.xb = w.xb;
     a.basic = w.basic; a.nonbasic = w.nonbasic; a.st = w.st;
-    a.trace = trace_on_ ? w.trace : nullptr; a.trace_cap = w.trace_cap;
+    a.trace = (trace_on_ || shadow_trace_) ? w.trace : nullptr; a.trace_cap = w.trace_cap;
     a.forced_q = a.forced_p = -1; a.forced_nocommit = 0;
     a.nt_force = (int)bt_nt_; a.old_only = bt_old_ ? 1 : 0;
     a.stamps = bt_stamps_ ? w.stamps : nullptr;
