@@ -354,6 +354,19 @@ int gomilp_pool_add_root(gomilp_pool *pool, const double *c, const double *A, in
     return (int)pool->extra_root.size();
 }
 
+// diagnostic (host only, no device): the column search of findLinearlyIndependent as the engine performs it for non-slack
+// starting bases; fast = 1: incremental QR (O(m^2 n)), 0: a fresh exact condition number per candidate (O(m^4))
+int64_t gomilp_debug_find_independent(const double *A, int64_t lda, int64_t m, int64_t n, int64_t *idx_out, int fast) {
+    if (!A || !idx_out || m <= 0 || n <= 0 || lda < n || m > 4096 || n > (1 << 20)) return -GOMILP_ERR_BAD_SHAPE;
+    std::vector<double> a((size_t)m * n);
+    for (int64_t i = 0; i < m; i++) for (int64_t j = 0; j < n; j++) a[(size_t)i * n + j] = A[i * lda + j];
+    std::vector<int32_t> idx;
+    if (fast) gomilp::general_find_linearly_independent(a, (int)m, (int)n, idx);
+    else gomilp::general_find_linearly_independent_slow(a, (int)m, (int)n, idx);
+    for (size_t k = 0; k < idx.size(); k++) idx_out[k] = idx[k];
+    return (int64_t)idx.size();
+}
+
 int64_t gomilp_lp_last_trace(gomilp_ctx *ctx, gomilp_pivot *out, int64_t cap) {
     if (!ctx) return -1;
     return ctx->eng->last_trace(out, cap);

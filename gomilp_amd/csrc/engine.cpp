@@ -191,7 +191,7 @@ int64_t Engine::upload(const double *c, const double *A, int64_t lda, const doub
     P->allone.assign(hs.begin() + 2 * n, hs.begin() + 3 * n);
     P->hb.assign(b, b + m);
     P->hc.assign(c, c + n);
-    if ((size_t)m * n <= ((size_t)1 << 22)) {  // small: keep A for the general initial-basis path
+    if ((size_t)m * n <= ((size_t)1 << 25)) {  // up to 256 MB: keep A for the general initial-basis path (equality rows, supplied basis)
         P->hA.resize((size_t)m * n);
         for (int i = 0; i < m; i++) memcpy(&P->hA[(size_t)i * n], A + (size_t)i * lda, sizeof(double) * (size_t)n);
     }
@@ -372,7 +372,7 @@ bool Engine::ensure_host_A(const Problem &P) {
     const Problem &R = *problems_[P.root];
     if (!ensure_host_A(R)) return false;
     const int m = P.m, n = P.n, m0 = R.m, n0 = R.n, K = (int)P.kvar.size();
-    if ((size_t)m * n > ((size_t)1 << 22)) return false;
+    if ((size_t)m * n > ((size_t)1 << 25)) return false;
     P.hA.assign((size_t)m * n, 0.0);
     for (int i = 0; i < m0; i++) memcpy(&P.hA[(size_t)i * n], &R.hA[(size_t)i * n0], sizeof(double) * (size_t)n0);
     for (int k = 0; k < K; k++) { P.hA[(size_t)(m0 + k) * n + P.kvar[k]] = P.ksign[k]; P.hA[(size_t)(m0 + k) * n + n0 + k] = 1.0; }
@@ -988,7 +988,7 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
         for (int pos = 0; pos < m; pos++) { xb[pos] = P.hb[rho[pos]]; if (xb[pos] < -1e-13) feasible = false; }
     } else {
         // general case (engine_general.cpp): host search over a kept copy of A, small problems on the tableau pipelines
-        if (!use_tab || m > 512 || !ensure_host_A(P)) return finish(GOMILP_ERR_UNSUPPORTED);
+        if (!use_tab || !ensure_host_A(P)) return finish(GOMILP_ERR_UNSUPPORTED);
         if (!initial_basic) {
             rc = general_find_linearly_independent(P.hA, m, n, basic);
             if (rc != GOMILP_OK) return finish(rc);  // ErrSingular, simplex.go:495-497

@@ -154,6 +154,7 @@ class Engine {
 
 // engine_general.cpp
 int general_find_linearly_independent(const std::vector<double> &A, int m, int n, std::vector<int32_t> &idxs);
+int general_find_linearly_independent_slow(const std::vector<double> &A, int m, int n, std::vector<int32_t> &idxs);
 bool general_basis_inverse(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, int ncols_with_art,
                            const std::vector<double> &art, std::vector<double> &binv);
 
@@ -181,6 +182,7 @@ int tab_ld(int nn);
 int launch_tableau_pivot(const TabArgs &a, int flags, int nparts, long long t, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 void launch_tab_gather(const double *At, int ld, int m, int nn, const int32_t *nonbasic, const int32_t *rho, double *T, int ldt,
                        bool tiled, hipStream_t s);
+void launch_tab_gemm(const double *Binv, int ldb, const double *At, int ld, int m, int nn, const int32_t *nonbasic, double *T, int ldt, bool tiled, hipStream_t s);
 void launch_tab_permute_cols(const double *Tin, int ld_in, double *Tout, int ld_out, int m, int nn_out, const int32_t *srcpos,
                              bool tiled, hipStream_t s);
 int tab_r_chunks(int m);

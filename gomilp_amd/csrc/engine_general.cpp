@@ -11,6 +11,9 @@
 // here instead of a permutation.
 #include "engine_work.hpp"
 
+#include <atomic>
+#include <thread>
+
 namespace gomilp {
 
 namespace {
@@ -92,7 +95,96 @@ double cond1_exact(const std::vector<double> &C, int m, int k) {
 }  // namespace
 
 // findLinearlyIndependent on the host copy of A.  Returns the accepted columns in scan order (basis position order).
+//
+// One Householder QR is carried along instead of a fresh factorisation per candidate (the reference's cost: sum_k m k^2 ~ m^4/3
+// flop, hours at m = 2048): a candidate column a is reduced with the k reflectors of the accepted columns (w = Q^T a), which
+// yields the new column of R (w[0..k)) and its diagonal entry (+-|w[k..m)|); R^-1 grows by one column in O(k^2), so the EXACT
+// kappa_1(R') = |R'|_1 |R'^-1|_1 of the decision `mat.Cond(columns, 1) <= 1e12` (simplex.go:630; R of a full-rank matrix is unique
+// up to row signs, which no norm sees) costs O(m k + k^2) per candidate, O(m^2 n) in all.  The last column makes the matrix
+// square, where the reference measures kappa_1 of the matrix itself through its LU: |A|_1 |R^-1 Q^T|_1 here.
 int general_find_linearly_independent(const std::vector<double> &A, int m, int n, std::vector<int32_t> &idxs) {
+    idxs.clear();
+    std::vector<double> V((size_t)m * m, 0.0);      // reflector k in column k (rows k..m-1), v_k normalised so that H = I - 2 v v^T / (v^T v)
+    std::vector<double> vnorm2(m, 0.0);
+    std::vector<double> R((size_t)m * m, 0.0), Rinv((size_t)m * m, 0.0);   // upper triangular, row-major m x m (leading k x k used)
+    std::vector<double> colsum_R(m, 0.0), colsum_Rinv(m, 0.0);              // 1-norm bookkeeping: absolute column sums
+    std::vector<double> w(m), t(m);
+    std::vector<double> Acols((size_t)m * m, 0.0);   // the accepted columns (for the square-case norm)
+    double nR = 0, nRinv = 0;
+    for (int i = n - 1; i >= 0; i--) {
+        const int k = (int)idxs.size();
+        if (k == m) break;
+        for (int r = 0; r < m; r++) w[r] = A[(size_t)r * n + i];
+        if (k == 0) {   // simplex.go:624-629: the first column is always accepted
+            double nrm = 0;
+            for (int r = 0; r < m; r++) nrm = hypot(nrm, w[r]);
+            const double alpha = w[0], beta = alpha >= 0 ? -nrm : nrm;
+            for (int r = 0; r < m; r++) V[(size_t)r * m + 0] = w[r];
+            V[0] = alpha - beta;
+            double vv = 0;
+            for (int r = 0; r < m; r++) vv += V[(size_t)r * m] * V[(size_t)r * m];
+            vnorm2[0] = vv;
+            R[0] = beta; Rinv[0] = beta != 0 ? 1 / beta : std::numeric_limits<double>::infinity();
+            colsum_R[0] = fabs(beta); colsum_Rinv[0] = fabs(Rinv[0]);
+            nR = colsum_R[0]; nRinv = colsum_Rinv[0];
+            for (int r = 0; r < m; r++) Acols[(size_t)r * m + 0] = A[(size_t)r * n + i];
+            idxs.push_back(i);
+            continue;
+        }
+        // w = H_{k-1} ... H_0 a
+        for (int j = 0; j < k; j++) {
+            if (vnorm2[j] == 0) continue;
+            double dot = 0;
+            for (int r = j; r < m; r++) dot += V[(size_t)r * m + j] * w[r];
+            const double f = 2 * dot / vnorm2[j];
+            for (int r = j; r < m; r++) w[r] -= f * V[(size_t)r * m + j];
+        }
+        double nrm = 0;
+        for (int r = k; r < m; r++) nrm = hypot(nrm, w[r]);
+        const double alpha = w[k], beta = alpha >= 0 ? -nrm : nrm;   // diagonal entry of the new R column
+        // candidate norms: |R'|_1, |R'^-1|_1 with R'^-1 = [[Rinv, -Rinv w_top / beta], [0, 1 / beta]]
+        double cs = fabs(beta);
+        for (int r = 0; r < k; r++) cs += fabs(w[r]);
+        double csi = beta != 0 ? fabs(1 / beta) : std::numeric_limits<double>::infinity();
+        for (int r = 0; r < k; r++) {
+            double acc = 0;
+            for (int c2 = r; c2 < k; c2++) acc += Rinv[(size_t)r * m + c2] * w[c2];
+            t[r] = beta != 0 ? -acc / beta : std::numeric_limits<double>::infinity();
+            csi += fabs(t[r]);
+        }
+        double cond;
+        if (beta == 0 || !std::isfinite(nRinv) || !std::isfinite(csi)) {
+            cond = std::numeric_limits<double>::infinity();   // a zero on the diagonal of R: exactly rank deficient (Dtrcon / Dgecon report rcond = 0)
+        } else if (k + 1 < m) {
+            cond = std::max(nR, cs) * std::max(nRinv, csi);
+        } else {
+            // square: kappa_1 of the matrix itself, |A|_1 |A^-1|_1 with A^-1 = R'^-1 Q^T
+            for (int r = 0; r < m; r++) Acols[(size_t)r * m + k] = A[(size_t)r * n + i];
+            if (!(nrm > 0) && !(fabs(alpha) > 0)) cond = std::numeric_limits<double>::infinity();
+            else {
+                std::vector<double> C((size_t)m * m), inv;
+                for (size_t q = 0; q < C.size(); q++) C[q] = Acols[q];
+                cond = invert(C, m, inv) ? norm1(C, m, m, m) * norm1(inv, m, m, m) : std::numeric_limits<double>::infinity();
+            }
+        }
+        if (cond > 1e12) continue;   // :630 not linearly independent (a NaN passes, as in the reference)
+        // accept: reflector k, new columns of R and R^-1
+        for (int r = 0; r < k; r++) { R[(size_t)r * m + k] = w[r]; Rinv[(size_t)r * m + k] = t[r]; }
+        R[(size_t)k * m + k] = beta; Rinv[(size_t)k * m + k] = 1 / beta;
+        colsum_R[k] = cs; colsum_Rinv[k] = csi;
+        nR = std::max(nR, cs); nRinv = std::max(nRinv, csi);
+        double vv = 0;
+        for (int r = k; r < m; r++) { const double v = (r == k) ? alpha - beta : w[r]; V[(size_t)r * m + k] = v; vv += v * v; }
+        vnorm2[k] = vv;
+        if (k + 1 < m) for (int r = 0; r < m; r++) Acols[(size_t)r * m + k] = A[(size_t)r * n + i];
+        idxs.push_back(i);
+    }
+    return (int)idxs.size() == m ? GOMILP_OK : GOMILP_ERR_SINGULAR;  // :495-497
+}
+
+// reference form of the same decisions: a fresh exact condition number per candidate (O(m^4); kept for the tests that pin
+// the incremental version against it)
+int general_find_linearly_independent_slow(const std::vector<double> &A, int m, int n, std::vector<int32_t> &idxs) {
     idxs.clear();
     std::vector<double> columns((size_t)m * m, 0.0);
     for (int i = n - 1; i >= 0; i--) {
@@ -106,6 +198,62 @@ int general_find_linearly_independent(const std::vector<double> &A, int m, int n
     return (int)idxs.size() == m ? GOMILP_OK : GOMILP_ERR_SINGULAR;  // :495-497
 }
 
+// B^-1 for large bases: LU with partial pivoting (rows of the trailing update split over host threads), then the m unit
+// right-hand sides solved independently, a slice per thread.  (Gauss-Jordan above is O(2 m^3) on one core: 20 s at m = 2048.)
+static bool invert_threaded(const std::vector<double> &A, int n, std::vector<double> &inv) {
+    const int nt = std::max(1, std::min<int>(16, (int)std::thread::hardware_concurrency()));
+    if (n < 256 || nt == 1) return invert(A, n, inv);
+    std::vector<double> LU(A);
+    std::vector<int> piv(n);
+    std::atomic<int> arrived(0), gen(0);
+    std::atomic<bool> ok(true);
+    auto barrier = [&](int &my_gen) {   // sense-reversing spin barrier of the team
+        my_gen++;
+        if (arrived.fetch_add(1) + 1 == nt) { arrived.store(0); gen.store(my_gen); }
+        else while (gen.load() < my_gen) std::this_thread::yield();
+    };
+    auto work = [&](int tid) {
+        int my_gen = 0;
+        for (int k = 0; k < n; k++) {
+            if (tid == 0) {
+                int p = k;
+                double best = fabs(LU[(size_t)k * n + k]);
+                for (int i = k + 1; i < n; i++) { const double v = fabs(LU[(size_t)i * n + k]); if (v > best) { best = v; p = i; } }
+                if (!(best > 0) || !std::isfinite(best)) ok.store(false);
+                piv[k] = p;
+                if (p != k) for (int j = 0; j < n; j++) std::swap(LU[(size_t)k * n + j], LU[(size_t)p * n + j]);
+            }
+            barrier(my_gen);
+            if (!ok.load()) return;
+            const double d = LU[(size_t)k * n + k];
+            const double *rk = &LU[(size_t)k * n];
+            for (int i = k + 1 + tid; i < n; i += nt) {
+                double *ri = &LU[(size_t)i * n];
+                const double f = ri[k] / d;
+                ri[k] = f;
+                if (f != 0) for (int j = k + 1; j < n; j++) ri[j] -= f * rk[j];
+            }
+            barrier(my_gen);
+        }
+        // columns of the inverse: P A = L U  ->  A^-1 e_c = U^-1 L^-1 P e_c
+        std::vector<double> x(n);
+        for (int c = tid; c < n; c += nt) {
+            for (int i = 0; i < n; i++) x[i] = 0;
+            x[c] = 1;
+            for (int k = 0; k < n; k++) if (piv[k] != k) std::swap(x[k], x[piv[k]]);
+            for (int i = 0; i < n; i++) { const double *ri = &LU[(size_t)i * n]; double s2 = x[i]; for (int j = 0; j < i; j++) s2 -= ri[j] * x[j]; x[i] = s2; }
+            for (int i = n - 1; i >= 0; i--) { const double *ri = &LU[(size_t)i * n]; double s2 = x[i]; for (int j = i + 1; j < n; j++) s2 -= ri[j] * x[j]; x[i] = s2 / ri[i]; }
+            for (int i = 0; i < n; i++) inv[(size_t)i * n + c] = x[i];
+        }
+    };
+    inv.assign((size_t)n * n, 0.0);
+    std::vector<std::thread> th;
+    for (int t2 = 1; t2 < nt; t2++) th.emplace_back(work, t2);
+    work(0);
+    for (auto &t2 : th) t2.join();
+    return ok.load();
+}
+
 // B^-1 of the basis made of the columns `basic` of A (row-major, m x n)
 bool general_basis_inverse(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, int ncols_with_art,
                            const std::vector<double> &art, std::vector<double> &binv) {
@@ -116,7 +264,7 @@ bool general_basis_inverse(const std::vector<double> &A, int m, int n, const std
             B[(size_t)i * m + p] = (j < n) ? A[(size_t)i * n + j] : art[i];
         }
     (void)ncols_with_art;
-    return invert(B, m, binv);
+    return invert_threaded(B, m, binv);
 }
 
 // ---- condition guards of gonum's LU.Solve (mat/lu.go:301,321) for SMALL bases, by replaying the pivot sequence on the host

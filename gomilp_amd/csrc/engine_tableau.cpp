@@ -371,6 +371,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
     if (!binv_host && (rc = stage_upload(w.rho, rho.data(), (size_t)m * sizeof(int32_t))) != GOMILP_OK) return rc;
     // (x_B itself was uploaded by Engine::solve)
     std::vector<double> art(P.ld, 0.0);  // Phase-I artificial column (simplex.go:533-542)
+    bool binv_on_device = false;
     auto set_up_T = [&](int nn) -> int {  // T = B^-1 A_N
         ldt_ = tab_ld(nn);
         if (!binv_host) {  // slack basis: B^-1 is the permutation rho
@@ -381,21 +382,18 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
             launches_++;
             return GOMILP_OK;
         }
-        // general basis (small problems): T on the host from the kept copy of A
-        std::vector<double> Th((size_t)m * ldt_, 0.0);
-        for (int jp = 0; jp < nn; jp++) {
-            const int j = nonbasic[jp];
-            for (int pos = 0; pos < m; pos++) {
-                double s = 0;
-                const double *bi = binv_host->data() + (size_t)pos * m;
-                if (j < n) for (int i = 0; i < m; i++) s += bi[i] * P.hA[(size_t)i * n + j];
-                else for (int i = 0; i < m; i++) s += bi[i] * art[i];
-                Th[(size_t)pos * ldt_ + jp] = s;
-            }
+        // general basis: B^-1 from the host (engine_general.cpp), T = B^-1 A_N as a device GEMM over the resident columns
+        // (At row n holds the Phase-I artificial column); straight into the layout the block kernels want
+        const int kr0 = bt_reg_k(P.m, ldt_, (int)bt_nt_);
+        t_tiled_ = use_bt_ && bt_tiled(P.m, ldt_, block_k_ > 0 ? (int)block_k_ : (kr0 > 0 ? 8 : 16), (int)bt_nt_, bt_old_ != 0);
+        if (!binv_on_device) {
+            HIP_TRY(hipMemcpy2DAsync(w.binv[0], (size_t)P.ld * sizeof(double), binv_host->data(), (size_t)m * sizeof(double), (size_t)m * sizeof(double), m,
+                                     hipMemcpyHostToDevice, stream_));
+            HIP_TRY(sync_stream());   // binv_host is pageable
+            binv_on_device = true;
         }
-        // same stream as everything else (a null-stream copy is not ordered against the non-blocking stream)
-        HIP_TRY(hipMemcpyAsync(w.T[0], Th.data(), Th.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
-        HIP_TRY(sync_stream());  // Th is a local
+        launch_tab_gemm(w.binv[0], P.ld, P.dAt, P.ld, m, nn, w.nonbasic, w.T[0], ldt_, t_tiled_, stream_);
+        launches_++;
         return GOMILP_OK;
     };
     int nn;

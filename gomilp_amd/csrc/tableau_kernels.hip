@@ -239,6 +239,51 @@ __global__ void k_tab_gather(const double *__restrict__ At, int ld, int m, int n
     }
 }
 
+// T[pos, jp] = sum_i Binv[pos, i] * At[var(jp)][i]  — T = B^-1 A_N for a general (non-slack) starting basis: B^-1 comes from
+// the host (engine_general.cpp), the product runs here.  64 x 64 output tile per workgroup, 4 x 4 per thread, K chunks of 16
+// through LDS; both operands are contiguous along i, so the staging loads are coalesced.
+__global__ __launch_bounds__(kBlock) void k_tab_gemm(const double *__restrict__ Binv, int ldb, const double *__restrict__ At, int ld, int m, int nn,
+                                                    const int32_t *__restrict__ nonbasic, double *__restrict__ T, int ldt, int tiled) {
+    __shared__ double sa[16][65], sb[16][65];
+    const int p0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // thread -> outputs (p0 + ty*4 + a, j0 + tx*4 + b)
+    double acc[4][4] = {};
+    const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 4;   // staging: row lr (0..63), k offset lk (0,4,8,12)
+    const int arow = p0 + lr, bcol = j0 + lr;
+    const double *ap = arow < m ? Binv + (size_t)arow * ldb : nullptr;
+    const double *bp = bcol < nn ? At + (size_t)nonbasic[bcol] * ld : nullptr;
+    for (int k0 = 0; k0 < m; k0 += 16) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int kk = k0 + lk + t;
+            sa[lk + t][lr] = (ap && kk < m) ? ap[kk] : 0.0;
+            sb[lk + t][lr] = (bp && kk < m) ? bp[kk] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) av[a] = sa[kk][ty * 4 + a];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bv[b] = sb[kk][tx * 4 + b];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] += av[a] * bv[b];
+        }
+        __syncthreads();
+    }
+    const int mrows = tiled ? ((m + 3) & ~3) : m;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int pos = p0 + ty * 4 + a, jp = j0 + tx * 4 + b;
+            if (pos < mrows && jp < ldt) T[tab_idx(pos, jp, ldt, tiled)] = (pos < m && jp < nn) ? acc[a][b] : 0.0;
+        }
+}
+
 // T_out[:, jp] = T_in[:, src[jp]]  (Phase I -> Phase II: nonbasic list rebuilt in ascending variable order)
 __global__ void k_tab_permute_cols(const double *__restrict__ Tin, int ld_in, double *__restrict__ Tout, int ld_out, int m,
                                    int nn_out, const int32_t *__restrict__ srcpos, int tiled) {
@@ -307,6 +352,10 @@ void launch_tab_gather(const double *At, int ld, int m, int nn, const int32_t *n
                        bool tiled, hipStream_t s) {
     dim3 grid((m + 3 + 31) / 32, (ldt + 31) / 32), block(32, 8);   // all ldt columns (+ pad rows): the kernel zero-fills the padding
     hipLaunchKernelGGL(k_tab_gather, grid, block, 0, s, At, ld, m, nn, nonbasic, rho, T, ldt, tiled ? 1 : 0);
+}
+void launch_tab_gemm(const double *Binv, int ldb, const double *At, int ld, int m, int nn, const int32_t *nonbasic, double *T, int ldt, bool tiled, hipStream_t s) {
+    dim3 grid((((m + 3) & ~3) + 63) / 64, (ldt + 63) / 64);
+    hipLaunchKernelGGL(k_tab_gemm, grid, dim3(kBlock), 0, s, Binv, ldb, At, ld, m, nn, nonbasic, T, ldt, tiled ? 1 : 0);
 }
 int tab_ld(int nn) { return ((nn + 511) / 512) * 512; }
 void launch_tab_permute_cols(const double *Tin, int ld_in, double *Tout, int ld_out, int m, int nn_out, const int32_t *srcpos,

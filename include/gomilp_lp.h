@@ -211,6 +211,11 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
                                 const double *sign, const double *rhs, double tol, double *z_out, double *x_out, int64_t ldx,
                                 int32_t *status_out, int32_t *has_x_out, gomilp_frontier_stats *stats);
 
+/* Diagnostic, host only: the column search of findLinearlyIndependent (simplex.go:611-637) as the engine performs it for
+ * non-slack starting bases (exact kappa_1 instead of the Hager estimate).  fast = 1: one Householder QR carried along,
+ * O(m^2 n); fast = 0: a fresh factorisation per candidate, O(m^4).  idx_out has room for m entries; returns their count. */
+int64_t gomilp_debug_find_independent(const double *A, int64_t lda, int64_t m, int64_t n, int64_t *idx_out, int fast);
+
 /* Library / device probes (no compute): used by the loader checks and by __graft_entry__. */
 const char *gomilp_version(void);
 int gomilp_device_count(void);

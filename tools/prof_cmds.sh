@@ -1,13 +1,20 @@
+# rocprofv3 evidence of a round (run on the GPU box through gpurun: bash tools/prof_cmds.sh <tag>)
 set -x
-mkdir -p gpurun_out/r2p
+TAG=${1:-r2}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 cd $R
-python bench.py > gpurun_out/r2p/bench_unprofiled.json 2> gpurun_out/r2p/bench_unprofiled.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2p/stats -- python3 bench.py --no-cpu-baseline > gpurun_out/r2p/bench_profiled.json 2> gpurun_out/r2p/prof.err
+HEAD="--no-cpu-baseline --concurrent 0 --milp-nodes 0 --c4 0 --frontier-vars 0"
+# 1. default bench, unprofiled (the numbers DESIGN.md quotes)
+python bench.py > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
+# 2. kernel stats of the headline region alone (metric LP) and of the frontier leg alone
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_M -- python3 bench.py $HEAD > $OUT/bench_M_profiled.json 2> $OUT/stats_M.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_C5 -- python3 tools/wave_prof.py 8 4 > $OUT/wave_profiled.out 2> $OUT/stats_C5.err
+# 3. PMC passes (separate runs; counters only)
 SMALL="--steps 1 --warmup 0 --no-cpu-baseline --concurrent 0 --milp-nodes 0 --c4 0"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r2p/pmc_fetch -- python3 bench.py $SMALL > gpurun_out/r2p/pmc_f.json 2> gpurun_out/r2p/pmc_f.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/r2p/pmc_write -- python3 bench.py $SMALL > gpurun_out/r2p/pmc_w.json 2> gpurun_out/r2p/pmc_w.err
-rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d gpurun_out/r2p/pmc_mfma -- python3 bench.py $SMALL > gpurun_out/r2p/pmc_m.json 2> gpurun_out/r2p/pmc_m.err
-ls gpurun_out/r2p/*/*/ | head -30
-du -sh gpurun_out/r2p
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $SMALL > $OUT/pmc_f.json 2> $OUT/pmc_f.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py $SMALL > $OUT/pmc_w.json 2> $OUT/pmc_w.err
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $OUT/pmc_mfma -- python3 bench.py $SMALL > $OUT/pmc_m.json 2> $OUT/pmc_m.err
+du -sh $OUT
