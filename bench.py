@@ -332,7 +332,7 @@ def main() -> int:
         nblocks = max(ksec[1], 1.0)
         K = ksec[3] / nblocks if ksec[1] > 0 else 8.0
         t_inner, t_upd = ksec[0] / nblocks, ksec[2] / nblocks
-        inner_name = "k_bt_inner2<1024,2,2,8,1>" if (tiled and m > 1024) else ("k_bt_inner2<512,2,2,8,0>" if tiled else "k_bt_inner<1024,%d,%d,0>" % ((m + 1023) // 1024, (nn + 1023) // 1024))
+        inner_name = "k_bt_inner2<512,4,4,8,0>" if (tiled and m > 1024) else ("k_bt_inner2<512,2,2,8,0>" if tiled else "k_bt_inner<1024,%d,%d,0>" % ((m + 1023) // 1024, (nn + 1023) // 1024))
         upd_name = "k_bt_update_tiled<8>" if tiled else "k_bt_update<16>"
         # byte model of THIS pipeline, per block of K pivots: the inner kernel reads one column and one row of T per pivot and
         # writes u_k, v_k' (8 B each) + loads / stores r, x_B and the index lists once per launch; the update reads and

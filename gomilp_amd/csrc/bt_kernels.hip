@@ -523,7 +523,7 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
             double d = -dcol[s];
             if (fabs(d) < 1e-13) d = 0;
             dn[s] = d;
-            quot[s] = xb_s[i] / fabs(d);
+            quot[s] = div_pos(xb_s[i], fabs(d));   // == xb / |d| bit for bit (kernels_common.h); discarded where d == 0
         }
 #pragma unroll
         for (int s = 0; s < RI; s++) {
@@ -616,9 +616,11 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
             reduce_rows(gl, dcol, dpv, xbp, up);
         }
         // ---- row p of the current tableau for this thread's columns, reduced costs, block terms
-        const double mult = rq / dpv;
-        const double theta = xbp / dpv;
+        // one exact reciprocal per pivot; r_q / d_p and x_B[p] / d_p as products with it (engine-own running quantities, like
+        // u_i = d_i * (-1/d_p): two IEEE divisions = 26 instructions less per wave and pivot)
         const double rinv = 1.0 / dpv, nrinv = -rinv;
+        const double mult = rq * rinv;
+        const double theta = xbp * rinv;
         char *Vk = reinterpret_cast<char *>(a.V + (size_t)k * a.ldt);
         char *Uk = reinterpret_cast<char *>(a.U + (size_t)k * a.ldu);
         // the row loads go out first: the u terms / x_B update below need nothing from them and run under their latency
@@ -857,7 +859,7 @@ __device__ __forceinline__ void bt_inner2_dual_body(const BTArgs &a) {
             for (int s = 0; s < CJ; s++) {
                 const int j = tid + s * NT;
                 const double v = vrow[s];
-                ratio[s] = (j < a.nn && v < -1e-13) ? r_s[j] / (-v) : inf;
+                ratio[s] = (j < a.nn && v < -1e-13) ? div_pos(r_s[j], -v) : inf;
             }
             const BtWin w = wave_first_min(ratio, std::integral_constant<int, CJ>());
 #pragma unroll
@@ -1176,11 +1178,11 @@ static BtCfg bt_cfg(int m, int ldt, int force) {   // force: context knob "bt_nt
         if (force && nt != force) continue;
         const int r = std::max(per(m, nt), per(ldt, nt));
         if (!force) {
-            // measured on gfx950: fat threads (many rows per thread) lose more on the column gather / row update than
-            // they gain on the reductions; keep at most 2 rows per thread unless the problem is small
-            // (m = 2048: 256 thr 13.8 us/pivot, 512 thr 9.2, 1024 thr 8.6; m = 1024: 8.0 / 6.1 / 6.6; m = 512: 5.4 / 4.9 / 5.6)
+            // measured on gfx950 (round 2, k_bt_inner2): 512 threads with up to 4 rows + 4 columns per thread hold every block term
+            // in registers without spilling (244 VGPRs of the 256 a thread of a 512-thread workgroup may use) — 37.7 us per 8
+            // pivots at m = 2048; 1024 threads x 2 need an LDS ring for one column slot and still spill 10 VGPRs: 40.7 us
             if (nt == 256) continue;
-            if (nt == 512 && r > 2) continue;
+            if (nt == 512 && r > 4) continue;
         }
         if (r <= 2) return {nt, 2, 2, 8};
         if (r <= 4) return {nt, 4, 4, nt <= 512 ? 8 : 0};

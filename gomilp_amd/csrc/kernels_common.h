@@ -200,9 +200,21 @@ __device__ __forceinline__ double row_min_f64(double x) {
     x = vmin_f64(x, ror_f64<0x128>(x));  // row_ror:8
     return x;
 }
+// rows combined with the gfx9 broadcast forms of DPP instead of 4 x v_readlane pairs: row_bcast15 hands lane 15 of a row to
+// the next row (row_mask 0xA: rows 1 and 3 take it), row_bcast31 hands lane 31 to rows 2 and 3 (row_mask 0xC); lane 63 then
+// holds the minimum of the wave — 6 VALU + 2 v_readlane instead of 19 instructions
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double bcast_f64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp((int)(unsigned int)b, (int)(unsigned int)b, CTRL, ROWMASK, 0xF, false);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp((int)(unsigned int)(b >> 32), (int)(unsigned int)(b >> 32), CTRL, ROWMASK, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ double wave_min_f64(double x) {
-    x = row_min_f64(x);
-    return vmin_f64(vmin_f64(readlane_f64(x, 15), readlane_f64(x, 31)), vmin_f64(readlane_f64(x, 47), readlane_f64(x, 63)));
+    x = row_min_f64(x);                               // every lane of a row holds the row's minimum
+    x = vmin_f64(x, bcast_f64<0x142, 0xA>(x));        // row_bcast:15 -> rows 1, 3: min(r0, r1), min(r2, r3)
+    x = vmin_f64(x, bcast_f64<0x143, 0xC>(x));        // row_bcast:31 -> rows 2, 3: row 3 = min of the wave
+    return readlane_f64(x, 63);
 }
 __device__ __forceinline__ unsigned int row_min_u32(unsigned int x) {
     x = min(x, ror_u32<0x121>(x));
@@ -210,6 +222,20 @@ __device__ __forceinline__ unsigned int row_min_u32(unsigned int x) {
     x = min(x, ror_u32<0x124>(x));
     x = min(x, ror_u32<0x128>(x));
     return x;
+}
+
+// x / d for d > 0 and operands in the normal range (|x| / d far from overflow and underflow: ratios of the ratio test):
+// reciprocal + two Newton steps + one residual correction — the instruction sequence of the compiler's IEEE division without
+// its scaling and fix-up stages (8 instead of 13 instructions), the same correctly rounded quotient where those stages are idle
+__device__ __forceinline__ double div_pos(double x, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    double q = x * r;
+    const double rem = __builtin_fma(-d, q, x);
+    return __builtin_fma(rem, r, q);
 }
 
 // dot of one padded row (ld doubles, 16-byte aligned) with the LDS-staged vector; result in all lanes
