@@ -31,15 +31,31 @@ def stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile to a temporary file next to the target and rename it into place, under a file lock: several ranks that import
+    the package on a fresh checkout at once (torchrun) neither compile concurrently into one file nor load a half-written one."""
     if not (force or stale()):
         return LIB
     hipcc = _hipcc()
     if hipcc is None:
         raise RuntimeError("hipcc not found and %s is missing or out of date" % LIB)
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not stale():      # another process built it while this one waited for the lock
+                return LIB
+            tmp = "%s.tmp.%d" % (LIB, os.getpid())
+            cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.run(cmd, check=True)
+                os.replace(tmp, LIB)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

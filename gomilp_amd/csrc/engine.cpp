@@ -301,7 +301,14 @@ int64_t Engine::upload_child_impl(const Problem &R, int64_t root, int K, const i
         if (sign[k] != 1.0) P->allone[var[k]] = 0;
         P->nnz[n0 + k] = 1; P->lastrow[n0 + k] = m0 + k; P->allone[n0 + k] = 1;
     }
-    P->verify_status = R.verify_status;  // bnb rows and their slack columns are never empty
+    // verifyInputs of the child (simplex.go:404-438): branch rows and their slack columns are never empty, so a row verdict of
+    // the root stands; a COLUMN verdict is re-derived, because a branch row can fill a column that was empty in the root
+    P->verify_status = R.verify_status;
+    if (R.verify_status == GOMILP_ERR_ZERO_COLUMN || R.verify_status == GOMILP_ERR_UNBOUNDED) {
+        P->verify_status = GOMILP_OK;
+        for (int j = 0; j < n && P->verify_status == GOMILP_OK; j++)
+            if (P->nnz[j] == 0) P->verify_status = (P->hc[j] < 0) ? GOMILP_ERR_UNBOUNDED : GOMILP_ERR_ZERO_COLUMN;
+    }
     // the host copy of [[A0, 0], [G#, I]] is only needed when a solve starts from a non-slack basis: built on demand
     P->hA.clear();
     P->root = root;
