@@ -1228,7 +1228,9 @@ static void bt_launch_nt(const BTArgs &a, const BtCfg &c, bool reg, size_t lds, 
     else { if (reg && NT <= 256) GOMILP_BT_LAUNCH(8, 8, (NT <= 256 ? 8 : 0)); else GOMILP_BT_LAUNCH(8, 8, 0); }
 #undef GOMILP_BT_LAUNCH
 }
+void launch_bt_inner_groups(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);   // btg_kernels.hip
 void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    if (a.groups > 0 && a.tiled) { launch_bt_inner_groups(a, s, e0, e1); return; }
     const size_t lds = (size_t)(a.ldt + a.ldu) * sizeof(double) + (size_t)(a.ldu + a.ldt) * sizeof(int);
     static bool attr_done = false;
     if (!attr_done) {

@@ -1,0 +1,502 @@
+// Block kernel of the blocked tableau pipeline spread over G workgroups of ONE XCD (gfx950).
+//
+// k_bt_inner2 (bt_kernels.hip) runs the K pivots of a block on a single CU: at 2048 rows every pivot drags 128 KB through
+// one L1 (a column and a row of T in 4x4 tiles) and about 600 VALU instructions per wave through 4 SIMDs, 4.7 us per pivot;
+// 4096-row shapes do not fit its registers at all.  Here G = 2 / 4 / 8 workgroups share a block: workgroup g owns the rows
+// and columns (s*G + g)*NT + t — x_B, r, the index lists and the block's rank-1 terms u_k[i], v'_k[j] of exactly those, in
+// LDS / registers as before — so loads, corrections and term shifts shrink by G and K = 16 terms fit in registers.
+// What stays global are the two argmins of a pivot (entering column: simplex.go:247, leaving row: :262-266).  Each becomes
+// an EXCHANGE through the XCD's L2:
+//   * every workgroup reduces its own candidates (v_min_f64 over DPP + ballot, as in k_bt_inner2) and wave 0 posts a
+//     record {min, first index, scalars everybody needs about the winner (r_q, the entering variable, v'_k[q]; or d_p,
+//     x_B[p], the leaving variable, u_k[p])} — 32 slots of 16 bytes {sequence number, value}, one 16-byte store per lane,
+//     so a slot can never be seen half-written;
+//   * wave 0 polls the G records (sc1 loads: served by L2, never by a stale L1 line) until every slot carries this
+//     exchange's sequence number, takes the lexicographic minimum (value, index) — floats.MinIdx over the whole vector —
+//     and hands the winner's record to the other waves through LDS.
+// Records are double buffered by sequence parity: a workgroup can be at most one exchange ahead of the slowest one.
+// Measured (tools/xsync_bench.hip, MI355X): 0.64 us per exchange at G = 4 on one XCD, 0.95 us across XCDs; the launch
+// therefore uses blocks 0, 8, 16, ... of a grid of 8*G (blocks are dealt round-robin over the 8 XCDs; the others leave at
+// once).  Placement is a speed matter only: the protocol is correct wherever the workgroups run.
+// Every workgroup takes the same decisions from the same exchanged values, so control flow never diverges between them; a
+// poll that sees no progress for ~1 s (a workgroup never got a CU) ends the launch with ST_XCHG_TIMEOUT in every workgroup.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "device_types.h"
+#include "kernels_common.h"
+
+namespace gomilp {
+
+namespace {
+
+constexpr int kXSlots = 32;            // slots per record
+constexpr int kXHeader = 16;           // doubles in front of the records: [0] = exchanges completed so far
+constexpr int kXSpinLimit = 2000000;   // polls (~0.5 us each) before a launch gives up
+
+typedef double xpair __attribute__((ext_vector_type(2)));   // {sequence number, value}
+
+__device__ __forceinline__ unsigned int tile_off_g(unsigned int i, unsigned int j, unsigned int ldt) {
+    return ((i >> 2) * (ldt >> 2) + (j >> 2)) * 16u + ((i & 3u) << 2) + (j & 3u);
+}
+__device__ __forceinline__ void xstore(xpair *p, xpair v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+template <int H> struct XLoad;
+template <> struct XLoad<1> {
+    static __device__ __forceinline__ void run(const xpair *p, xpair (&v)[1]) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(p) : "memory");
+    }
+};
+template <> struct XLoad<2> {
+    static __device__ __forceinline__ void run(const xpair *p, xpair (&v)[2]) {
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]) : "v"(p) : "memory");
+    }
+};
+template <> struct XLoad<4> {
+    static __device__ __forceinline__ void run(const xpair *p, xpair (&v)[4]) {
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p) : "memory");
+    }
+};
+
+struct XWin { double m; unsigned int i; const double *pay; };   // winner of an exchange: value, first index, its payload
+struct BtWinG { double m; unsigned int i; };                   // a wave's own winner
+
+}  // namespace
+
+// G workgroups x NT threads, RI rows and RI columns per thread (m <= G*NT*RI, ldt <= G*NT*RI), KR block terms in registers
+template <int G, int NT, int RI, int KR, bool STAMP = false>
+__global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
+    if (blockIdx.x & 7u) return;
+    constexpr int NW = NT / 64;
+    constexpr int H = G / 2;   // 64 lanes read two records per load
+    static_assert(G == 2 || G == 4 || G == 8, "G");
+    static_assert(KR + 3 <= kXSlots - 2, "payload");
+    const int g = (int)(blockIdx.x >> 3);
+    __shared__ double xb_s[RI * NT], r_s[RI * NT];   // slots only their owner thread touches
+    __shared__ int basic_s[RI * NT], nonbasic_s[RI * NT];
+    __shared__ double redM[16];
+    __shared__ unsigned int redI[16];
+    __shared__ double pay[16][KR + 3];
+    __shared__ double xres[2][2][kXSlots];   // [entering / leaving][sequence parity]: the winner's record
+    __shared__ int s_dead;
+    // STAMP: diagnostic build (knob "bt_stamps"): cycles per pivot segment and wave of workgroup 0 (s_memtime), summed in LDS
+    __shared__ unsigned long long s_acc[STAMP ? 16 : 1][16];
+    unsigned long long tprev = 0;
+    auto stamp = [&](int seg) {
+        if constexpr (STAMP) {
+            unsigned long long t;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (seg >= 0 && (threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6][seg] += t - tprev;
+            tprev = t;
+        }
+    };
+    DevState *st = a.st;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
+    const int done = __hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    long long xs = (long long)a.xbuf[0];   // written by workgroup 0 at the end of the previous launch
+    xpair *recs = reinterpret_cast<xpair *>(a.xbuf + kXHeader);   // [parity][G][kXSlots]
+    const double inf = __builtin_inf();
+    const unsigned int ldt = (unsigned int)a.ldt;
+    const char *Tb = reinterpret_cast<const char *>(a.T);
+    auto ldT = [&](unsigned int elem) -> double { return *reinterpret_cast<const double *>(Tb + (elem << 3)); };
+    auto gidx = [&](int s) -> int { return (s * G + g) * NT + tid; };   // row / column index of this thread's slot s
+    double x0[RI], r0[RI];
+    int b0[RI], n0[RI];
+#pragma unroll
+    for (int s = 0; s < RI; s++) {
+        const int i = gidx(s);
+        x0[s] = i < a.m ? a.xb[i] : 0.0;
+        b0[s] = i < a.m ? a.basic[i] : 0;
+        r0[s] = i < a.nn ? a.r[i] : inf;   // padding never wins an argmin
+        n0[s] = i < a.nn ? a.nonbasic[i] : 0;
+    }
+    if (done) {
+        if (g == 0 && tid == 0) st->kdone = 0;
+        return;
+    }
+    double ureg[RI][KR], vreg[RI][KR];
+#pragma unroll
+    for (int s = 0; s < RI; s++) {
+        xb_s[s * NT + tid] = x0[s];
+        basic_s[s * NT + tid] = b0[s];
+        r_s[s * NT + tid] = r0[s];
+        nonbasic_s[s * NT + tid] = n0[s];
+#pragma unroll
+        for (int j = 0; j < KR; j++) { ureg[s][j] = 0; vreg[s][j] = 0; }
+    }
+    if (tid == 0) s_dead = 0;
+    if constexpr (STAMP) { if (tid < 256) s_acc[tid >> 4][tid & 15] = 0; }
+    __syncthreads();
+    int kd = 0, status = ST_RUNNING, blands = 0;
+    bool dead = false;
+    long long trace_len = 0, npiv = 0;
+    if (g == 0 && tid == 0) { trace_len = st->trace_len; npiv = st->pivots; }
+
+    auto wave_first_min = [&](const double (&val)[RI]) -> BtWinG {
+        double x = val[0];
+#pragma unroll
+        for (int s = 1; s < RI; s++) x = vmin_f64(x, val[s]);
+        BtWinG w;
+        w.m = wave_min_f64(x);
+        w.i = 0xFFFFFFFFu;
+#pragma unroll
+        for (int s = RI - 1; s >= 0; s--) {
+            const unsigned long long mask = __ballot(val[s] == w.m);
+            if (mask) w.i = (unsigned int)((s * G + g) * NT + wbase + __builtin_ctzll(mask));
+        }
+        return w;
+    };
+    // the exchange: in = this workgroup's per-wave results in redM / redI / pay; out = the winner over all G workgroups
+    auto xchg = [&](int which) -> XWin {
+        stamp(which * 6 + 0);
+        __syncthreads();
+        stamp(which * 6 + 1);
+        xs += 1;
+        const double seqd = (double)xs;
+        const int par = (int)(xs & 1);
+        double *res = &xres[which][par][0];
+        if (wv == 0) {
+            const double x = lane < NW ? redM[lane] : inf;
+            const unsigned int ii = lane < NW ? redI[lane] : 0xFFFFFFFFu;
+            const double fm = readlane_f64(row_min_f64(x), 15);
+            const unsigned int key = (x == fm) ? ii : 0xFFFFFFFFu;
+            const unsigned int fi = (unsigned int)__builtin_amdgcn_readlane((int)row_min_u32(key), 15);
+            const int ww = (int)((fi & (unsigned int)(NT - 1)) >> 6);
+            if (lane < kXSlots) {
+                const int pl = lane < 2 ? 0 : (lane - 2 < KR + 3 ? lane - 2 : KR + 2);
+                xpair v;
+                v.x = seqd;
+                v.y = lane == 0 ? fm : lane == 1 ? (double)fi : pay[ww][pl];
+                xstore(recs + ((size_t)(par * G + g) * kXSlots + lane), v);
+            }
+            if constexpr (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(which * 6 + 2);
+            const xpair *src = recs + (size_t)par * G * kXSlots + lane;   // lane l: slot l & 31 of record (l >> 5) + 2h
+            xpair got[H];
+            int spins = 0;
+            for (;;) {
+                XLoad<H>::run(src, got);
+                bool ok = true;
+#pragma unroll
+                for (int h = 0; h < H; h++) ok = ok && (got[h].x == seqd);
+                if (__all(ok)) break;
+                if (++spins > kXSpinLimit) { s_dead = 1; break; }
+            }
+            stamp(which * 6 + 3);
+            // lexicographic minimum of (value, first index) over the G records; a NaN value never wins (v_min_f64)
+            double mg[G], ig[G];
+#pragma unroll
+            for (int q2 = 0; q2 < G; q2++) {
+                mg[q2] = readlane_f64(got[q2 >> 1].y, (q2 & 1) * 32);
+                ig[q2] = readlane_f64(got[q2 >> 1].y, (q2 & 1) * 32 + 1);
+            }
+            double bm = mg[0];
+#pragma unroll
+            for (int q2 = 1; q2 < G; q2++) bm = vmin_f64(bm, mg[q2]);
+            double bi = 4294967295.0;
+            int gw = 0;
+#pragma unroll
+            for (int q2 = 0; q2 < G; q2++)
+                if (mg[q2] == bm && ig[q2] < bi) { bi = ig[q2]; gw = q2; }
+            double wval = got[0].y;
+#pragma unroll
+            for (int h = 1; h < H; h++)
+                if ((gw >> 1) == h) wval = got[h].y;
+            if ((lane >> 5) == (gw & 1)) res[lane & 31] = wval;
+            stamp(which * 6 + 4);
+        }
+        __syncthreads();
+        stamp(which * 6 + 5);
+        if (s_dead) dead = true;
+        XWin r;
+        r.m = res[0];
+        r.i = (unsigned int)res[1];
+        r.pay = res + 2;
+        return r;
+    };
+    // entering column: (min, q); r_q, the entering variable and v'_k[q] (newest first) in the winner's payload
+    auto reduce_cols = [&](const double (&val)[RI]) -> XWin {
+        const BtWinG w = wave_first_min(val);
+#pragma unroll
+        for (int s = 0; s < RI; s++)
+            if ((unsigned int)gidx(s) == w.i) {
+                pay[wv][0] = r_s[s * NT + tid];
+                pay[wv][1] = (double)nonbasic_s[s * NT + tid];
+#pragma unroll
+                for (int j = 0; j < KR; j++) pay[wv][2 + j] = vreg[s][j];
+            }
+        if (lane == 0) { redM[wv] = w.m; redI[wv] = w.i; }
+        return xchg(0);
+    };
+    // leaving row: (min, p); d_p, x_B[p], the leaving variable and u_k[p]
+    auto reduce_rows = [&](const double (&val)[RI], const double (&dcol)[RI]) -> XWin {
+        const BtWinG w = wave_first_min(val);
+#pragma unroll
+        for (int s = 0; s < RI; s++)
+            if ((unsigned int)gidx(s) == w.i) {
+                pay[wv][0] = dcol[s];
+                pay[wv][1] = xb_s[s * NT + tid];
+                pay[wv][2] = (double)basic_s[s * NT + tid];
+#pragma unroll
+                for (int j = 0; j < KR; j++) pay[wv][3 + j] = ureg[s][j];
+            }
+        if (lane == 0) { redM[wv] = w.m; redI[wv] = w.i; }
+        return xchg(1);
+    };
+    auto column = [&](int q, const double *vq, double (&dcol)[RI]) {
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            const int i = gidx(s);
+            const unsigned int ic = (unsigned int)(i < a.m ? i : a.m - 1);
+            double d = ldT(tile_off_g(ic, (unsigned int)q, ldt));
+#pragma unroll
+            for (int j = 0; j < KR; j++) d = __builtin_fma(ureg[s][j], vq[j], d);
+            dcol[s] = i < a.m ? d : 0.0;
+        }
+    };
+    // ratio vector (simplex.go:321-340), branch-free as in k_bt_inner2
+    auto ratios = [&](const double (&dcol)[RI], double (&mvv)[RI]) {
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            const int i = gidx(s);
+            double d = -dcol[s];
+            if (fabs(d) < 1e-13) d = 0;
+            const double quot = div_pos(xb_s[s * NT + tid], fabs(d));
+            mvv[s] = (d >= 0 || i >= a.m) ? inf : quot;
+        }
+    };
+
+    for (int k = 0; k < a.kmax; k++) {
+        stamp(-1);
+        const bool forced = (k == 0 && a.forced_q >= 0);
+        int q, p, ent = 0, lea = 0;
+        double rq = 0, dpv = 1.0, xbp = 0;
+        const double *vq, *up;
+        bool bland = false;
+        double dcol[RI];
+        if (!forced) {
+            XWin fq;
+            {
+                double rv[RI];
+#pragma unroll
+                for (int s = 0; s < RI; s++) rv[s] = r_s[s * NT + tid];
+                fq = reduce_cols(rv);
+            }
+            if (dead) break;
+            q = (int)fq.i; rq = fq.pay[0]; ent = (int)fq.pay[1]; vq = fq.pay + 2;
+            if (fq.i >= (unsigned int)a.nn) { q = 0; rq = __builtin_nan(""); }   // every r_j is NaN: MinIdx returns 0
+            if (rq >= -a.tol) { status = ST_OPTIMAL; break; }                    // simplex.go:248
+            column(q, vq, dcol);
+            XWin w;
+            {
+                double mvv[RI];
+                ratios(dcol, mvv);
+                w = reduce_rows(mvv, dcol);
+            }
+            if (dead) break;
+            p = (int)w.i; dpv = w.pay[0]; xbp = w.pay[1]; lea = (int)w.pay[2]; up = w.pay + 3;
+            const double mv = w.m;
+            if (mv == inf || w.i >= (unsigned int)a.m) { status = ST_UNBOUNDED; break; }   // simplex.go:328-330
+            if (mv <= 0) {
+                // replaceBland (simplex.go:347-383), as in k_bt_inner2: candidates in position order
+                bland = true;
+                blands++;
+                int cand = -1;
+                bool found = false;
+                for (;;) {
+                    double fl[RI];
+#pragma unroll
+                    for (int s = 0; s < RI; s++) {
+                        const int j = gidx(s);
+                        double rv = r_s[s * NT + tid];
+                        if (fabs(rv) < 1e-13) rv = 0;
+                        fl[s] = (j < a.nn && j > cand && !(rv > -1e-14)) ? 0.0 : inf;
+                    }
+                    const XWin fc = reduce_cols(fl);
+                    if (dead) break;
+                    if (fc.m != 0.0) break;   // candidates exhausted -> ErrBland
+                    cand = (int)fc.i;
+                    const double rqc = fc.pay[0];
+                    const int entc = (int)fc.pay[1];
+                    column(cand, fc.pay + 2, dcol);
+                    XWin w2;
+                    {
+                        double mvv[RI];
+                        ratios(dcol, mvv);
+                        w2 = reduce_rows(mvv, dcol);
+                    }
+                    if (dead) break;
+                    if (w2.m == inf || w2.i >= (unsigned int)a.m) { status = ST_UNBOUNDED; break; }   // :356-360
+                    if (fabs(w2.m) > 1e-12) {   // :362
+                        q = cand; p = (int)w2.i; rq = rqc; ent = entc; dpv = w2.pay[0]; xbp = w2.pay[1]; lea = (int)w2.pay[2]; up = w2.pay + 3;
+                        found = true;
+                        break;
+                    }
+                    double gl[RI];
+                    ratios(dcol, gl);
+#pragma unroll
+                    for (int s = 0; s < RI; s++) gl[s] = (gidx(s) < a.m && !(gl[s] > 1e-12)) ? 0.0 : inf;
+                    const XWin gw = reduce_rows(gl, dcol);
+                    if (dead) break;
+                    if (gw.m == 0.0) {   // :368-379
+                        q = cand; p = (int)gw.i; rq = rqc; ent = entc; dpv = gw.pay[0]; xbp = gw.pay[1]; lea = (int)gw.pay[2]; up = gw.pay + 3;
+                        found = true;
+                        break;
+                    }
+                }
+                if (dead || status == ST_UNBOUNDED) break;
+                if (!found) { status = ST_BLAND_FAILED; break; }
+            }
+        } else {
+            // set-up pivot chosen by the host (first pivot of a block: all block terms are zero)
+            q = a.forced_q; p = a.forced_p; rq = 0;
+            double fl[RI];
+#pragma unroll
+            for (int s = 0; s < RI; s++) fl[s] = (gidx(s) == q) ? 0.0 : inf;
+            const XWin fc = reduce_cols(fl);
+            if (dead) break;
+            ent = (int)fc.pay[1];
+            column(q, fc.pay + 2, dcol);
+            double gl[RI];
+#pragma unroll
+            for (int s = 0; s < RI; s++) gl[s] = (gidx(s) == p) ? 0.0 : inf;
+            const XWin gw = reduce_rows(gl, dcol);
+            if (dead) break;
+            dpv = gw.pay[0]; xbp = gw.pay[1]; lea = (int)gw.pay[2]; up = gw.pay + 3;
+        }
+        // ---- row p for this thread's columns, reduced costs, block terms (formulas of k_bt_inner2)
+        const double rinv = 1.0 / dpv, nrinv = -rinv;
+        const double mult = rq * rinv;
+        const double theta = xbp * rinv;
+        double *Vk = a.V + (size_t)k * a.ldt;
+        double *Uk = a.U + (size_t)k * a.ldu;
+        const bool commit_lists = !(forced && a.forced_nocommit) || (forced && a.forced_nocommit >= 2);
+        double vrow[RI];
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            const int j = gidx(s);
+            vrow[s] = j < a.ldt ? ldT(tile_off_g((unsigned int)p, (unsigned int)j, ldt)) : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            const int i = gidx(s);
+            if (i < a.ldu) {
+                const double u = (i == p) ? rinv - 1.0 : dcol[s] * nrinv;
+                if (i < a.m) xb_s[s * NT + tid] = (i == p) ? theta : __builtin_fma(-theta, dcol[s], xb_s[s * NT + tid]);
+                Uk[i] = u;
+#pragma unroll
+                for (int jj = KR - 1; jj > 0; jj--) ureg[s][jj] = ureg[s][jj - 1];
+                ureg[s][0] = u;
+                if (i == p && commit_lists) basic_s[s * NT + tid] = ent;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            const int j = gidx(s);
+            if (j < a.ldt) {
+                double v = vrow[s];
+#pragma unroll
+                for (int jj = 0; jj < KR; jj++) v = __builtin_fma(up[jj], vreg[s][jj], v);
+                r_s[s * NT + tid] = (j == q) ? -mult : __builtin_fma(-mult, v, r_s[s * NT + tid]);
+                const double vprime = (j == q) ? dpv + 1.0 : v;
+                Vk[j] = vprime;
+#pragma unroll
+                for (int jj = KR - 1; jj > 0; jj--) vreg[s][jj] = vreg[s][jj - 1];
+                vreg[s][0] = vprime;
+                if (j == q && commit_lists) nonbasic_s[s * NT + tid] = lea;
+            }
+        }
+        if constexpr (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(12);
+        if (forced && a.forced_nocommit == 3) status = ST_FORCED_DONE;
+        if (g == 0 && tid == 0 && !(forced && a.forced_nocommit)) {   // simplex.go:280
+            if (a.trace && trace_len < a.trace_cap) {
+                DevPivot &tr = a.trace[trace_len];
+                tr.phase = a.phase; tr.bland = bland ? 1 : 0; tr.min_idx = q; tr.replace = p; tr.entering = ent; tr.leaving = lea;
+            }
+            trace_len += 1;
+            npiv += 1;
+        }
+        kd = k + 1;
+    }
+    if (dead) status = ST_XCHG_TIMEOUT;
+    if constexpr (STAMP) {
+        if (a.stamps && g == 0 && lane == 0) {
+            for (int sg = 0; sg < 16; sg++) a.stamps[wv * 16 + sg] += s_acc[wv][sg];
+            if (wv == 0) a.stamps[16 * 16] += (unsigned long long)kd;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < RI; s++) {
+        const int i = gidx(s);
+        if (i < a.ldt) a.r[i] = i < a.nn ? r_s[s * NT + tid] : 0.0;
+        if (i < a.ldu) a.xb[i] = xb_s[s * NT + tid];
+        if (i < a.m) a.basic[i] = basic_s[s * NT + tid];
+        if (i < a.nn) a.nonbasic[i] = nonbasic_s[s * NT + tid];
+    }
+    if (tid == 0 && (g == 0 || dead)) {
+        if (g == 0) {
+            st->trace_len = trace_len;
+            st->pivots = npiv;
+            st->kdone = kd;
+            st->bland_steps += blands;
+            a.xbuf[0] = (double)xs;
+        }
+        if (status != ST_RUNNING) { st->done = 1; st->status = status; }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+size_t bt_xbuf_doubles() { return (size_t)kXHeader + (size_t)2 * 8 * kXSlots * 2; }
+
+// workgroups for a shape (knob "bt_groups": -1 = never, 0 = by shape, 2 / 4 / 8 = forced where the shape fits)
+BtGroupCfg bt_group_cfg(int m, int ldt, int knob) {
+    BtGroupCfg c = {0, 0, 0};
+    if (knob < 0) return c;
+    const int need = m > ldt ? m : ldt;
+    auto fits = [&](int G, int nt, int ri) { return (long)G * nt * ri >= need; };
+    if (knob == 2 || knob == 4 || knob == 8) {
+        const int G = knob;
+        if (fits(G, 512, 1)) c = {G, 512, 1};
+        else if (fits(G, 512, 2)) c = {G, 512, 2};
+        return c;
+    }
+    if (knob != 0) return c;
+    // up to 2048 rows the single-workgroup kernel is as fast (measured at 2048 x 2048: 80 us per 16 pivots with G = 4 against
+    // 37 us per 8 with k_bt_inner2: the exchanges cost what the shorter loads and corrections save)
+    if (need <= 2048) return c;
+    if (need <= 4096) return {8, 512, 1};
+    if (need <= 8192) return {8, 512, 2};
+    return c;
+}
+
+template <int G, int NT, int RI>
+static void btg_launch(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    if constexpr (RI == 1) {
+        if (a.stamps) { hipExtLaunchKernelGGL((k_bt_innerG<G, NT, RI, 16, true>), dim3(8 * G), dim3(NT), 0, s, e0, e1, 0, a); return; }
+    }
+    hipExtLaunchKernelGGL((k_bt_innerG<G, NT, RI, 16>), dim3(8 * G), dim3(NT), 0, s, e0, e1, 0, a);
+}
+void launch_bt_inner_groups(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const int G = a.groups, ri = a.group_ri;
+    if (G == 2) { if (ri == 1) btg_launch<2, 512, 1>(a, s, e0, e1); else btg_launch<2, 512, 2>(a, s, e0, e1); }
+    else if (G == 4) { if (ri == 1) btg_launch<4, 512, 1>(a, s, e0, e1); else btg_launch<4, 512, 2>(a, s, e0, e1); }
+    else { if (ri == 1) btg_launch<8, 512, 1>(a, s, e0, e1); else btg_launch<8, 512, 2>(a, s, e0, e1); }
+}
+const char *bt_group_kernel_name(int G, int ri) {
+    static const char *names[3][2] = {{"k_bt_innerG<2,512,1,16>", "k_bt_innerG<2,512,2,16>"}, {"k_bt_innerG<4,512,1,16>", "k_bt_innerG<4,512,2,16>"},
+                                      {"k_bt_innerG<8,512,1,16>", "k_bt_innerG<8,512,2,16>"}};
+    return names[G == 2 ? 0 : G == 4 ? 1 : 2][ri == 1 ? 0 : 1];
+}
+
+}  // namespace gomilp

@@ -14,6 +14,7 @@ enum : int32_t {
     ST_LU_SINGULAR = 5,  // exact zero pivot in the final gonum-order LU
     ST_BLAND_FAILED = 6,  // replaceBland exhausted its candidates (lp.ErrBland, simplex.go:382)
     ST_FORCED_DONE = 7,   // a set-up pivot ordered with forced_nocommit = 3 has run: later launches of the superstep are no-ops
+    ST_XCHG_TIMEOUT = 9,    // multi-workgroup block kernel (btg_kernels.hip): an exchange saw no progress (a workgroup never ran)
     ST_DUAL_INFEASIBLE = 8  // dual simplex (warm start): a row with x_B < 0 has no negative entry: the relaxation is infeasible
 };
 
@@ -126,7 +127,12 @@ struct BTArgs {
     int32_t nt_force;     // context knob "bt_nt": 0 = pick the thread count by shape, else 256 / 512 / 1024
     int32_t tiled, old_only;  // T is in the 4x4-tile layout of the register-resident inner kernel; knob "bt_old"
     unsigned long long *stamps;   // diagnostic build only (knob "bt_stamps"): per-wave cycle sums per pivot segment
+    double *xbuf;                 // multi-workgroup block kernel: exchange records in HBM (btg_kernels.hip)
+    int32_t groups, group_ri;     // its workgroup count (0: single-workgroup kernels) and rows / columns per thread
 };
+
+// shape of the multi-workgroup block kernel for a tableau (btg_kernels.hip): groups == 0 -> single-workgroup kernels
+struct BtGroupCfg { int groups, nt, ri; };
 
 // ---- device-batched relaxations (batch_kernels.hip, engine_batch.cpp) ------------------------------------------------
 // One BatchLP per relaxation of a wave, resident in HBM.  `bt` is the argument block of the block kernels for the

@@ -49,6 +49,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "blocked") blocked_ = v ? 1 : 0;
     else if (key == "bt_nt") { if (v != 0 && v != 256 && v != 512 && v != 1024) return GOMILP_ERR_BAD_SHAPE; bt_nt_ = v; }
     else if (key == "bt_old") bt_old_ = v ? 1 : 0;
+    else if (key == "bt_groups") { if (v != -1 && v != 0 && v != 2 && v != 4 && v != 8) return GOMILP_ERR_BAD_SHAPE; bt_groups_ = v; }
     else if (key == "bt_stamps") bt_stamps_ = v ? 1 : 0;
     else if (key == "cond_guard") cond_guard_ = v ? 1 : 0;
     else if (key == "block_k") { if (v < 0 || v > bt_max_k()) return GOMILP_ERR_BAD_SHAPE; block_k_ = v; }
@@ -1056,6 +1057,10 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
             const size_t cap = (size_t)bt_max_k() * (size_t)std::max(w.cap_ld, P.ld);
             HIP_TRY(dmalloc(&w.btU, cap));
             w.cap_btU = cap;
+        }
+        if (use_bt_ && !w.xbuf) {   // exchange records of the multi-workgroup block kernel: zero = no exchange has happened
+            HIP_TRY(dmalloc(&w.xbuf, bt_xbuf_doubles()));
+            HIP_TRY(hipMemsetAsync(w.xbuf, 0, bt_xbuf_doubles() * sizeof(double), stream_));
         }
         if (!use_bt_) {   // the blocked kernels never read the padding of r
             HIP_TRY(hipMemsetAsync(w.R[0], 0, (size_t)w.cap_ldt * sizeof(double), stream_));

@@ -105,6 +105,8 @@ class Engine {
                       const std::vector<double> *binv_host);
     void bt_layout(const Problem &P, bool tiled);
     BTArgs make_bt_args(const Problem &P, int phase, double tol, int nn, int kmax);
+    // block size and tableau layout of the blocked pipeline for the current ldt_ (knobs block_k / bt_nt / bt_old / bt_groups)
+    void bt_plan(const Problem &P, int *K, bool *tiled) const;
     int bt_forced_pivot(const Problem &P, int phase, double tol, int nn, int q, int p, int nocommit);
     int run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_lp_stats *st);
     void account_samples(gomilp_lp_stats *st, const std::vector<int64_t> &sample_t, int64_t executed, int nk);
@@ -133,7 +135,7 @@ class Engine {
     std::unique_ptr<Work> w_;
     // knobs
     int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 2, tableau_ = 1, blocked_ = 1, block_k_ = 0,  // block_k_ 0 = auto
-            bt_nt_ = 0, bt_old_ = 0, bt_stamps_ = 0,
+            bt_nt_ = 0, bt_old_ = 0, bt_stamps_ = 0, bt_groups_ = 0,   // bt_groups_: -1 never, 0 by shape, 2 / 4 / 8 forced
             cond_guard_ = 1;   // replay the condition guards of the reference on the host for bases of up to 64 rows
     bool shadow_trace_ = false;   // this solve records its pivots for the replay even when the caller did not ask for a trace   // developer knobs of the block kernels (per context: tests force the 1024-thread instance)
     // per-solve state
@@ -195,6 +197,11 @@ bool bt_supported(int m, int nn);
 int bt_max_k();
 int bt_reg_k(int m, int ldt, int nt_force);
 bool bt_tiled(int m, int ldt, int kmax, int nt_force, bool old_only);
+// btg_kernels.hip: the block kernel over G workgroups of one XCD
+BtGroupCfg bt_group_cfg(int m, int ldt, int knob);
+size_t bt_xbuf_doubles();
+void launch_bt_inner_groups(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+const char *bt_group_kernel_name(int G, int ri);
 constexpr int kBtStampSegs = 16;   // cycle sums per wave written by the diagnostic build of k_bt_inner2
 void launch_bt_tile(const double *src, double *dst, int m, int ldt, bool to_tiles, hipStream_t s);
 void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);

@@ -196,6 +196,18 @@ void Engine::bt_layout(const Problem &P, bool tiled) {
     t_tiled_ = tiled;
 }
 
+void Engine::bt_plan(const Problem &P, int *K, bool *tiled) const {
+    const BtGroupCfg gc = bt_old_ ? BtGroupCfg{0, 0, 0} : bt_group_cfg(P.m, ldt_, (int)bt_groups_);
+    if (gc.groups) {   // multi-workgroup block kernel: 16 terms per row / column in registers, tiled layout
+        *K = block_k_ > 0 ? (int)std::min<int64_t>(block_k_, 16) : 16;
+        *tiled = true;
+        return;
+    }
+    // block size: 8 when the block's rank-1 terms fit in registers (bt_kernels.hip), else 16
+    *K = block_k_ > 0 ? (int)block_k_ : (bt_reg_k(P.m, ldt_, (int)bt_nt_) > 0 ? 8 : 16);
+    *tiled = bt_tiled(P.m, ldt_, *K, (int)bt_nt_, bt_old_ != 0);
+}
+
 BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int kmax) {
     Work &w = *w_;
     BTArgs a;
@@ -208,6 +220,10 @@ BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int
     a.forced_q = a.forced_p = -1; a.forced_nocommit = 0;
     a.nt_force = (int)bt_nt_; a.old_only = bt_old_ ? 1 : 0;
     a.stamps = bt_stamps_ ? w.stamps : nullptr;
+    if (a.tiled && !bt_old_) {
+        const BtGroupCfg gc = bt_group_cfg(P.m, ldt_, (int)bt_groups_);
+        a.groups = gc.groups; a.group_ri = gc.ri; a.xbuf = w.xbuf;
+    }
     return a;
 }
 
@@ -217,7 +233,7 @@ int Engine::bt_forced_pivot(const Problem &P, int phase, double tol, int nn, int
     DevState &hs = *w.st_host;
     hs.done = 0; hs.status = ST_RUNNING; hs.kdone = 0;
     sync_state_to_device();
-    bt_layout(P, bt_tiled(P.m, ldt_, 1, (int)bt_nt_, bt_old_ != 0));
+    { int K1; bool tiled1; bt_plan(P, &K1, &tiled1); bt_layout(P, tiled1 || bt_tiled(P.m, ldt_, 1, (int)bt_nt_, bt_old_ != 0)); }
     BTArgs a = make_bt_args(P, phase, tol, nn, 1);
     a.forced_q = q; a.forced_p = p; a.forced_nocommit = nocommit;
     launch_bt_inner(a, stream_, nullptr, nullptr);
@@ -242,9 +258,9 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
     }
     const double t_loop0 = now_s();
     int ret = GOMILP_OK;
-    // block size: 8 when the block's rank-1 terms fit in registers (bt_kernels.hip), else 16
-    const int K = block_k_ > 0 ? (int)block_k_ : (bt_reg_k(P.m, ldt_, (int)bt_nt_) > 0 ? 8 : 16);
-    bt_layout(P, bt_tiled(P.m, ldt_, K, (int)bt_nt_, bt_old_ != 0));
+    int K; bool tiled_plan;
+    bt_plan(P, &K, &tiled_plan);
+    bt_layout(P, tiled_plan);
     const int64_t blocks_per_chunk = std::max<int64_t>(1, chunk_ / K);
     const bool sampling = sample_events_ > 0;
     int64_t block_no = 0;
@@ -326,6 +342,8 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
         if (hs.status == ST_OPTIMAL) break;
         if (hs.status == ST_UNBOUNDED) { ret = GOMILP_ERR_UNBOUNDED; break; }
         if (hs.status == ST_BLAND_FAILED) { ret = GOMILP_ERR_BLAND; break; }
+        if (hs.status == ST_XCHG_TIMEOUT && w.xbuf)   // records of the abandoned exchange must not meet a later launch
+            hipMemsetAsync(w.xbuf, 0, bt_xbuf_doubles() * sizeof(double), stream_);
         ret = GOMILP_ERR_DEVICE;
         break;
     }
@@ -339,7 +357,7 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
         fprintf(stderr, "{\"bt_stamps\": {\"m\": %d, \"nn\": %d, \"phase\": %d, \"pivots\": %llu, \"cycles_per_pivot_by_wave\": [", P.m, nn, phase, np);
         for (int wv = 0; wv < 16; wv++) {
             fprintf(stderr, "%s[", wv ? ", " : "");
-            for (int sg = 0; sg < 11; sg++) fprintf(stderr, "%s%.1f", sg ? ", " : "", np ? (double)w.stamps_host[wv * kBtStampSegs + sg] / (double)np : 0.0);
+            for (int sg = 0; sg < 13; sg++) fprintf(stderr, "%s%.1f", sg ? ", " : "", np ? (double)w.stamps_host[wv * kBtStampSegs + sg] / (double)np : 0.0);
             fprintf(stderr, "]");
         }
         fprintf(stderr, "]}}\n");
@@ -376,16 +394,14 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         ldt_ = tab_ld(nn);
         if (!binv_host) {  // slack basis: B^-1 is the permutation rho
             // straight into the layout the block kernels want: no conversion pass before the first pivot
-            const int kr0 = bt_reg_k(P.m, ldt_, (int)bt_nt_);
-            t_tiled_ = use_bt_ && bt_tiled(P.m, ldt_, block_k_ > 0 ? (int)block_k_ : (kr0 > 0 ? 8 : 16), (int)bt_nt_, bt_old_ != 0);
+            { int K0; bool tl0; bt_plan(P, &K0, &tl0); t_tiled_ = use_bt_ && tl0; }
             launch_tab_gather(P.dAt, P.ld, m, nn, w.nonbasic, w.rho, w.T[0], ldt_, t_tiled_, stream_);
             launches_++;
             return GOMILP_OK;
         }
         // general basis: B^-1 from the host (engine_general.cpp), T = B^-1 A_N as a device GEMM over the resident columns
         // (At row n holds the Phase-I artificial column); straight into the layout the block kernels want
-        const int kr0 = bt_reg_k(P.m, ldt_, (int)bt_nt_);
-        t_tiled_ = use_bt_ && bt_tiled(P.m, ldt_, block_k_ > 0 ? (int)block_k_ : (kr0 > 0 ? 8 : 16), (int)bt_nt_, bt_old_ != 0);
+        { int K0; bool tl0; bt_plan(P, &K0, &tl0); t_tiled_ = use_bt_ && tl0; }
         if (!binv_on_device) {
             HIP_TRY(hipMemcpy2DAsync(w.binv[0], (size_t)P.ld * sizeof(double), binv_host->data(), (size_t)m * sizeof(double), (size_t)m * sizeof(double), m,
                                      hipMemcpyHostToDevice, stream_));

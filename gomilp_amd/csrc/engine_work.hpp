@@ -70,6 +70,7 @@ struct Engine::Work {
     double *pd_ratio = nullptr, *px_ratio = nullptr;
     double *T[2] = {nullptr, nullptr}, *R[2] = {nullptr, nullptr}, *tscratch = nullptr;  // tableau pipelines
     double *btU = nullptr, *btV = nullptr;  // blocked tableau: rank-1 terms of the running block
+    double *xbuf = nullptr;                 // multi-workgroup block kernel: exchange records (btg_kernels.hip)
     int32_t *srcpos = nullptr;
     int32_t *unitrow = nullptr;  // final solve: unit-column rows per basis position
     int32_t *denseflag = nullptr, *dlist = nullptr;  // final solve: steps that did arithmetic / their compact list
@@ -120,7 +121,7 @@ struct Engine::Work {
         for (auto **p : {&pi_price, &pi_ratio, &lpl[0], &lpl[1], &lpr[0], &lpr[1], &pv_price, &pb_ratio}) { if (*p) hipFree(*p); *p = nullptr; }
         if (pd_ratio) hipFree(pd_ratio); pd_ratio = nullptr;
         if (px_ratio) hipFree(px_ratio); px_ratio = nullptr;
-        for (double **p : {&T[0], &T[1], &R[0], &R[1], &tscratch, &btU, &btV}) { if (*p) hipFree(*p); *p = nullptr; }
+        for (double **p : {&T[0], &T[1], &R[0], &R[1], &tscratch, &btU, &btV, &xbuf}) { if (*p) hipFree(*p); *p = nullptr; }
         if (srcpos) hipFree(srcpos); srcpos = nullptr;
         cap_T = 0; cap_ldt = 0; cap_btU = 0;
         if (stamps) hipFree(stamps); stamps = nullptr;
