@@ -332,8 +332,8 @@ def main() -> int:
         nblocks = max(ksec[1], 1.0)
         K = ksec[3] / nblocks if ksec[1] > 0 else 8.0
         t_inner, t_upd = ksec[0] / nblocks, ksec[2] / nblocks
-        inner_name = "k_bt_inner2<512,4,4,8,0>" if (tiled and m > 1024) else ("k_bt_inner2<512,2,2,8,0>" if tiled else "k_bt_inner<1024,%d,%d,0>" % ((m + 1023) // 1024, (nn + 1023) // 1024))
-        upd_name = "k_bt_update_tiled<8>" if tiled else "k_bt_update<16>"
+        inner_name = "k_bt_inner2<512,4,4,8,0>" if (tiled and m > 1024) else ("k_bt_inner2<512,2,2,8,0>" if tiled else "k_bt_innerG<8,512,%d,16>" % (1 if max(m, nn) <= 4096 else 2))
+        upd_name = "k_bt_update_tiled<8>" if tiled else "k_bt_update_tiled<16>"
         # byte model of THIS pipeline, per block of K pivots: the inner kernel reads one column and one row of T per pivot and
         # writes u_k, v_k' (8 B each) + loads / stores r, x_B and the index lists once per launch; the update reads and
         # writes T once
@@ -456,8 +456,10 @@ def main() -> int:
                      "inner_us_per_launch": 1e6 * k4[0] / nb4, "update_us_per_launch": 1e6 * k4[2] / nb4, "pivots_per_launch": k4[3] / nb4,
                      "update_GBs": 16.0 * m4 * m4 / (k4[2] / nb4) / 1e9 if k4[2] > 0 else 0.0,
                      "update_frac_of_hbm_peak": 16.0 * m4 * m4 / (k4[2] / nb4) / 1e9 / HBM_PEAK_GBS if k4[2] > 0 else 0.0,
-                     "note": "the 134 MB tableau (x2 with the second buffer) no longer fits the Infinity Cache with everything else: the update runs at the HBM rate; "
-                             "row-major k_bt_inner, K = 16 (the block terms of 4096 rows do not fit one CU's registers)"}
+                     "inner_kernel": "k_bt_innerG<8,512,1,16>",
+                     "note": "the 134 MB tableau no longer fits the Infinity Cache with everything else: the update runs at the HBM rate; block kernel = 8 workgroups "
+                             "of one XCD, two L2 exchanges per pivot, K = 16 terms per row / column in registers (btg_kernels.hip); the single-workgroup "
+                             "k_bt_inner (knob bt_groups = -1) needs 295 us per 16 pivots at this size"}
         p4.free()
         cx4.close()
         del c4, A4, b4

@@ -456,6 +456,11 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
     }
 }
 
+// Tried and dropped (round 2): every participant ONE wave on its own CU (no barrier, no LDS hop; terms in LDS by position,
+// prefetched under the load latency).  Bit-identical results, but slower at 2048 rows: 8 waves x 4 rows 107.7 us per 16
+// pivots, 16 waves x 2 rows 97.0 us, against 80.2 us for 4 workgroups of 8 waves: one wave issues its ~1500 instructions
+// per pivot alone on a SIMD, and an exchange among 16 participants waits for the slowest of 16.
+
 // ---- host side ---------------------------------------------------------------------------------
 size_t bt_xbuf_doubles() { return (size_t)kXHeader + (size_t)2 * 8 * kXSlots * 2; }
 

@@ -222,7 +222,7 @@ BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int
     a.stamps = bt_stamps_ ? w.stamps : nullptr;
     if (a.tiled && !bt_old_) {
         const BtGroupCfg gc = bt_group_cfg(P.m, ldt_, (int)bt_groups_);
-        a.groups = gc.groups; a.group_ri = gc.ri; a.xbuf = w.xbuf;
+        a.groups = gc.groups; a.group_ri = gc.ri; a.group_nt = gc.nt; a.xbuf = w.xbuf;
     }
     return a;
 }

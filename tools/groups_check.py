@@ -11,13 +11,14 @@ def t5(piv):
     return a[:, [0, 2, 3, 4, 5]]
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
+knobs = [int(v) for v in sys.argv[2:]]
 bad = 0
 if what in ("small", "all"):
     for m, seed in ((64, 5), (128, 7), (256, 7), (512, 3)):
         c, A, b = synth.dense_lp_standard_form(m, seed)
         o = O.simplex(c, A, b, 0.0, None, fast_initial_basis=True, trace=True)
         mask = synth.integrality_mask(m, m)
-        for G in (2, 4, 8):
+        for G in (knobs or (2, 4, 8)):
             cx = lp.Context(bt_groups=G)
             root = cx.upload(c, A, b)
             g = root.solve(0.0, trace=True)
@@ -40,7 +41,7 @@ if what in ("M", "all"):
     fx = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "lp_M.npz"))
     m, seed = synth.CONFIGS["M"]
     c, A, b = synth.dense_lp_standard_form(m, seed)
-    for G in (4, 8, 2):
+    for G in (knobs or (4, 8, 2)):
         cx = lp.Context(bt_groups=G, sample_events=64, chunk=64)
         p = cx.upload(c, A, b)
         r = p.solve(0.0, trace=True)
@@ -58,7 +59,7 @@ if what in ("C4",):
     fx = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "lp_C4_prefix.npz"))
     m, seed = synth.CONFIGS["C4"]
     c, A, b = synth.dense_lp_standard_form(m, seed)
-    for G in (8, 0):
+    for G in (knobs or (8, 0)):
         cx = lp.Context(bt_groups=G if G else -1, sample_events=64, chunk=64)
         p = cx.upload(c, A, b)
         r = p.solve(0.0, trace=True)
