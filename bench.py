@@ -326,14 +326,15 @@ def main() -> int:
     pipeline = last.stats["pipeline"]
 
     # ---- roofline: the kernel with the largest share of the timed region, then the loop, then the streaming kernel alone
-    tiled = m <= 2048 and nn <= 2048
     bytes_pivot_survey = 8.0 * (m * nn + 3.0 * m * m)      # SURVEY.md §8d per-unit figure (explicit-inverse model)
     if pipeline == "blocked":
         nblocks = max(ksec[1], 1.0)
         K = ksec[3] / nblocks if ksec[1] > 0 else 8.0
         t_inner, t_upd = ksec[0] / nblocks, ksec[2] / nblocks
-        inner_name = "k_bt_inner2<512,4,4,8,0>" if (tiled and m > 1024) else ("k_bt_inner2<512,2,2,8,0>" if tiled else "k_bt_innerG<8,512,%d,16>" % (1 if max(m, nn) <= 4096 else 2))
-        upd_name = "k_bt_update_tiled<8>" if tiled else "k_bt_update_tiled<16>"
+        need = max(m, nn)
+        inner_name = ("k_bt_inner2<512,2,2,8,0>" if need <= 1024 else "k_bt_innerG<8,256,1,16>" if need <= 2048 else
+                      "k_bt_innerG<8,512,%d,16>" % (1 if need <= 4096 else 2))
+        upd_name = "k_bt_update_tiled<8>" if need <= 1024 else "k_bt_update_tiled<16>"
         # byte model of THIS pipeline, per block of K pivots: the inner kernel reads one column and one row of T per pivot and
         # writes u_k, v_k' (8 B each) + loads / stores r, x_B and the index lists once per launch; the update reads and
         # writes T once
@@ -341,13 +342,14 @@ def main() -> int:
         bytes_update = 16.0 * m * nn
         block_s = loop_s / max(pivots / K, 1.0)   # wall time of the loop per block: kernels + boundaries + the host's chunk waits
         share_inner = t_inner / max(t_inner + t_upd, 1e-30)
-        traffic, tsrc = newest_pmc("k_bt_inner2")
+        traffic, tsrc = newest_pmc(inner_name.split("<")[0] + "<")
         roofline = {
             "bound": "latency", "kernel": inner_name, "time_share": share_inner * loop_s / dt,
             "achieved": bytes_inner / t_inner / 1e9 if t_inner > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "traffic": traffic, "traffic_source": tsrc,
             "bytes_per_launch": bytes_inner, "avg_launch_us": 1e6 * t_inner, "us_per_pivot": 1e6 * t_inner / K, "pivots_per_launch": K,
-            "note": "single-workgroup kernel (1 of 256 CUs): two workgroup-wide first-index argmins and two dependent tableau reads per "
+            "note": ("single-workgroup kernel (1 of 256 CUs)" if need <= 1024 else "8 workgroups of one XCD (8 of 256 CUs), two exchanges through that XCD's L2 per pivot") +
+                    ": two first-index argmins over all columns / rows and two dependent tableau reads per "
                     "pivot; its roof is the dependent-latency chain, not HBM bandwidth — `frac` is reported against the HBM peak all the same",
             "loop": {"bytes_per_block": bytes_inner + bytes_update, "block_us": 1e6 * block_s,
                      "kernel_us_per_block": 1e6 * (t_inner + t_upd), "achieved_GBs": (bytes_inner + bytes_update) / block_s / 1e9,

@@ -477,9 +477,11 @@ BtGroupCfg bt_group_cfg(int m, int ldt, int knob) {
         return c;
     }
     if (knob != 0) return c;
-    // up to 2048 rows the single-workgroup kernel is as fast (measured at 2048 x 2048: 80 us per 16 pivots with G = 4 against
-    // 37 us per 8 with k_bt_inner2: the exchanges cost what the shorter loads and corrections save)
-    if (need <= 2048) return c;
+    // measured per 16 pivots at 2048 x 2048 (MI355X): 8 workgroups x 256 threads 70.9 us, 4 x 512 80.2, 4 x 256 x 2 rows 75.9,
+    // 8 x 128 x 2 rows 87.1, 2 x 512 x 2 rows 91.2 — against 2 x 37.2 us of k_bt_inner2<512,4,4,8> and a rank-8 update more
+    // per 16 pivots; at 4096 x 4096: 8 x 512 83.9 us, 8 x 256 x 2 rows 95.1.  One row + one column per thread, 8 workgroups.
+    if (need <= 1024) return c;   // one workgroup holds these (k_bt_inner2<512,2,2,8>: 3.1 us per pivot)
+    if (need <= 2048) return {8, 256, 1};
     if (need <= 4096) return {8, 512, 1};
     if (need <= 8192) return {8, 512, 2};
     return c;
@@ -494,11 +496,12 @@ static void btg_launch(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t
 }
 void launch_bt_inner_groups(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const int G = a.groups, ri = a.group_ri;
+    if (a.group_nt == 256) { btg_launch<8, 256, 1>(a, s, e0, e1); return; }
     if (G == 2) { if (ri == 1) btg_launch<2, 512, 1>(a, s, e0, e1); else btg_launch<2, 512, 2>(a, s, e0, e1); }
     else if (G == 4) { if (ri == 1) btg_launch<4, 512, 1>(a, s, e0, e1); else btg_launch<4, 512, 2>(a, s, e0, e1); }
     else { if (ri == 1) btg_launch<8, 512, 1>(a, s, e0, e1); else btg_launch<8, 512, 2>(a, s, e0, e1); }
 }
-const char *bt_group_kernel_name(int G, int ri) {
+const char *bt_group_kernel_name(int G, int ri) {   // (512-thread instances)
     static const char *names[3][2] = {{"k_bt_innerG<2,512,1,16>", "k_bt_innerG<2,512,2,16>"}, {"k_bt_innerG<4,512,1,16>", "k_bt_innerG<4,512,2,16>"},
                                       {"k_bt_innerG<8,512,1,16>", "k_bt_innerG<8,512,2,16>"}};
     return names[G == 2 ? 0 : G == 4 ? 1 : 2][ri == 1 ? 0 : 1];

@@ -24,10 +24,10 @@ with open("profiles/%s_pmc_counters.csv" % tag, "w") as out:
     out.write("kernel,launches,FETCH_SIZE_mean_KB_raw,WRITE_SIZE_mean_KB\n")
     for k, n, fk, wk in rows: out.write('"%s",%d,%.3f,%.3f\n' % (k, n, fk, wk))
 m, nn = 2048, 2048
-alg = {"k_bt_update_tiled<8>": 16.0 * m * nn, "k_bt_inner2<512, 4": 8 * 16.0 * (m + nn) + 24.0 * (m + nn)}
+alg = {"k_bt_update_tiled<16>": 16.0 * m * nn, "k_bt_innerG<8, 256": 16 * 16.0 * (m + nn) + 24.0 * (m + nn)}
 docs = []
-for key, note in (("k_bt_update_tiled<8>", "streaming rank-8 update: 16-byte coalesced loads and stores, the calibrated shape"),
-                  ("k_bt_inner2<512, 4", "single-workgroup block kernel: 8-byte reads of 128-byte tile lines (one column + one row of T per pivot); FETCH_SIZE is "
+for key, note in (("k_bt_update_tiled<16>", "streaming rank-16 update: 16-byte coalesced loads and stores, the calibrated shape"),
+                  ("k_bt_innerG<8, 256", "block kernel, 8 workgroups of one XCD: 8-byte reads of 128-byte tile lines (one column + one row of T per pivot) + the exchange records; FETCH_SIZE is "
                                        "UNCALIBRATED for this shape (MI355X_MICROARCH.md: only wide coalesced reads are known to report 1/2) — the x2 figure is an upper bound"),
                   ("k_bt_inner2_batch", "batched block kernel (C5 wave): mean over launches with 1..256 active relaxations"),
                   ("k_bt_update_tiled_batch", "batched rank-8 update (C5 wave): mean over launches with 1..256 active relaxations")):
