@@ -79,8 +79,6 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
     static_assert(G == 2 || G == 4 || G == 8, "G");
     static_assert(KR + 3 <= kXSlots - 2, "payload");
     const int g = (int)(blockIdx.x >> 3);
-    __shared__ double xb_s[RI * NT], r_s[RI * NT];   // slots only their owner thread touches
-    __shared__ int basic_s[RI * NT], nonbasic_s[RI * NT];
     __shared__ double redM[16];
     __shared__ unsigned int redI[16];
     __shared__ double pay[16][KR + 3];
@@ -110,15 +108,15 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
     const char *Tb = reinterpret_cast<const char *>(a.T);
     auto ldT = [&](unsigned int elem) -> double { return *reinterpret_cast<const double *>(Tb + (elem << 3)); };
     auto gidx = [&](int s) -> int { return (s * G + g) * NT + tid; };   // row / column index of this thread's slot s
-    double x0[RI], r0[RI];
-    int b0[RI], n0[RI];
+    double xbv[RI], rv[RI];   // x_B, r and the index lists of this thread's rows / columns: registers
+    int basv[RI], nbasv[RI];
 #pragma unroll
     for (int s = 0; s < RI; s++) {
         const int i = gidx(s);
-        x0[s] = i < a.m ? a.xb[i] : 0.0;
-        b0[s] = i < a.m ? a.basic[i] : 0;
-        r0[s] = i < a.nn ? a.r[i] : inf;   // padding never wins an argmin
-        n0[s] = i < a.nn ? a.nonbasic[i] : 0;
+        xbv[s] = i < a.m ? a.xb[i] : 0.0;
+        basv[s] = i < a.m ? a.basic[i] : 0;
+        rv[s] = i < a.nn ? a.r[i] : inf;   // padding never wins an argmin
+        nbasv[s] = i < a.nn ? a.nonbasic[i] : 0;
     }
     if (done) {
         if (g == 0 && tid == 0) st->kdone = 0;
@@ -127,10 +125,6 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
     double ureg[RI][KR], vreg[RI][KR];
 #pragma unroll
     for (int s = 0; s < RI; s++) {
-        xb_s[s * NT + tid] = x0[s];
-        basic_s[s * NT + tid] = b0[s];
-        r_s[s * NT + tid] = r0[s];
-        nonbasic_s[s * NT + tid] = n0[s];
 #pragma unroll
         for (int j = 0; j < KR; j++) { ureg[s][j] = 0; vreg[s][j] = 0; }
     }
@@ -193,21 +187,32 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
                 if (++spins > kXSpinLimit) { s_dead = 1; break; }
             }
             stamp(which * 6 + 3);
-            // lexicographic minimum of (value, first index) over the G records; a NaN value never wins (v_min_f64)
-            double mg[G], ig[G];
+            // lexicographic minimum of (value, first index) over the G records; a NaN value never wins (v_min_f64).
+            // Lanes 0 / 32 of got[h] hold the values of records 2h / 2h + 1, lanes 1 / 33 their indices: minimum first, then
+            // the index of the record(s) that attain it (almost always one)
+            const bool slot0 = (lane & 31) == 0;
+            double xm = inf;
 #pragma unroll
-            for (int q2 = 0; q2 < G; q2++) {
-                mg[q2] = readlane_f64(got[q2 >> 1].y, (q2 & 1) * 32);
-                ig[q2] = readlane_f64(got[q2 >> 1].y, (q2 & 1) * 32 + 1);
+            for (int h = 0; h < H; h++) xm = vmin_f64(xm, slot0 ? got[h].y : inf);
+            const double bm = vmin_f64(readlane_f64(xm, 0), readlane_f64(xm, 32));
+            unsigned int cand = 0;
+#pragma unroll
+            for (int h = 0; h < H; h++) {
+                const unsigned long long mk = __ballot(slot0 && got[h].y == bm);
+                cand |= ((unsigned int)(mk & 1ull) << (2 * h)) | ((unsigned int)((mk >> 32) & 1ull) << (2 * h + 1));
             }
-            double bm = mg[0];
-#pragma unroll
-            for (int q2 = 1; q2 < G; q2++) bm = vmin_f64(bm, mg[q2]);
             double bi = 4294967295.0;
             int gw = 0;
+            while (cand) {
+                const int q2 = __builtin_ctz(cand);
+                cand &= cand - 1;
+                double gy = got[0].y;
 #pragma unroll
-            for (int q2 = 0; q2 < G; q2++)
-                if (mg[q2] == bm && ig[q2] < bi) { bi = ig[q2]; gw = q2; }
+                for (int h = 1; h < H; h++)
+                    if ((q2 >> 1) == h) gy = got[h].y;
+                const double ig = readlane_f64(gy, (q2 & 1) * 32 + 1);
+                if (ig < bi) { bi = ig; gw = q2; }
+            }
             double wval = got[0].y;
 #pragma unroll
             for (int h = 1; h < H; h++)
@@ -230,8 +235,8 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
 #pragma unroll
         for (int s = 0; s < RI; s++)
             if ((unsigned int)gidx(s) == w.i) {
-                pay[wv][0] = r_s[s * NT + tid];
-                pay[wv][1] = (double)nonbasic_s[s * NT + tid];
+                pay[wv][0] = rv[s];
+                pay[wv][1] = (double)nbasv[s];
 #pragma unroll
                 for (int j = 0; j < KR; j++) pay[wv][2 + j] = vreg[s][j];
             }
@@ -245,8 +250,8 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
         for (int s = 0; s < RI; s++)
             if ((unsigned int)gidx(s) == w.i) {
                 pay[wv][0] = dcol[s];
-                pay[wv][1] = xb_s[s * NT + tid];
-                pay[wv][2] = (double)basic_s[s * NT + tid];
+                pay[wv][1] = xbv[s];
+                pay[wv][2] = (double)basv[s];
 #pragma unroll
                 for (int j = 0; j < KR; j++) pay[wv][3 + j] = ureg[s][j];
             }
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
             const int i = gidx(s);
             double d = -dcol[s];
             if (fabs(d) < 1e-13) d = 0;
-            const double quot = div_pos(xb_s[s * NT + tid], fabs(d));
+            const double quot = div_pos(xbv[s], fabs(d));
             mvv[s] = (d >= 0 || i >= a.m) ? inf : quot;
         }
     };
@@ -287,9 +292,6 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
         if (!forced) {
             XWin fq;
             {
-                double rv[RI];
-#pragma unroll
-                for (int s = 0; s < RI; s++) rv[s] = r_s[s * NT + tid];
                 fq = reduce_cols(rv);
             }
             if (dead) break;
@@ -318,9 +320,9 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
 #pragma unroll
                     for (int s = 0; s < RI; s++) {
                         const int j = gidx(s);
-                        double rv = r_s[s * NT + tid];
-                        if (fabs(rv) < 1e-13) rv = 0;
-                        fl[s] = (j < a.nn && j > cand && !(rv > -1e-14)) ? 0.0 : inf;
+                        double rr = rv[s];
+                        if (fabs(rr) < 1e-13) rr = 0;
+                        fl[s] = (j < a.nn && j > cand && !(rr > -1e-14)) ? 0.0 : inf;
                     }
                     const XWin fc = reduce_cols(fl);
                     if (dead) break;
@@ -392,12 +394,12 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
             const int i = gidx(s);
             if (i < a.ldu) {
                 const double u = (i == p) ? rinv - 1.0 : dcol[s] * nrinv;
-                if (i < a.m) xb_s[s * NT + tid] = (i == p) ? theta : __builtin_fma(-theta, dcol[s], xb_s[s * NT + tid]);
+                if (i < a.m) xbv[s] = (i == p) ? theta : __builtin_fma(-theta, dcol[s], xbv[s]);
                 Uk[i] = u;
 #pragma unroll
                 for (int jj = KR - 1; jj > 0; jj--) ureg[s][jj] = ureg[s][jj - 1];
                 ureg[s][0] = u;
-                if (i == p && commit_lists) basic_s[s * NT + tid] = ent;
+                if (i == p && commit_lists) basv[s] = ent;
             }
         }
 #pragma unroll
@@ -407,13 +409,13 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
                 double v = vrow[s];
 #pragma unroll
                 for (int jj = 0; jj < KR; jj++) v = __builtin_fma(up[jj], vreg[s][jj], v);
-                r_s[s * NT + tid] = (j == q) ? -mult : __builtin_fma(-mult, v, r_s[s * NT + tid]);
+                rv[s] = (j == q) ? -mult : __builtin_fma(-mult, v, rv[s]);
                 const double vprime = (j == q) ? dpv + 1.0 : v;
                 Vk[j] = vprime;
 #pragma unroll
                 for (int jj = KR - 1; jj > 0; jj--) vreg[s][jj] = vreg[s][jj - 1];
                 vreg[s][0] = vprime;
-                if (j == q && commit_lists) nonbasic_s[s * NT + tid] = lea;
+                if (j == q && commit_lists) nbasv[s] = lea;
             }
         }
         if constexpr (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -439,10 +441,10 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
 #pragma unroll
     for (int s = 0; s < RI; s++) {
         const int i = gidx(s);
-        if (i < a.ldt) a.r[i] = i < a.nn ? r_s[s * NT + tid] : 0.0;
-        if (i < a.ldu) a.xb[i] = xb_s[s * NT + tid];
-        if (i < a.m) a.basic[i] = basic_s[s * NT + tid];
-        if (i < a.nn) a.nonbasic[i] = nonbasic_s[s * NT + tid];
+        if (i < a.ldt) a.r[i] = i < a.nn ? rv[s] : 0.0;
+        if (i < a.ldu) a.xb[i] = xbv[s];
+        if (i < a.m) a.basic[i] = basv[s];
+        if (i < a.nn) a.nonbasic[i] = nbasv[s];
     }
     if (tid == 0 && (g == 0 || dead)) {
         if (g == 0) {

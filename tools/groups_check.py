@@ -60,7 +60,7 @@ if what in ("C4",):
     m, seed = synth.CONFIGS["C4"]
     c, A, b = synth.dense_lp_standard_form(m, seed)
     for G in (knobs or (8, 0)):
-        cx = lp.Context(bt_groups=G if G else -1, sample_events=64, chunk=64)
+        cx = lp.Context(bt_groups=G, sample_events=64, chunk=64)
         p = cx.upload(c, A, b)
         r = p.solve(0.0, trace=True)
         want = fx["trace"][:, [0, 2, 3, 4, 5]].astype(np.int64)
