@@ -357,7 +357,7 @@ def main() -> int:
                      "model": "per block of K pivots: 16*m*(n-m) (rank-K update: T read + written once) + K*16*(m+n-m) + 24*(m+n-m) (block kernel)"},
             "streaming_kernel": {"bound": "hbm", "kernel": upd_name, "bytes_per_launch": bytes_update, "avg_launch_us": 1e6 * t_upd,
                                  "achieved": bytes_update / t_upd / 1e9 if t_upd > 0 else 0.0, "frac": bytes_update / t_upd / 1e9 / HBM_PEAK_GBS if t_upd > 0 else 0.0,
-                                 "traffic": newest_pmc("k_bt_update_tiled")[0], "traffic_source": newest_pmc("k_bt_update_tiled")[1],
+                                 "traffic": newest_pmc(upd_name.split("<")[0] + "<")[0], "traffic_source": newest_pmc(upd_name.split("<")[0] + "<")[1],
                                  "time_share": (1 - share_inner) * loop_s / dt,
                                  "note": "the %.1f MB tableau stays in the 256 MB Infinity Cache between launches: a MALL rate where it exceeds the ~6.3 TB/s HBM copy rate" % (8e-6 * m * nn)},
             "sampled_blocks": int(ksec[1]), "sampled_pivots": int(ksec[3]),
