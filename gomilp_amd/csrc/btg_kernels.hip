@@ -33,7 +33,7 @@ namespace gomilp {
 
 namespace {
 
-constexpr int kXSlots = 32;            // slots per record
+constexpr int kXSlots = 8;             // slots per record (one 128-byte line): min, first index, 3 scalars of the winner
 constexpr int kXHeader = 16;           // doubles in front of the records: [0] = exchanges completed so far
 constexpr int kXSpinLimit = 2000000;   // polls (~0.5 us each) before a launch gives up
 
@@ -51,21 +51,7 @@ template <> struct XLoad<1> {
         asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(p) : "memory");
     }
 };
-template <> struct XLoad<2> {
-    static __device__ __forceinline__ void run(const xpair *p, xpair (&v)[2]) {
-        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
-                     : "=&v"(v[0]), "=&v"(v[1]) : "v"(p) : "memory");
-    }
-};
-template <> struct XLoad<4> {
-    static __device__ __forceinline__ void run(const xpair *p, xpair (&v)[4]) {
-        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
-                     "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p) : "memory");
-    }
-};
-
-struct XWin { double m; unsigned int i; const double *pay; };   // winner of an exchange: value, first index, its payload
+struct XWin { double m; unsigned int i; double p0, p1, p2; };    // winner of an exchange: value, first index, its scalars
 struct BtWinG { double m; unsigned int i; };                   // a wave's own winner
 
 }  // namespace
@@ -75,15 +61,11 @@ template <int G, int NT, int RI, int KR, bool STAMP = false>
 __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
     if (blockIdx.x & 7u) return;
     constexpr int NW = NT / 64;
-    constexpr int H = G / 2;   // 64 lanes read two records per load
     static_assert(G == 2 || G == 4 || G == 8, "G");
-    static_assert(KR + 3 <= kXSlots - 2, "payload");
     const int g = (int)(blockIdx.x >> 3);
     __shared__ double redM[16];
     __shared__ unsigned int redI[16];
-    __shared__ double pay[16][KR + 3];
-    __shared__ double xres[2][2][kXSlots];   // [entering / leaving][sequence parity]: the winner's record
-    __shared__ int s_dead;
+    __shared__ double pay[16][4];
     // STAMP: diagnostic build (knob "bt_stamps"): cycles per pivot segment and wave of workgroup 0 (s_memtime), summed in LDS
     __shared__ unsigned long long s_acc[STAMP ? 16 : 1][16];
     unsigned long long tprev = 0;
@@ -107,6 +89,14 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
     const unsigned int ldt = (unsigned int)a.ldt;
     const char *Tb = reinterpret_cast<const char *>(a.T);
     auto ldT = [&](unsigned int elem) -> double { return *reinterpret_cast<const double *>(Tb + (elem << 3)); };
+    // block terms of OTHER workgroups' rows / columns come from the U / V rows of the running block in global memory:
+    // agent-scope (sc1) stores by the owner, agent-scope loads here — never a stale L1 line, correct on any XCD
+    auto ld_term = [&](const double *p) -> double {
+        return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    };
+    auto st_term = [&](double *p, double v) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     auto gidx = [&](int s) -> int { return (s * G + g) * NT + tid; };   // row / column index of this thread's slot s
     double xbv[RI], rv[RI];   // x_B, r and the index lists of this thread's rows / columns: registers
     int basv[RI], nbasv[RI];
@@ -128,7 +118,6 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
 #pragma unroll
         for (int j = 0; j < KR; j++) { ureg[s][j] = 0; vreg[s][j] = 0; }
     }
-    if (tid == 0) s_dead = 0;
     if constexpr (STAMP) { if (tid < 256) s_acc[tid >> 4][tid & 15] = 0; }
     __syncthreads();
     int kd = 0, status = ST_RUNNING, blands = 0;
@@ -150,15 +139,19 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
         }
         return w;
     };
-    // the exchange: in = this workgroup's per-wave results in redM / redI / pay; out = the winner over all G workgroups
+    // The exchange.  In: this workgroup's per-wave winners in redM / redI / pay.  Wave 0 reduces them and posts the
+    // workgroup's record; EVERY wave then polls the G records itself (one 16-byte load per lane: lane l reads slot l & 7 of
+    // record l >> 3), picks the winner with one wave-wide min and keeps its scalars as uniform values — no second barrier,
+    // no LDS hop.  A wave can pass the poll only after wave 0 has posted, i.e. after it has read redM / redI / pay, so the
+    // next reduction may overwrite them without another barrier.
     auto xchg = [&](int which) -> XWin {
-        stamp(which * 6 + 0);
+        stamp(which * 5 + 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's term stores have reached L2 / memory before the post
         __syncthreads();
-        stamp(which * 6 + 1);
+        stamp(which * 5 + 1);
         xs += 1;
         const double seqd = (double)xs;
         const int par = (int)(xs & 1);
-        double *res = &xres[which][par][0];
         if (wv == 0) {
             const double x = lane < NW ? redM[lane] : inf;
             const unsigned int ii = lane < NW ? redI[lane] : 0xFFFFFFFFu;
@@ -167,69 +160,47 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
             const unsigned int fi = (unsigned int)__builtin_amdgcn_readlane((int)row_min_u32(key), 15);
             const int ww = (int)((fi & (unsigned int)(NT - 1)) >> 6);
             if (lane < kXSlots) {
-                const int pl = lane < 2 ? 0 : (lane - 2 < KR + 3 ? lane - 2 : KR + 2);
                 xpair v;
                 v.x = seqd;
-                v.y = lane == 0 ? fm : lane == 1 ? (double)fi : pay[ww][pl];
+                v.y = lane == 0 ? fm : lane == 1 ? (double)fi : pay[ww][lane < 5 ? lane - 2 : 3];
                 xstore(recs + ((size_t)(par * G + g) * kXSlots + lane), v);
             }
             if constexpr (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            stamp(which * 6 + 2);
-            const xpair *src = recs + (size_t)par * G * kXSlots + lane;   // lane l: slot l & 31 of record (l >> 5) + 2h
-            xpair got[H];
-            int spins = 0;
-            for (;;) {
-                XLoad<H>::run(src, got);
-                bool ok = true;
-#pragma unroll
-                for (int h = 0; h < H; h++) ok = ok && (got[h].x == seqd);
-                if (__all(ok)) break;
-                if (++spins > kXSpinLimit) { s_dead = 1; break; }
-            }
-            stamp(which * 6 + 3);
-            // lexicographic minimum of (value, first index) over the G records; a NaN value never wins (v_min_f64).
-            // Lanes 0 / 32 of got[h] hold the values of records 2h / 2h + 1, lanes 1 / 33 their indices: minimum first, then
-            // the index of the record(s) that attain it (almost always one)
-            const bool slot0 = (lane & 31) == 0;
-            double xm = inf;
-#pragma unroll
-            for (int h = 0; h < H; h++) xm = vmin_f64(xm, slot0 ? got[h].y : inf);
-            const double bm = vmin_f64(readlane_f64(xm, 0), readlane_f64(xm, 32));
-            unsigned int cand = 0;
-#pragma unroll
-            for (int h = 0; h < H; h++) {
-                const unsigned long long mk = __ballot(slot0 && got[h].y == bm);
-                cand |= ((unsigned int)(mk & 1ull) << (2 * h)) | ((unsigned int)((mk >> 32) & 1ull) << (2 * h + 1));
-            }
-            double bi = 4294967295.0;
-            int gw = 0;
-            while (cand) {
-                const int q2 = __builtin_ctz(cand);
-                cand &= cand - 1;
-                double gy = got[0].y;
-#pragma unroll
-                for (int h = 1; h < H; h++)
-                    if ((q2 >> 1) == h) gy = got[h].y;
-                const double ig = readlane_f64(gy, (q2 & 1) * 32 + 1);
-                if (ig < bi) { bi = ig; gw = q2; }
-            }
-            double wval = got[0].y;
-#pragma unroll
-            for (int h = 1; h < H; h++)
-                if ((gw >> 1) == h) wval = got[h].y;
-            if ((lane >> 5) == (gw & 1)) res[lane & 31] = wval;
-            stamp(which * 6 + 4);
         }
-        __syncthreads();
-        stamp(which * 6 + 5);
-        if (s_dead) dead = true;
+        stamp(which * 5 + 2);
+        const bool act = lane < G * kXSlots;
+        const xpair *src = recs + (size_t)par * G * kXSlots + (act ? lane : 0);
+        xpair got[1];
+        int spins = 0;
+        for (;;) {
+            XLoad<1>::run(src, got);
+            if (__all(!act || got[0].x == seqd)) break;
+            if (++spins > kXSpinLimit) { dead = true; break; }
+        }
+        stamp(which * 5 + 3);
+        // lexicographic minimum of (value, first index) over the G records; a NaN value never wins (v_min_f64)
+        const bool slot0 = act && (lane & (kXSlots - 1)) == 0;
+        const double val = got[0].y;
+        const double bm = wave_min_f64(slot0 ? val : inf);
+        unsigned long long mk = __ballot(slot0 && val == bm);
+        double bi = 4294967295.0;
+        int gl = 0;   // lane of the winner's slot 0
+        while (mk) {
+            const int l0 = (int)__builtin_ctzll(mk);
+            mk &= mk - 1;
+            const double ig = readlane_f64(val, l0 + 1);
+            if (ig < bi) { bi = ig; gl = l0; }
+        }
         XWin r;
-        r.m = res[0];
-        r.i = (unsigned int)res[1];
-        r.pay = res + 2;
+        r.m = bm;
+        r.i = (unsigned int)bi;
+        r.p0 = readlane_f64(val, gl + 2);
+        r.p1 = readlane_f64(val, gl + 3);
+        r.p2 = readlane_f64(val, gl + 4);
+        stamp(which * 5 + 4);
         return r;
     };
-    // entering column: (min, q); r_q, the entering variable and v'_k[q] (newest first) in the winner's payload
+    // entering column: (min, q); payload r_q, the entering variable
     auto reduce_cols = [&](const double (&val)[RI]) -> XWin {
         const BtWinG w = wave_first_min(val);
 #pragma unroll
@@ -237,13 +208,11 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
             if ((unsigned int)gidx(s) == w.i) {
                 pay[wv][0] = rv[s];
                 pay[wv][1] = (double)nbasv[s];
-#pragma unroll
-                for (int j = 0; j < KR; j++) pay[wv][2 + j] = vreg[s][j];
             }
         if (lane == 0) { redM[wv] = w.m; redI[wv] = w.i; }
         return xchg(0);
     };
-    // leaving row: (min, p); d_p, x_B[p], the leaving variable and u_k[p]
+    // leaving row: (min, p); payload d_p, x_B[p], the leaving variable
     auto reduce_rows = [&](const double (&val)[RI], const double (&dcol)[RI]) -> XWin {
         const BtWinG w = wave_first_min(val);
 #pragma unroll
@@ -252,21 +221,28 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
                 pay[wv][0] = dcol[s];
                 pay[wv][1] = xbv[s];
                 pay[wv][2] = (double)basv[s];
-#pragma unroll
-                for (int j = 0; j < KR; j++) pay[wv][3 + j] = ureg[s][j];
             }
         if (lane == 0) { redM[wv] = w.m; redI[wv] = w.i; }
         return xchg(1);
     };
-    auto column = [&](int q, const double *vq, double (&dcol)[RI]) {
+    // column q of the current tableau for this thread's rows; v'_j[q] of the block's k earlier pivots (newest first) from V
+    auto column = [&](int q, int k, double (&dcol)[RI]) {
+        double d0[RI];
 #pragma unroll
         for (int s = 0; s < RI; s++) {
             const int i = gidx(s);
             const unsigned int ic = (unsigned int)(i < a.m ? i : a.m - 1);
-            double d = ldT(tile_off_g(ic, (unsigned int)q, ldt));
+            d0[s] = ldT(tile_off_g(ic, (unsigned int)q, ldt));
+        }
+        double vq[KR];
+#pragma unroll
+        for (int jj = 0; jj < KR; jj++) vq[jj] = jj < k ? ld_term(a.V + (size_t)(k - 1 - jj) * a.ldt + q) : 0.0;
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            double d = d0[s];
 #pragma unroll
             for (int j = 0; j < KR; j++) d = __builtin_fma(ureg[s][j], vq[j], d);
-            dcol[s] = i < a.m ? d : 0.0;
+            dcol[s] = gidx(s) < a.m ? d : 0.0;
         }
     };
     // ratio vector (simplex.go:321-340), branch-free as in k_bt_inner2
@@ -286,19 +262,15 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
         const bool forced = (k == 0 && a.forced_q >= 0);
         int q, p, ent = 0, lea = 0;
         double rq = 0, dpv = 1.0, xbp = 0;
-        const double *vq, *up;
         bool bland = false;
         double dcol[RI];
         if (!forced) {
-            XWin fq;
-            {
-                fq = reduce_cols(rv);
-            }
+            const XWin fq = reduce_cols(rv);
             if (dead) break;
-            q = (int)fq.i; rq = fq.pay[0]; ent = (int)fq.pay[1]; vq = fq.pay + 2;
+            q = (int)fq.i; rq = fq.p0; ent = (int)fq.p1;
             if (fq.i >= (unsigned int)a.nn) { q = 0; rq = __builtin_nan(""); }   // every r_j is NaN: MinIdx returns 0
             if (rq >= -a.tol) { status = ST_OPTIMAL; break; }                    // simplex.go:248
-            column(q, vq, dcol);
+            column(q, k, dcol);
             XWin w;
             {
                 double mvv[RI];
@@ -306,7 +278,7 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
                 w = reduce_rows(mvv, dcol);
             }
             if (dead) break;
-            p = (int)w.i; dpv = w.pay[0]; xbp = w.pay[1]; lea = (int)w.pay[2]; up = w.pay + 3;
+            p = (int)w.i; dpv = w.p0; xbp = w.p1; lea = (int)w.p2;
             const double mv = w.m;
             if (mv == inf || w.i >= (unsigned int)a.m) { status = ST_UNBOUNDED; break; }   // simplex.go:328-330
             if (mv <= 0) {
@@ -328,9 +300,9 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
                     if (dead) break;
                     if (fc.m != 0.0) break;   // candidates exhausted -> ErrBland
                     cand = (int)fc.i;
-                    const double rqc = fc.pay[0];
-                    const int entc = (int)fc.pay[1];
-                    column(cand, fc.pay + 2, dcol);
+                    const double rqc = fc.p0;
+                    const int entc = (int)fc.p1;
+                    column(cand, k, dcol);
                     XWin w2;
                     {
                         double mvv[RI];
@@ -340,18 +312,18 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
                     if (dead) break;
                     if (w2.m == inf || w2.i >= (unsigned int)a.m) { status = ST_UNBOUNDED; break; }   // :356-360
                     if (fabs(w2.m) > 1e-12) {   // :362
-                        q = cand; p = (int)w2.i; rq = rqc; ent = entc; dpv = w2.pay[0]; xbp = w2.pay[1]; lea = (int)w2.pay[2]; up = w2.pay + 3;
+                        q = cand; p = (int)w2.i; rq = rqc; ent = entc; dpv = w2.p0; xbp = w2.p1; lea = (int)w2.p2;
                         found = true;
                         break;
                     }
-                    double gl[RI];
-                    ratios(dcol, gl);
+                    double gl2[RI];
+                    ratios(dcol, gl2);
 #pragma unroll
-                    for (int s = 0; s < RI; s++) gl[s] = (gidx(s) < a.m && !(gl[s] > 1e-12)) ? 0.0 : inf;
-                    const XWin gw = reduce_rows(gl, dcol);
+                    for (int s = 0; s < RI; s++) gl2[s] = (gidx(s) < a.m && !(gl2[s] > 1e-12)) ? 0.0 : inf;
+                    const XWin gw = reduce_rows(gl2, dcol);
                     if (dead) break;
                     if (gw.m == 0.0) {   // :368-379
-                        q = cand; p = (int)gw.i; rq = rqc; ent = entc; dpv = gw.pay[0]; xbp = gw.pay[1]; lea = (int)gw.pay[2]; up = gw.pay + 3;
+                        q = cand; p = (int)gw.i; rq = rqc; ent = entc; dpv = gw.p0; xbp = gw.p1; lea = (int)gw.p2;
                         found = true;
                         break;
                     }
@@ -367,14 +339,14 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
             for (int s = 0; s < RI; s++) fl[s] = (gidx(s) == q) ? 0.0 : inf;
             const XWin fc = reduce_cols(fl);
             if (dead) break;
-            ent = (int)fc.pay[1];
-            column(q, fc.pay + 2, dcol);
-            double gl[RI];
+            ent = (int)fc.p1;
+            column(q, k, dcol);
+            double gl2[RI];
 #pragma unroll
-            for (int s = 0; s < RI; s++) gl[s] = (gidx(s) == p) ? 0.0 : inf;
-            const XWin gw = reduce_rows(gl, dcol);
+            for (int s = 0; s < RI; s++) gl2[s] = (gidx(s) == p) ? 0.0 : inf;
+            const XWin gw = reduce_rows(gl2, dcol);
             if (dead) break;
-            dpv = gw.pay[0]; xbp = gw.pay[1]; lea = (int)gw.pay[2]; up = gw.pay + 3;
+            dpv = gw.p0; xbp = gw.p1; lea = (int)gw.p2;
         }
         // ---- row p for this thread's columns, reduced costs, block terms (formulas of k_bt_inner2)
         const double rinv = 1.0 / dpv, nrinv = -rinv;
@@ -389,13 +361,16 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
             const int j = gidx(s);
             vrow[s] = j < a.ldt ? ldT(tile_off_g((unsigned int)p, (unsigned int)j, ldt)) : 0.0;
         }
+        double up[KR];   // u_j[p] of the block's k earlier pivots, newest first
+#pragma unroll
+        for (int jj = 0; jj < KR; jj++) up[jj] = jj < k ? ld_term(a.U + (size_t)(k - 1 - jj) * a.ldu + p) : 0.0;
 #pragma unroll
         for (int s = 0; s < RI; s++) {
             const int i = gidx(s);
             if (i < a.ldu) {
                 const double u = (i == p) ? rinv - 1.0 : dcol[s] * nrinv;
                 if (i < a.m) xbv[s] = (i == p) ? theta : __builtin_fma(-theta, dcol[s], xbv[s]);
-                Uk[i] = u;
+                st_term(Uk + i, u);
 #pragma unroll
                 for (int jj = KR - 1; jj > 0; jj--) ureg[s][jj] = ureg[s][jj - 1];
                 ureg[s][0] = u;
@@ -411,7 +386,7 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
                 for (int jj = 0; jj < KR; jj++) v = __builtin_fma(up[jj], vreg[s][jj], v);
                 rv[s] = (j == q) ? -mult : __builtin_fma(-mult, v, rv[s]);
                 const double vprime = (j == q) ? dpv + 1.0 : v;
-                Vk[j] = vprime;
+                st_term(Vk + j, vprime);
 #pragma unroll
                 for (int jj = KR - 1; jj > 0; jj--) vreg[s][jj] = vreg[s][jj - 1];
                 vreg[s][0] = vprime;
@@ -419,7 +394,7 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
             }
         }
         if constexpr (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp(12);
+        stamp(10);
         if (forced && a.forced_nocommit == 3) status = ST_FORCED_DONE;
         if (g == 0 && tid == 0 && !(forced && a.forced_nocommit)) {   // simplex.go:280
             if (a.trace && trace_len < a.trace_cap) {
