@@ -153,23 +153,34 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
         const double seqd = (double)xs;
         const int par = (int)(xs & 1);
         if (wv == 0) {
-            const double x = lane < NW ? redM[lane] : inf;
-            const unsigned int ii = lane < NW ? redI[lane] : 0xFFFFFFFFu;
-            const double fm = readlane_f64(row_min_f64(x), 15);
-            const unsigned int key = (x == fm) ? ii : 0xFFFFFFFFu;
-            const unsigned int fi = (unsigned int)__builtin_amdgcn_readlane((int)row_min_u32(key), 15);
-            const int ww = (int)((fi & (unsigned int)(NT - 1)) >> 6);
+            // the workgroup's winner over its NW waves (uniform LDS reads, every lane computes the same): first index among the
+            // waves that attain the minimum; lanes 0..7 post {sequence number, value}
+            double fm = redM[0];
+            unsigned int fi = redI[0];
+            double v0 = pay[0][lane < 5 && lane >= 2 ? lane - 2 : 3];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; w2++) {
+                const double mw = redM[w2];
+                const unsigned int iw = redI[w2];
+                const double pw = pay[w2][lane < 5 && lane >= 2 ? lane - 2 : 3];
+                // (value, index) lexicographic; a NaN minimum (index 0xFFFFFFFF) never replaces anything
+                const bool take = (mw < fm) || (mw == fm && iw < fi) || (fm != fm && mw == mw);
+                fm = take ? mw : fm;
+                fi = take ? iw : fi;
+                v0 = take ? pw : v0;
+            }
             if (lane < kXSlots) {
                 xpair v;
                 v.x = seqd;
-                v.y = lane == 0 ? fm : lane == 1 ? (double)fi : pay[ww][lane < 5 ? lane - 2 : 3];
+                v.y = lane == 0 ? fm : lane == 1 ? (double)fi : v0;
                 xstore(recs + ((size_t)(par * G + g) * kXSlots + lane), v);
             }
             if constexpr (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         stamp(which * 5 + 2);
-        const bool act = lane < G * kXSlots;
-        const xpair *src = recs + (size_t)par * G * kXSlots + (act ? lane : 0);
+        // lane l reads slot l >> 3 of record l & 7: the G minima sit in lanes 0..G-1, their indices in lanes 8.., the scalars behind
+        const bool act = (lane & 7) < G && (lane >> 3) < 5;
+        const xpair *src = recs + (size_t)par * G * kXSlots + (act ? (lane & 7) * kXSlots + (lane >> 3) : 0);
         xpair got[1];
         int spins = 0;
         for (;;) {
@@ -178,25 +189,29 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
             if (++spins > kXSpinLimit) { dead = true; break; }
         }
         stamp(which * 5 + 3);
-        // lexicographic minimum of (value, first index) over the G records; a NaN value never wins (v_min_f64)
-        const bool slot0 = act && (lane & (kXSlots - 1)) == 0;
+        // lexicographic minimum of (value, first index) over the G records; a NaN value never wins (v_min_f64): min over
+        // lanes 0..7 by three DPP steps inside the half row
         const double val = got[0].y;
-        const double bm = wave_min_f64(slot0 ? val : inf);
-        unsigned long long mk = __ballot(slot0 && val == bm);
+        double xm = (lane < G) ? val : inf;
+        xm = vmin_f64(xm, dpp_f64<0xB1>(xm));    // quad_perm [1,0,3,2]
+        xm = vmin_f64(xm, dpp_f64<0x4E>(xm));    // quad_perm [2,3,0,1]
+        xm = vmin_f64(xm, dpp_f64<0x141>(xm));   // row_half_mirror
+        const double bm = readlane_f64(xm, 0);
+        unsigned int mk = (unsigned int)(__ballot(lane < G && val == bm) & 0xFFull);
         double bi = 4294967295.0;
-        int gl = 0;   // lane of the winner's slot 0
+        int gw = 0;
         while (mk) {
-            const int l0 = (int)__builtin_ctzll(mk);
+            const int g2 = __builtin_ctz(mk);
             mk &= mk - 1;
-            const double ig = readlane_f64(val, l0 + 1);
-            if (ig < bi) { bi = ig; gl = l0; }
+            const double ig = readlane_f64(val, 8 + g2);
+            if (ig < bi) { bi = ig; gw = g2; }
         }
         XWin r;
         r.m = bm;
         r.i = (unsigned int)bi;
-        r.p0 = readlane_f64(val, gl + 2);
-        r.p1 = readlane_f64(val, gl + 3);
-        r.p2 = readlane_f64(val, gl + 4);
+        r.p0 = readlane_f64(val, 16 + gw);
+        r.p1 = readlane_f64(val, 24 + gw);
+        r.p2 = readlane_f64(val, 32 + gw);
         stamp(which * 5 + 4);
         return r;
     };
