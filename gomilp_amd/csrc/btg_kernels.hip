@@ -42,13 +42,20 @@ typedef double xpair __attribute__((ext_vector_type(2)));   // {sequence number,
 __device__ __forceinline__ unsigned int tile_off_g(unsigned int i, unsigned int j, unsigned int ldt) {
     return ((i >> 2) * (ldt >> 2) + (j >> 2)) * 16u + ((i & 3u) << 2) + (j & 3u);
 }
-__device__ __forceinline__ void xstore(xpair *p, xpair v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+// Two forms of the record accesses.  SAFE: sc1 (agent scope: written through to / read from the memory side — correct
+// wherever the workgroups run, but the round trip depends on which HBM stack the line lives in: 1950-2630 cycles per
+// exchange over 16 placements in tools/xsync_bench.hip, which showed up as 68 vs 78 us per launch from one process to the
+// next).  FAST, used once the workgroups have seen that they share one XCD: plain stores (write-through L1 -> that XCD's
+// L2, the coherence point of its CUs) and nt loads (never served by L1) — 1860-1920 cycles at every placement.
+__device__ __forceinline__ void xstore(xpair *p, xpair v, bool fast) {
+    if (fast) asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
 template <int H> struct XLoad;
 template <> struct XLoad<1> {
-    static __device__ __forceinline__ void run(const xpair *p, xpair (&v)[1]) {
-        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(p) : "memory");
+    static __device__ __forceinline__ void run(const xpair *p, xpair (&v)[1], bool fast) {
+        if (fast) asm volatile("global_load_dwordx4 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(p) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(p) : "memory");
     }
 };
 struct XWin { double m; unsigned int i; double p0, p1, p2; };    // winner of an exchange: value, first index, its scalars
@@ -98,6 +105,12 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto gidx = [&](int s) -> int { return (s * G + g) * NT + tid; };   // row / column index of this thread's slot s
+    // `fast` is decided by the first exchange of the launch, which carries every workgroup's XCC id: all equal -> the
+    // same-XCD record accesses from then on (every workgroup sees the same ids, so all switch together)
+    unsigned int myxcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(myxcc));
+    myxcc &= 0xFu;
+    bool fast = false, first = true;
     double xbv[RI], rv[RI];   // x_B, r and the index lists of this thread's rows / columns: registers
     int basv[RI], nbasv[RI];
 #pragma unroll
@@ -172,19 +185,19 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
             if (lane < kXSlots) {
                 xpair v;
                 v.x = seqd;
-                v.y = lane == 0 ? fm : lane == 1 ? (double)fi : v0;
-                xstore(recs + ((size_t)(par * G + g) * kXSlots + lane), v);
+                v.y = lane == 0 ? fm : lane == 1 ? (double)fi : lane == 5 ? (double)myxcc : v0;
+                xstore(recs + ((size_t)(par * G + g) * kXSlots + lane), v, fast);
             }
             if constexpr (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         stamp(which * 5 + 2);
         // lane l reads slot l >> 3 of record l & 7: the G minima sit in lanes 0..G-1, their indices in lanes 8.., the scalars behind
-        const bool act = (lane & 7) < G && (lane >> 3) < 5;
+        const bool act = (lane & 7) < G && (lane >> 3) < 6;
         const xpair *src = recs + (size_t)par * G * kXSlots + (act ? (lane & 7) * kXSlots + (lane >> 3) : 0);
         xpair got[1];
         int spins = 0;
         for (;;) {
-            XLoad<1>::run(src, got);
+            XLoad<1>::run(src, got, fast);
             if (__all(!act || got[0].x == seqd)) break;
             if (++spins > kXSpinLimit) { dead = true; break; }
         }
@@ -212,6 +225,10 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
         r.p0 = readlane_f64(val, 16 + gw);
         r.p1 = readlane_f64(val, 24 + gw);
         r.p2 = readlane_f64(val, 32 + gw);
+        if (first) {   // slot 5 of every record: the XCC the workgroup runs on
+            fast = !dead && __all(!(act && (lane >> 3) == 5) || val == (double)myxcc);
+            first = false;
+        }
         stamp(which * 5 + 4);
         return r;
     };

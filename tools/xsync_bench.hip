@@ -98,7 +98,28 @@ template <int POL, bool ALLWAVES> void run(const char *name, int G, int stride, 
     CK(hipFree(lines)); CK(hipFree(sink)); CK(hipFree(cycles)); CK(hipFree(err));
 }
 
-int main() {
+// placement test: the same exchange with its record lines at different offsets of one large allocation
+template <int POL> void place(int G, int rounds) {
+    const size_t span = (size_t)64 << 20;
+    char *big; double *sink; long long *cycles; int *err, *bad, *xcc;
+    CK(hipMalloc(&big, span)); CK(hipMemset(big, 0, span));
+    CK(hipMalloc(&sink, (size_t)G * 8 * 512 * sizeof(double)));
+    CK(hipMalloc(&cycles, 8 * sizeof(long long))); CK(hipMalloc(&err, sizeof(int))); CK(hipMalloc(&bad, sizeof(int))); CK(hipMalloc(&xcc, 8 * sizeof(int)));
+    for (size_t off : {(size_t)0, (size_t)4096, (size_t)8192, (size_t)16384, (size_t)65536, (size_t)1 << 20, (size_t)2 << 20, (size_t)3 << 20, (size_t)5 << 20, (size_t)8 << 20,
+                       (size_t)13 << 20, (size_t)21 << 20, (size_t)34 << 20, (size_t)55 << 20, ((size_t)55 << 20) + 4096 * 3, ((size_t)21 << 20) + 4096 * 7}) {
+        CK(hipMemset(err, 0, sizeof(int))); CK(hipMemset(bad, 0, sizeof(int)));
+        hipLaunchKernelGGL((k_xsync<POL, false>), dim3(G * 8), dim3(512), 0, 0, reinterpret_cast<double *>(big + off), G, 8, rounds, cycles, err, sink, bad, xcc);
+        CK(hipDeviceSynchronize());
+        long long h[8]; CK(hipMemcpy(h, cycles, sizeof(h), hipMemcpyDeviceToHost));
+        printf("POL %d G=%d offset %9zu: %.0f ticks/round\n", POL, G, off, (double)h[0] / (rounds - 8));
+        fflush(stdout);
+    }
+    CK(hipFree(big)); CK(hipFree(sink)); CK(hipFree(cycles)); CK(hipFree(err)); CK(hipFree(bad)); CK(hipFree(xcc));
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1) { place<1>(8, 20000); place<6>(8, 20000); return 0; }
+
     const int R = 20000;
     for (int G : {2, 4, 8}) {
         run<1, false>("sc1/sc1 sameXCD", G, 8, R);
