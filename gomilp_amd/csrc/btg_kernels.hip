@@ -8,16 +8,19 @@
 // What stays global are the two argmins of a pivot (entering column: simplex.go:247, leaving row: :262-266).  Each becomes
 // an EXCHANGE through the XCD's L2:
 //   * every workgroup reduces its own candidates (v_min_f64 over DPP + ballot, as in k_bt_inner2) and wave 0 posts a
-//     record {min, first index, scalars everybody needs about the winner (r_q, the entering variable, v'_k[q]; or d_p,
-//     x_B[p], the leaving variable, u_k[p])} — 32 slots of 16 bytes {sequence number, value}, one 16-byte store per lane,
-//     so a slot can never be seen half-written;
-//   * wave 0 polls the G records (sc1 loads: served by L2, never by a stale L1 line) until every slot carries this
-//     exchange's sequence number, takes the lexicographic minimum (value, index) — floats.MinIdx over the whole vector —
-//     and hands the winner's record to the other waves through LDS.
+//     record {min, first index, three scalars about the winner (r_q, the entering variable; or d_p, x_B[p], the leaving
+//     variable), the workgroup's XCC id} — one 128-byte line of 8 slots {sequence number, value}, one 16-byte store per
+//     lane, so a slot can never be seen half-written;
+//   * every wave polls the G records (loads that L1 never serves) until every slot carries this exchange's sequence
+//     number and takes the lexicographic minimum (value, index) — floats.MinIdx over the whole vector — itself: one
+//     barrier per exchange, no LDS hop;
+//   * the block terms of foreign rows / columns (v'_j[q], u_j[p]) are read from the U / V rows of the running block, which
+//     the owners write anyway for the update kernel (agent-scope stores, awaited before the owner's next post).
 // Records are double buffered by sequence parity: a workgroup can be at most one exchange ahead of the slowest one.
-// Measured (tools/xsync_bench.hip, MI355X): 0.64 us per exchange at G = 4 on one XCD, 0.95 us across XCDs; the launch
+// Measured (tools/xsync_bench.hip, MI355X): 0.64 us per bare exchange at G = 4 on one XCD, 0.95 us across XCDs; the launch
 // therefore uses blocks 0, 8, 16, ... of a grid of 8*G (blocks are dealt round-robin over the 8 XCDs; the others leave at
-// once).  Placement is a speed matter only: the protocol is correct wherever the workgroups run.
+// once).  Placement is a speed matter only: the first exchange of a launch uses agent-scope accesses and carries the XCC
+// ids; only if all are equal do the record accesses drop to the L2-only forms (see xstore).
 // Every workgroup takes the same decisions from the same exchanged values, so control flow never diverges between them; a
 // poll that sees no progress for ~1 s (a workgroup never got a CU) ends the launch with ST_XCHG_TIMEOUT in every workgroup.
 #include <hip/hip_runtime.h>
