@@ -104,7 +104,10 @@ gomilp_ctx *gomilp_ctx_create(int device, int *status);
 void gomilp_ctx_destroy(gomilp_ctx *ctx);
 int gomilp_ctx_device(const gomilp_ctx *ctx);
 /* knobs: "chunk" (pivots enqueued between host checks), "refresh" (pivots between x_B/y recomputations, 0 = never),
- * "trace" (1 = record pivots), "max_pivots" (safety cap, 0 = none).  Returns GOMILP_OK or GOMILP_ERR_BAD_SHAPE. */
+ * "trace" (1 = record pivots), "max_pivots" (safety cap, 0 = none).  Developer knobs of the pivot pipelines (tests force
+ * kernel instances with them; results do not depend on them): "tableau", "blocked", "block_k", "bt_nt" (threads of the
+ * single-workgroup block kernel), "bt_groups" (-1: single-workgroup block kernels only, 0: by shape, 2 / 4 / 8: that many
+ * workgroups), "bt_old", "bt_stamps", "sample_events", "cond_guard".  Returns GOMILP_OK or GOMILP_ERR_BAD_SHAPE. */
 int gomilp_ctx_set(gomilp_ctx *ctx, const char *key, int64_t value);
 
 /* Upload a standard-form LP (row-major A, stride lda) and keep it resident.  Returns a problem id >= 0, or
