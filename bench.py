@@ -78,6 +78,36 @@ def newest_pmc(kernel_substr):
     return best or (None, None)
 
 
+def mfma_object(m, nn, pipeline, ksec):
+    """Where the matrix cores are used on this path and how busy they are.  The only GEMM-shaped step is the rank-16 update of
+    the tableau (k_bt_update_mfma16: T += U V'^T, v_mfma_f64_16x16x4_f64, shapes beyond 1024 rows); it moves 16 bytes per 32
+    flop and runs at the MALL / HBM rate, so its MFMA pipes are mostly idle by construction."""
+    if pipeline != "blocked" or max(m, nn) <= 1024 or ksec[1] <= 0:
+        return {"util": 0.0, "why": "this shape runs the rank-8 VALU update (1 flop per byte moved); no MFMA instruction is issued"}
+    t_upd = ksec[2] / ksec[1]
+    n_mfma = (m // 16) * (nn // 16) * 4.0                 # wave-level v_mfma_f64_16x16x4_f64 per update launch
+    flops = n_mfma * 2048.0
+    simd_cycles = 1024 * t_upd * 2.4e9                     # 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
+    counters, src = None, None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            for ent in json.load(open(path)):
+                if "k_bt_update_mfma16" in ent.get("kernel", "") and "mfma_counters_mean_per_launch" in ent:
+                    counters, src = ent["mfma_counters_mean_per_launch"], os.path.relpath(path, ROOT)
+        except Exception:
+            pass
+    return {"kernel": "k_bt_update_mfma16", "instructions_per_launch": n_mfma, "tflops": flops / t_upd / 1e12 if t_upd > 0 else 0.0,
+            "util": (n_mfma * 64.0) / simd_cycles if t_upd > 0 else 0.0,
+            "util_model": "MFMA instructions x 64 issue cycles (f64 16x16x4) / (1024 SIMDs x launch duration x 2.4 GHz)",
+            "time_share_of_kernel": (ksec[2] / max(ksec[0] + ksec[2], 1e-30)),
+            "counters_per_launch": counters, "counters_source": src,
+            "why_low": "the update is bound by the 16 bytes it moves per element (2 flop/byte; the f64 MFMA ridge of gfx950 is ~10 flop/byte); "
+                       "the matrix cores replace 32 VALU multiply-adds + 16 LDS reads per 16 bytes, which had made the VALU form of the rank-16 update "
+                       "issue-bound (13.9 us against 12.5 us). Pricing itself is one row update per pivot in the tableau form, and sibling "
+                       "relaxations do not share a matrix once their bases differ: there is no batched pricing GEMM"}
+
+
 def main() -> int:
     args = parse_args()
     # ONE JSON line on stdout: libraries that print banners there (RCCL at communicator set-up) go to stderr instead
@@ -334,7 +364,7 @@ def main() -> int:
         need = max(m, nn)
         inner_name = ("k_bt_inner2<512,2,2,8,0>" if need <= 1024 else "k_bt_innerG<8,256,1,16>" if need <= 2048 else
                       "k_bt_innerG<8,512,%d,16>" % (1 if need <= 4096 else 2))
-        upd_name = "k_bt_update_tiled<8>" if need <= 1024 else "k_bt_update_tiled<16>"
+        upd_name = "k_bt_update_tiled<8>" if need <= 1024 else "k_bt_update_mfma16"
         # byte model of THIS pipeline, per block of K pivots: the inner kernel reads one column and one row of T per pivot and
         # writes u_k, v_k' (8 B each) + loads / stores r, x_B and the index lists once per launch; the update reads and
         # writes T once
@@ -357,7 +387,7 @@ def main() -> int:
                      "model": "per block of K pivots: 16*m*(n-m) (rank-K update: T read + written once) + K*16*(m+n-m) + 24*(m+n-m) (block kernel)"},
             "streaming_kernel": {"bound": "hbm", "kernel": upd_name, "bytes_per_launch": bytes_update, "avg_launch_us": 1e6 * t_upd,
                                  "achieved": bytes_update / t_upd / 1e9 if t_upd > 0 else 0.0, "frac": bytes_update / t_upd / 1e9 / HBM_PEAK_GBS if t_upd > 0 else 0.0,
-                                 "traffic": newest_pmc(upd_name.split("<")[0] + "<")[0], "traffic_source": newest_pmc(upd_name.split("<")[0] + "<")[1],
+                                 "traffic": newest_pmc(upd_name.split("<")[0])[0], "traffic_source": newest_pmc(upd_name.split("<")[0])[1],
                                  "time_share": (1 - share_inner) * loop_s / dt,
                                  "note": "the %.1f MB tableau stays in the 256 MB Infinity Cache between launches: a MALL rate where it exceeds the ~6.3 TB/s HBM copy rate" % (8e-6 * m * nn)},
             "sampled_blocks": int(ksec[1]), "sampled_pivots": int(ksec[3]),
@@ -380,10 +410,7 @@ def main() -> int:
         "config": {"workload": "%s: %dx%d dense LP, splitmix64 seed %d, one full solve per step" % (args.workload, m, n, seed),
                    "pivots_per_solve": int(last.stats["pivots_phase2"]), "parallelism": "1 relaxation on 1 GPU", "pipeline": pipeline, "chunk": args.chunk},
         "roofline": roofline,
-        "mfma": {"util": 0.0, "why": "nothing on this path is GEMM-shaped with a shared operand: pricing is one row update per pivot "
-                 "(tableau form), the rank-8 update of T does 16 flop per 16 bytes moved (1 flop/byte; the f64 MFMA ridge of gfx950 is ~10 flop/byte) "
-                 "and runs at the MALL/HBM rate; sibling relaxations do not share a matrix once their bases differ, so there is no batched pricing GEMM",
-                 "evidence": "profiles/README.md: SQ_INSTS_VALU_MFMA_* / SQ_VALU_MFMA_BUSY_CYCLES = 0 in the rocprofv3 --pmc pass"},
+        "mfma": mfma_object(m, nn, pipeline, ksec),
         "breakdown": {"pivot_loop_s": loop_s, "final_solve_s": final_s, "final_device_s": final_dev, "final_host_s": final_host, "wall_s": dt,
                       "drift_xb": last.stats["drift_xb"], "z": last.z},
     }
@@ -459,7 +486,7 @@ def main() -> int:
                      "update_GBs": 16.0 * m4 * m4 / (k4[2] / nb4) / 1e9 if k4[2] > 0 else 0.0,
                      "update_frac_of_hbm_peak": 16.0 * m4 * m4 / (k4[2] / nb4) / 1e9 / HBM_PEAK_GBS if k4[2] > 0 else 0.0,
                      "inner_kernel": "k_bt_innerG<8,512,1,16>",
-                     "note": "the 134 MB tableau no longer fits the Infinity Cache with everything else: the update runs at the HBM rate; block kernel = 8 workgroups "
+                     "note": "the 134 MB tableau no longer fits the Infinity Cache with everything else: the update (k_bt_update_mfma16) runs at the HBM rate; block kernel = 8 workgroups "
                              "of one XCD, two L2 exchanges per pivot, K = 16 terms per row / column in registers (btg_kernels.hip); the single-workgroup "
                              "k_bt_inner (knob bt_groups = -1) needs 295 us per 16 pivots at this size"}
         p4.free()

@@ -1164,6 +1164,68 @@ __global__ __launch_bounds__(kBlock) void k_bt_update_tiled_batch(const BatchLP 
     bt_update_tiled_body<KMAX>(a, tilerows_per_wg, bx, by);
 }
 
+// Rank-16 update on the matrix cores.  With K = 16 the update does 2 flop per byte moved and the VALU form above runs at
+// 4.8 TB/s (13.9 us for the 67 MB of a 2048 x 2048 tableau; the rank-8 form streams at 6.8 TB/s): the 16 LDS reads and 32
+// multiply-adds per 16 bytes, not the memory system, set its pace.  A 16 x 16 block of T in the 4x4-tile layout is exactly
+// the C/D operand of v_mfma_f64_16x16x4_f64 (lane l, register r <-> row (l >> 4) + 4 r, column l & 15: tile row r, row
+// l >> 4 of the tile, tile column (l & 15) >> 2, column l & 3 of the tile), so for each r the 64 lanes read the 512
+// contiguous bytes of four neighbouring tiles; A = u_k[row] (lane: row l & 15, k = 4 s + (l >> 4)), B = v'_k[column], four
+// MFMAs (k = 0..15) per block.  One wave = a strip of 16 rows x `cw` column blocks, the u operands loaded once.
+typedef double bt_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_bt_update_mfma16(BTArgs a, int cw) {
+    const int kd = a.st->kdone;
+    if (kd <= 0) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ncb = a.ldt >> 4;
+    const int cb0 = ((int)blockIdx.x * 4 + wv) * cw;
+    if (cb0 >= ncb) return;
+    const int cb1 = min(cb0 + cw, ncb);
+    const int strip = (int)blockIdx.y;
+    const int row = strip * 16 + l15;
+    double av[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int k = 4 * s + l4;
+        av[s] = (k < kd && row < a.m) ? a.U[(size_t)k * a.ldu + row] : 0.0;   // rows of U beyond the pivots of this block are stale
+    }
+    const int ntr = (a.m + 3) >> 2;   // tile rows that exist
+    const size_t trow = (size_t)(a.ldt >> 2) * 16;   // doubles per tile row
+    double *base = a.T + (size_t)(strip * 4) * trow + (size_t)(l15 >> 2) * 16 + l4 * 4 + (l15 & 3);
+    bool valid[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) valid[r] = strip * 4 + r < ntr;
+    constexpr int UN = 4;   // column blocks in flight per wave: 16 loads of 8 bytes per lane before the first MFMA
+    for (int cb = cb0; cb < cb1; cb += UN) {
+        bt_d4 c[UN];
+        double bv[UN][4];
+#pragma unroll
+        for (int x = 0; x < UN; x++) {
+            const bool in = cb + x < cb1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) c[x][r] = (in && valid[r]) ? base[(size_t)r * trow + (size_t)(cb + x) * 64] : 0.0;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const int k = 4 * s + l4;
+                bv[x][s] = (in && k < kd) ? a.V[(size_t)k * a.ldt + (cb + x) * 16 + l15] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < UN; x++) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) c[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[x][s], c[x], 0, 0, 0);
+        }
+#pragma unroll
+        for (int x = 0; x < UN; x++) {
+            if (cb + x < cb1) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (valid[r]) base[(size_t)r * trow + (size_t)(cb + x) * 64] = c[x][r];
+            }
+        }
+    }
+}
+
 // ---- launch wrappers ---------------------------------------------------------------------------
 
 int bt_max_k() { return kBtMaxK; }
@@ -1311,7 +1373,13 @@ void launch_bt_update(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t 
         while (tr > 4 && gx * ((ntr + tr - 1) / tr) < 512) tr >>= 1;
         dim3 grid(gx, (ntr + tr - 1) / tr);
         if (a.kmax <= 8) hipExtLaunchKernelGGL((k_bt_update_tiled<8>), grid, dim3(kBlock), 0, s, e0, e1, 0, a, tr);
-        else hipExtLaunchKernelGGL((k_bt_update_tiled<16>), grid, dim3(kBlock), 0, s, e0, e1, 0, a, tr);
+        else if (a.kmax == 16 && !a.old_only && a.upd_valu == 0) {   // matrix cores (knob "bt_upd_valu" = 1: the VALU form)
+            // column blocks per wave: 4 = one trip of 16 loads per lane; measured at 2048 x 2048: 1 -> 19.7 us, 2 -> 14.2, 4 -> 12.5,
+            // 8 -> 14.5, 16 -> 16.6 (the VALU form: 13.9); at 4096 x 4096: 40.9 us against 46
+            const int ncb = a.ldt >> 4, cw = 4;
+            dim3 gm((unsigned int)((ncb + 4 * cw - 1) / (4 * cw)), (unsigned int)((a.m + 15) / 16));
+            hipExtLaunchKernelGGL(k_bt_update_mfma16, gm, dim3(256), 0, s, e0, e1, 0, a, cw);
+        } else hipExtLaunchKernelGGL((k_bt_update_tiled<16>), grid, dim3(kBlock), 0, s, e0, e1, 0, a, tr);
         return;
     }
     const int ld2 = a.ldt / 2;

@@ -17,5 +17,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_C4 -- python3
 SMALL="--steps 1 --warmup 0 --no-cpu-baseline --concurrent 0 --milp-nodes 0 --c4 0"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $SMALL > $OUT/pmc_f.json 2> $OUT/pmc_f.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py $SMALL > $OUT/pmc_w.json 2> $OUT/pmc_w.err
-rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $OUT/pmc_mfma -- python3 bench.py $SMALL > $OUT/pmc_m.json 2> $OUT/pmc_m.err
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/pmc_mfma -- python3 bench.py $SMALL > $OUT/pmc_m.json 2> $OUT/pmc_m.err
 du -sh $OUT
