@@ -11,7 +11,8 @@ def t5(piv):
     return a[:, [0, 2, 3, 4, 5]]
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
-knobs = [int(v) for v in sys.argv[2:]]
+extra = dict((a.split("=")[0], int(a.split("=")[1])) for a in sys.argv[2:] if "=" in a)   # e.g. block_k=32
+knobs = [int(v) for v in sys.argv[2:] if "=" not in v]
 bad = 0
 if what in ("small", "all"):
     for m, seed in ((64, 5), (128, 7), (256, 7), (512, 3)):
@@ -42,7 +43,7 @@ if what in ("M", "all"):
     m, seed = synth.CONFIGS["M"]
     c, A, b = synth.dense_lp_standard_form(m, seed)
     for G in (knobs or (4, 8, 2)):
-        cx = lp.Context(bt_groups=G, sample_events=64, chunk=64)
+        cx = lp.Context(bt_groups=G, sample_events=64, chunk=64, **extra)
         p = cx.upload(c, A, b)
         r = p.solve(0.0, trace=True)
         got, want = t5(r.pivots), fx["trace"][:, [0, 2, 3, 4, 5]].astype(np.int64)
@@ -60,7 +61,7 @@ if what in ("C4",):
     m, seed = synth.CONFIGS["C4"]
     c, A, b = synth.dense_lp_standard_form(m, seed)
     for G in (knobs or (8, 0)):
-        cx = lp.Context(bt_groups=G, sample_events=64, chunk=64)
+        cx = lp.Context(bt_groups=G, sample_events=64, chunk=64, **extra)
         p = cx.upload(c, A, b)
         r = p.solve(0.0, trace=True)
         want = fx["trace"][:, [0, 2, 3, 4, 5]].astype(np.int64)
