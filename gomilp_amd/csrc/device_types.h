@@ -129,6 +129,7 @@ struct BTArgs {
     unsigned long long *stamps;   // diagnostic build only (knob "bt_stamps"): per-wave cycle sums per pivot segment
     double *xbuf;                 // multi-workgroup block kernel: exchange records in HBM (btg_kernels.hip)
     int32_t groups, group_ri;     // its workgroup count (0: single-workgroup kernels) and rows / columns per thread
+    int32_t fault, pad_f;         // knob "bt_fault" (tests): workgroup 1 of the multi-workgroup block kernel leaves at once
     int32_t group_nt, upd_valu;   // threads per workgroup; knob "bt_upd_valu": rank-16 update on the VALU instead of the matrix cores
 };
 

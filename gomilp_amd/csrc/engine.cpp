@@ -50,6 +50,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "bt_nt") { if (v != 0 && v != 256 && v != 512 && v != 1024) return GOMILP_ERR_BAD_SHAPE; bt_nt_ = v; }
     else if (key == "bt_old") bt_old_ = v ? 1 : 0;
     else if (key == "bt_upd_valu") bt_upd_valu_ = v ? 1 : 0;
+    else if (key == "bt_fault") bt_fault_ = v ? 1 : 0;
     else if (key == "bt_groups") { if (v != -1 && v != 0 && v != 2 && v != 4 && v != 8) return GOMILP_ERR_BAD_SHAPE; bt_groups_ = v; }
     else if (key == "bt_stamps") bt_stamps_ = v ? 1 : 0;
     else if (key == "cond_guard") cond_guard_ = v ? 1 : 0;

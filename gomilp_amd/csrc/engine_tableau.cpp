@@ -221,6 +221,7 @@ BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int
     a.nt_force = (int)bt_nt_; a.old_only = bt_old_ ? 1 : 0;
     a.stamps = bt_stamps_ ? w.stamps : nullptr;
     a.upd_valu = bt_upd_valu_ ? 1 : 0;
+    a.fault = bt_fault_ ? 1 : 0;
     if (a.tiled && !bt_old_) {
         const BtGroupCfg gc = bt_group_cfg(P.m, ldt_, (int)bt_groups_);
         a.groups = gc.groups; a.group_ri = gc.ri; a.group_nt = gc.nt; a.xbuf = w.xbuf;
