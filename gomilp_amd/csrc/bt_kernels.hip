@@ -1172,16 +1172,15 @@ __global__ __launch_bounds__(kBlock) void k_bt_update_tiled_batch(const BatchLP 
 // contiguous bytes of four neighbouring tiles; A = u_k[row] (lane: row l & 15, k = 4 s + (l >> 4)), B = v'_k[column], four
 // MFMAs (k = 0..15) per block.  One wave = a strip of 16 rows x `cw` column blocks, the u operands loaded once.
 typedef double bt_d4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_bt_update_mfma16(BTArgs a, int cw) {
+__device__ __forceinline__ void bt_update_mfma16_body(const BTArgs &a, int cw, int bx, int strip) {
     const int kd = a.st->kdone;
     if (kd <= 0) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int ncb = a.ldt >> 4;
-    const int cb0 = ((int)blockIdx.x * 4 + wv) * cw;
+    const int cb0 = (bx * 4 + wv) * cw;
     if (cb0 >= ncb) return;
     const int cb1 = min(cb0 + cw, ncb);
-    const int strip = (int)blockIdx.y;
     const int row = strip * 16 + l15;
     double av[4];
 #pragma unroll
@@ -1224,6 +1223,21 @@ __global__ __launch_bounds__(256) void k_bt_update_mfma16(BTArgs a, int cw) {
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_bt_update_mfma16(BTArgs a, int cw) { bt_update_mfma16_body(a, cw, (int)blockIdx.x, (int)blockIdx.y); }
+// batched form: block L works on the relaxation at list position L / ntiles, tile L % ntiles (tile-minor: the tiles of a large
+// tableau spread over all XCDs)
+__global__ __launch_bounds__(256) void k_bt_update_mfma16_batch(const BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count, int gx, int ntiles, int cw) {
+    const unsigned int li = blockIdx.x / (unsigned int)ntiles, tile = blockIdx.x % (unsigned int)ntiles;
+    if ((int)li >= *count) return;
+    const BatchLP &lp = lps[ids[li]];
+    const int stage = lp.stage;
+    if (stage == BS_DONE || stage == BS_HOST) return;
+    const BTArgs a = lp.bt;
+    const int bx = (int)(tile % (unsigned int)gx), strip = (int)(tile / (unsigned int)gx);
+    if (strip * 16 >= ((a.m + 3) & ~3)) return;
+    bt_update_mfma16_body(a, cw, bx, strip);
 }
 
 // ---- launch wrappers ---------------------------------------------------------------------------
@@ -1314,7 +1328,15 @@ bool bt_tiled(int m, int ldt, int kmax, int nt_force, bool old_only) {
 }
 // ---- batched launches (device-batched frontier, engine_batch.cpp): one configuration for the whole wave, chosen from
 // the largest relaxation; the register-resident kernel on the tiled layout only
+BtGroupCfg bt_group_cfg(int m, int ldt, int knob);   // btg_kernels.hip
+void launch_bt_inner_groups_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, const BtGroupCfg &c, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+// pivots per block of the batched schedule for a wave of this shape class: 16 where the 8-workgroup kernel runs, else 8
+int bt_batch_k(int m_max, int ldt_max) {
+    const BtGroupCfg g = bt_group_cfg(m_max, ldt_max, 0);
+    return (g.groups == 8 && g.ri == 1) ? 16 : 8;
+}
 bool bt_batch_supported(int m_max, int ldt_max) {
+    if (bt_batch_k(m_max, ldt_max) == 16) return true;
     if (!bt_tiled(m_max, ldt_max, 8, 0, false)) return false;
     const BtCfg c = bt_cfg(m_max, ldt_max, 0);
     return c.ri == 2 || (c.ri == 4 && c.nt == 512);
@@ -1328,6 +1350,7 @@ static void bt_inner_batch_nt(const BatchLP *lps, const int *ids, const int *cou
 }
 // ids / count: the active list of the previous control step (device); nlp: an upper bound of *count the host knows
 void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    if (bt_batch_k(m_max, ldt_max) == 16) { launch_bt_inner_groups_batch(lps, ids, count, nlp, bt_group_cfg(m_max, ldt_max, 0), s, e0, e1); return; }
     const BtCfg c = bt_cfg(m_max, ldt_max, 0);
     if (c.ri == 2) { if (c.nt == 512) bt_inner_batch_nt<512, 2, 0>(lps, ids, count, nlp, s, e0, e1); else bt_inner_batch_nt<1024, 2, 1>(lps, ids, count, nlp, s, e0, e1); }
     else bt_inner_batch_nt<512, 4, 0>(lps, ids, count, nlp, s, e0, e1);
@@ -1346,10 +1369,17 @@ void launch_bt_inner_dual_batch(const BatchLP *lps, const int *ids, const int *c
     else bt_inner_dual_batch_nt<512, 4, 0>(lps, ids, count, nlp, s);
 }
 const char *bt_batch_kernel_name(int m_max, int ldt_max) {
+    if (bt_batch_k(m_max, ldt_max) == 16) return bt_group_cfg(m_max, ldt_max, 0).nt == 256 ? "k_bt_innerG_batch<8,256,1,16>" : "k_bt_innerG_batch<8,512,1,16>";
     const BtCfg c = bt_cfg(m_max, ldt_max, 0);
     return c.ri == 2 ? (c.nt == 512 ? "k_bt_inner2_batch<512,2,2,8,0>" : "k_bt_inner2_batch<1024,2,2,8,1>") : "k_bt_inner2_batch<512,4,4,8,0>";
 }
 void launch_bt_update_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    if (bt_batch_k(m_max, ldt_max) == 16) {   // rank-16 update on the matrix cores, one relaxation after the other inside one launch
+        const int ncb = ldt_max >> 4, cw = 4;
+        const int gxm = (ncb + 4 * cw - 1) / (4 * cw), gym = (m_max + 15) / 16;
+        hipExtLaunchKernelGGL(k_bt_update_mfma16_batch, dim3((unsigned int)(gxm * gym * nlp)), dim3(256), 0, s, e0, e1, 0, lps, ids, count, gxm, gxm * gym, cw);
+        return;
+    }
     const int gx = (2 * ldt_max + kBlock - 1) / kBlock;
     const int ntr = (m_max + 3) / 4;
     const bool xcd_local = (size_t)m_max * (size_t)ldt_max * sizeof(double) <= ((size_t)3 << 20);   // fits one XCD's 4 MB L2

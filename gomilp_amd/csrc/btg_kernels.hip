@@ -67,12 +67,10 @@ struct BtWinG { double m; unsigned int i; };                   // a wave's own w
 }  // namespace
 
 // G workgroups x NT threads, RI rows and RI columns per thread (m <= G*NT*RI, ldt <= G*NT*RI), KR block terms in registers
-template <int G, int NT, int RI, int KR, bool STAMP = false>
-__global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
-    if (blockIdx.x & 7u) return;
+template <int G, int NT, int RI, int KR, bool STAMP>
+__device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g) {
     constexpr int NW = NT / 64;
     static_assert(G == 2 || G == 4 || G == 8, "G");
-    const int g = (int)(blockIdx.x >> 3);
     if (a.fault && g == 1) return;   // test hook: a workgroup that never takes part -> the others must give up (ST_XCHG_TIMEOUT)
     __shared__ double redM[16];
     __shared__ unsigned int redI[16];
@@ -469,6 +467,27 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
     }
 }
 
+template <int G, int NT, int RI, int KR, bool STAMP = false>
+__global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
+    if (blockIdx.x & 7u) return;   // blocks 0, 8, 16, ...: all on XCD 0
+    bt_innerG_body<G, NT, RI, KR, STAMP>(a, (int)(blockIdx.x >> 3));
+}
+// Batched form (device-batched waves of large relaxations, engine_batch.cpp): the relaxation at position p of the active list
+// runs on XCD p % 8 — block b = x + 8 j serves position (j / G) * 8 + x as its workgroup j % G — so up to 8 relaxations
+// advance at once, each inside one L2.  Blocks are dispatched in index order and all G workgroups of a relaxation lie in one
+// run of 8 G blocks, so a relaxation whose first workgroup is resident gets the others as soon as slots free up.
+template <int G, int NT, int RI, int KR>
+__global__ __launch_bounds__(NT) void k_bt_innerG_batch(const BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count) {
+    const unsigned int x8 = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const int lpos = (int)((j / G) * 8u + x8);
+    if (lpos >= *count) return;
+    const BatchLP &lp = lps[ids[lpos]];
+    const int stage = lp.stage;
+    if (stage == BS_DONE || stage == BS_HOST || stage == BS_DUAL) return;
+    const BTArgs a = lp.bt;
+    bt_innerG_body<G, NT, RI, KR, false>(a, (int)(j % G));
+}
+
 // Tried and dropped (round 2): every participant ONE wave on its own CU (no barrier, no LDS hop; terms in LDS by position,
 // prefetched under the load latency).  Bit-identical results, but slower at 2048 rows: 8 waves x 4 rows 107.7 us per 16
 // pivots, 16 waves x 2 rows 97.0 us, against 80.2 us for 4 workgroups of 8 waves: one wave issues its ~1500 instructions
@@ -513,6 +532,12 @@ void launch_bt_inner_groups(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEv
     if (G == 2) { if (ri == 1) btg_launch<2, 512, 1>(a, s, e0, e1); else btg_launch<2, 512, 2>(a, s, e0, e1); }
     else if (G == 4) { if (ri == 1) btg_launch<4, 512, 1>(a, s, e0, e1); else btg_launch<4, 512, 2>(a, s, e0, e1); }
     else { if (ri == 1) btg_launch<8, 512, 1>(a, s, e0, e1); else btg_launch<8, 512, 2>(a, s, e0, e1); }
+}
+// batched launch: the whole wave has the shape class of its largest relaxation (8 workgroups; 256 or 512 threads)
+void launch_bt_inner_groups_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, const BtGroupCfg &c, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const unsigned int grid = 64u * (unsigned int)((nlp + 7) / 8);
+    if (c.nt == 256) hipExtLaunchKernelGGL((k_bt_innerG_batch<8, 256, 1, 16>), dim3(grid), dim3(256), 0, s, e0, e1, 0, lps, ids, count);
+    else hipExtLaunchKernelGGL((k_bt_innerG_batch<8, 512, 1, 16>), dim3(grid), dim3(512), 0, s, e0, e1, 0, lps, ids, count);
 }
 const char *bt_group_kernel_name(int G, int ri) {   // (512-thread instances)
     static const char *names[3][2] = {{"k_bt_innerG<2,512,1,16>", "k_bt_innerG<2,512,2,16>"}, {"k_bt_innerG<4,512,1,16>", "k_bt_innerG<4,512,2,16>"},

@@ -278,7 +278,7 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
     for (int r = 0; r < nroots && !any_p1; r++) for (double v : views[r]->hb) if (v < -1e-13) { any_p1 = true; break; }
     for (int64_t k = koff[0]; k < koff[count] && !any_p1; k++) if (rhs[k] < -1e-13) any_p1 = true;
     const Engine::RootOpt *warm = (pool->warm_start && pool->opt.valid && nroots == 1) ? &pool->opt : nullptr;
-    for (int r = 0; r < nroots && use_batch; r++) use_batch = pool->batch->eligible(*views[r], K_max, any_p1 && !warm);
+    for (int r = 0; r < nroots && use_batch; r++) use_batch = pool->batch->eligible(*views[r], K_max, any_p1 && !warm, warm != nullptr);
     if (use_batch) {
         std::mutex agg_mu;
         auto on_done_at = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) {

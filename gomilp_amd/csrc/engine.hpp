@@ -207,6 +207,7 @@ void launch_bt_tile(const double *src, double *dst, int m, int ldt, bool to_tile
 void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 void launch_bt_update(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 bool bt_batch_supported(int m_max, int ldt_max);
+int bt_batch_k(int m_max, int ldt_max);
 void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void launch_bt_update_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 const char *bt_batch_kernel_name(int m_max, int ldt_max);

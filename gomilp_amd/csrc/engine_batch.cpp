@@ -21,7 +21,7 @@ double bnow() {
     } while (0)
 constexpr int kRing = 2;          // snapshots in flight
 constexpr int kMaxSteps = 4096;   // supersteps per wave (slots of the active counter; the last slot serves the prologue)
-constexpr int kBlockK = 8;        // pivots per block: the register-resident kernel (bt_kernels.hip)
+constexpr int kBlockK = 16;       // rows of U / V per relaxation: pivots per block are 8 (k_bt_inner2_batch) or 16 (k_bt_innerG_batch), bt_batch_k()
 template <typename T>
 hipError_t bmalloc(T **p, size_t count) { return hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T)); }
 template <typename T>
@@ -37,6 +37,7 @@ struct BatchEngine::Buf {
     int *h_active[kRing] = {nullptr, nullptr};
     hipEvent_t ev[kRing] = {nullptr, nullptr};
     double *d_T = nullptr, *d_R = nullptr, *d_xb = nullptr, *d_U = nullptr, *d_V = nullptr, *d_scratch = nullptr, *d_art = nullptr;
+    double *d_xbuf = nullptr;   // exchange records of the multi-workgroup block kernel, one set per relaxation slot
     int32_t *d_basic = nullptr, *d_nonbasic = nullptr, *d_srcpos = nullptr;
     DevState *d_st = nullptr;
     int32_t *d_var = nullptr, *h_var = nullptr;
@@ -52,9 +53,9 @@ struct BatchEngine::Buf {
 
     void free_lp_buffers() {
         for (void *p : {(void *)d_lps, (void *)d_T, (void *)d_R, (void *)d_xb, (void *)d_U, (void *)d_V, (void *)d_scratch, (void *)d_art,
-                        (void *)d_basic, (void *)d_nonbasic, (void *)d_srcpos, (void *)d_st, (void *)d_ids[0], (void *)d_ids[1], (void *)d_out})
+                        (void *)d_basic, (void *)d_nonbasic, (void *)d_srcpos, (void *)d_st, (void *)d_ids[0], (void *)d_ids[1], (void *)d_out, (void *)d_xbuf})
             if (p) hipFree(p);
-        d_lps = nullptr; d_T = d_R = d_xb = d_U = d_V = d_scratch = d_art = nullptr; d_basic = d_nonbasic = d_srcpos = nullptr; d_st = nullptr; d_ids[0] = d_ids[1] = nullptr; d_out = nullptr;
+        d_lps = nullptr; d_T = d_R = d_xb = d_U = d_V = d_scratch = d_art = d_xbuf = nullptr; d_basic = d_nonbasic = d_srcpos = nullptr; d_st = nullptr; d_ids[0] = d_ids[1] = nullptr; d_out = nullptr;
         for (void *p : {(void *)h_lps, (void *)h_snap[0], (void *)h_snap[1], (void *)h_basic, (void *)h_xb})
             if (p) hipHostFree(p);
         h_lps = nullptr; h_snap[0] = h_snap[1] = nullptr; h_basic = nullptr; h_xb = nullptr;
@@ -88,12 +89,13 @@ BatchEngine::~BatchEngine() {
     if (copy_stream_) hipStreamDestroy(copy_stream_);
 }
 
-bool BatchEngine::eligible(const Engine::RootView &R, int K_max, bool phase1) const {
+bool BatchEngine::eligible(const Engine::RootView &R, int K_max, bool phase1, bool warm) const {
     if (R.verify_status != GOMILP_OK || !R.unit_basis) return false;
     const int m = R.m + K_max, n = R.n + K_max;
     if (m >= n || !((n - m) < 2 * m)) return false;              // the tableau formulation (engine.cpp: use_tab)
     if (n + 2 > 8000) return false;                              // k_b_ctrl keeps two int lists of n in (default-limit) LDS
     const int ldt1 = batch_ldt(n - m + (phase1 ? 1 : 0));
+    if (warm && bt_batch_k(m, ldt1) != 8) return false;          // the dual-simplex block kernel exists in the single-workgroup form only
     return bt_batch_supported(m, ldt1);
 }
 
@@ -131,6 +133,7 @@ int BatchEngine::ensure(int nlp, int m_max, int n_max, int ldt1, int64_t ktot) {
         B_TRY(bmalloc(&b.d_R, L * cldt)); B_TRY(bmalloc(&b.d_xb, L * cldu)); B_TRY(bmalloc(&b.d_art, L * cldu));
         B_TRY(bmalloc(&b.d_U, L * kBlockK * cldu)); B_TRY(bmalloc(&b.d_V, L * kBlockK * cldt));
         B_TRY(bmalloc(&b.d_scratch, L * 64 * cldt));
+        B_TRY(bmalloc(&b.d_xbuf, L * bt_xbuf_doubles()));
         B_TRY(bmalloc(&b.d_basic, L * cldu)); B_TRY(bmalloc(&b.d_nonbasic, L * cldt)); B_TRY(bmalloc(&b.d_srcpos, L * cldt));
         B_TRY(bmalloc(&b.d_st, L));
         B_TRY(bmalloc(&b.d_ids[0], L)); B_TRY(bmalloc(&b.d_ids[1], L));
@@ -180,6 +183,10 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
     int rc = ensure(nlp, m_max, n_max, ldt1, ktot);
     if (rc != GOMILP_OK) return rc;
     Buf &b = *b_;
+    // pivots per block and block kernel of this wave's shape class: large relaxations run the 8-workgroup kernel (one XCD each)
+    const int kb = bt_batch_k(m_max, ldt1);
+    const BtGroupCfg grp = bt_group_cfg(m_max, ldt1, 0);
+    if (kb == 16) B_TRY(hipMemsetAsync(b.d_xbuf, 0, (size_t)nlp * bt_xbuf_doubles() * sizeof(double), stream_));   // no exchange has happened
     // ---- root data the kernels read in place + the unit-column rows of each root's slack basis
     std::vector<const int32_t *> rho_of(nroots, nullptr);
     for (int r = 0; r < nroots; r++) {
@@ -220,7 +227,8 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         lp.scratch = b.d_scratch + (size_t)i * 64 * b.cap_ldt;
         lp.basic = b.d_basic + (size_t)i * b.cap_ldu; lp.nonbasic = b.d_nonbasic + (size_t)i * b.cap_ldt; lp.srcpos = b.d_srcpos + (size_t)i * b.cap_ldt;
         lp.st = b.d_st + i;
-        lp.tol_user = tol; lp.kblock = kBlockK; lp.stage = BS_HOST;
+        lp.tol_user = tol; lp.kblock = kb; lp.stage = BS_HOST;
+        if (kb == 16) { lp.bt.groups = grp.groups; lp.bt.group_ri = grp.ri; lp.bt.group_nt = grp.nt; lp.bt.xbuf = b.d_xbuf + (size_t)i * bt_xbuf_doubles(); }
         if (warm) {
             lp.warm = 1; lp.T0 = warm->dT; lp.r0 = warm->dr; lp.xb0 = warm->dxb; lp.basic0 = warm->dbasic; lp.nonbasic0 = warm->dnonbasic;
             lp.posvar0 = warm->dposvar; lp.ldt0 = warm->ldt; lp.tiled0 = warm->tiled;

@@ -34,7 +34,7 @@ class BatchEngine {
     ~BatchEngine();
     // can children of this root with up to K_max branch rows take the batched path?
     // (phase1: some relaxation of the wave starts infeasible — the Phase-I tableau is one column wider)
-    bool eligible(const Engine::RootView &R, int K_max, bool phase1) const;
+    bool eligible(const Engine::RootView &R, int K_max, bool phase1, bool warm = false) const;
     int run(const Engine::RootView &R, int64_t count, const int64_t *koff, const int32_t *var, const double *sign,
             const double *rhs, double tol, const DoneFn &on_done, Stats *stats) {
         const Engine::RootView *one = &R;
