@@ -212,7 +212,7 @@ def main() -> int:
             return r.status, r.z, r.x, r.has_x
 
         dev = None if comm is None else torch.device("cuda", local_rank)
-        for _ in range(max(3, warmup)):   # first-touch allocations and code loading of every worker end inside the first waves
+        for _ in range(max(6, warmup)):   # first-touch allocations and code loading of every worker end inside the first waves
             wave = fr.solve_wave(solve_shard, children, mask5, rank, world, wave_dist, dev, comm=comm)
         acc = dict(inner=0.0, update=0.0, blocks=0, blocks_sampled=0, batch=0.0, pivots=0, phase1=0, bland=0, fallbacks=0, batched=0)
         per_wave = []
