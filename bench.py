@@ -207,8 +207,10 @@ def main() -> int:
         holder = {}
 
         def solve_shard(chs):
+            ts = time.perf_counter()
             r = pool.solve(chs)
             holder["stats"] = r.stats
+            holder["solve_s"] = time.perf_counter() - ts
             return r.status, r.z, r.x, r.has_x
 
         dev = None if comm is None else torch.device("cuda", local_rank)
@@ -223,6 +225,9 @@ def main() -> int:
             wave = fr.solve_wave(solve_shard, children, mask5, rank, world, wave_dist, dev, comm=comm)
             per_wave.append(time.perf_counter() - tw)
             st = holder["stats"]
+            if os.environ.get("GOMILP_BENCH_DEBUG"):
+                print("wave %.2f ms: solve %.2f (batch %.2f) exchange+rest %.2f" % (1e3 * per_wave[-1], 1e3 * holder["solve_s"], 1e3 * st["seconds_batch"],
+                                                                                 1e3 * (per_wave[-1] - holder["solve_s"])), file=sys.stderr)
             acc["blocks"] += st["blocks"]; acc["batch"] += st["seconds_batch"]
             acc["pivots"] += st["pivots_phase1"] + st["pivots_phase2"]; acc["phase1"] += st["phase1_runs"]; acc["bland"] += st["bland_steps"]
             acc["fallbacks"] += st["host_fallbacks"]; acc["batched"] += st["batched_relaxations"]
