@@ -39,6 +39,8 @@ struct gomilp_pool {
     int warm_start = 0;         // knob: 1 = children start from the solved root's optimal basis (gomilp_pool_solve_root), dual simplex
     Engine::RootOpt opt;        // final state of the root after gomilp_pool_solve_root
     std::unique_ptr<BatchEngine> batch;
+    std::unique_ptr<BatchEngine> batch2;   // second schedule for waves of large relaxations (created on first use)
+    int split_large = 1;        // knob: waves of >= 4 large relaxations run as two interleaved schedules
     Engine::RootView view;      // of eng[0]'s root (all workers hold the same data)
     // further roots (gomilp_pool_add_root): resident in worker 0's engine only, read in place by the others
     std::vector<int64_t> extra_root;
@@ -148,6 +150,7 @@ int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value) {
     if (!pool || !key) return GOMILP_ERR_BAD_SHAPE;
     std::lock_guard<std::mutex> g(pool->call_mu);
     if (std::string(key) == "batched") { pool->batched = value ? 1 : 0; return GOMILP_OK; }
+    if (std::string(key) == "split_large") { pool->split_large = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "warm_start") { pool->warm_start = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "sample_batch") { pool->batch->set_sampling(value != 0); return GOMILP_OK; }
     int rc = GOMILP_OK;
@@ -299,7 +302,31 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
             }
         };
         auto on_done = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) { on_done_at(i, o, basic, xb); };
-        const int rc = pool->batch->run_roots(views.data(), nroots, root_of, count, koff, var, sign, rhs, tol, on_done, &bs, warm);
+        // Large relaxations (8-workgroup block kernel, rank-16 update): a block step of one schedule is [block kernels of all its
+        // relaxations side by side] then [their updates one after the other]; two schedules of half the wave each, on two
+        // streams, put one half's updates under the other half's block kernels.
+        int m_big = 0, nn_big = 0;
+        for (int r = 0; r < nroots; r++) { m_big = std::max(m_big, views[r]->m + K_max); nn_big = std::max(nn_big, views[r]->n - views[r]->m + (any_p1 ? 1 : 0)); }
+        const bool two = pool->split_large && !warm && count >= 4 && gomilp::bt_batch_k(m_big, gomilp::batch_ldt(nn_big)) == 16;
+        int rc;
+        if (two) {
+            if (!pool->batch2) pool->batch2.reset(new BatchEngine(pool->device));
+            const int64_t half = count / 2;
+            BatchEngine::Stats bs2;
+            int rc2 = GOMILP_OK;
+            auto on_done2 = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) { on_done_at(i + half, o, basic, xb); };
+            std::thread t2([&] {
+                hipSetDevice(pool->device);
+                rc2 = pool->batch2->run_roots(views.data(), nroots, root_of ? root_of + half : nullptr, count - half, koff + half, var, sign, rhs, tol, on_done2, &bs2, nullptr);
+            });
+            rc = pool->batch->run_roots(views.data(), nroots, root_of, half, koff, var, sign, rhs, tol, on_done, &bs, nullptr);
+            t2.join();
+            if (rc == GOMILP_OK) rc = rc2;
+            bs.launches += bs2.launches; bs.supersteps += bs2.supersteps; bs.blocks += bs2.blocks; bs.blocks_sampled += bs2.blocks_sampled;
+            bs.seconds_inner += bs2.seconds_inner; bs.seconds_update += bs2.seconds_update; bs.seconds_total = std::max(bs.seconds_total, bs2.seconds_total);
+        } else {
+            rc = pool->batch->run_roots(views.data(), nroots, root_of, count, koff, var, sign, rhs, tol, on_done, &bs, warm);
+        }
         pool->drain();
         if (rc != GOMILP_OK) return rc;
     } else {

@@ -160,7 +160,7 @@ typedef struct gomilp_frontier_stats {
 
 gomilp_pool *gomilp_pool_create(int device, int workers, int *status);
 void gomilp_pool_destroy(gomilp_pool *pool);
-/* knobs: "sample_batch" (1: time every batched block launch with HIP events), "batched" (default 1: the pivot loops of a wave run device-batched — grid.x = relaxation, O(1) host round trips per
+/* knobs: "split_large" (default 1: a wave of >= 4 relaxations beyond 1024 rows runs as two interleaved schedules), "sample_batch" (1: time every batched block launch with HIP events), "batched" (default 1: the pivot loops of a wave run device-batched — grid.x = relaxation, O(1) host round trips per
  * superstep for the whole wave; 0: one host thread + stream per relaxation); any gomilp_ctx_set key is forwarded to the
  * worker contexts. */
 int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value);
