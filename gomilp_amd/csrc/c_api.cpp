@@ -394,6 +394,16 @@ int64_t gomilp_debug_find_independent(const double *A, int64_t lda, int64_t m, i
     return (int64_t)idx.size();
 }
 
+// diagnostic: the same search with the scan on the device (general_kernels.hip), on a problem resident in `ctx`
+int64_t gomilp_debug_find_independent_device(gomilp_ctx *ctx, int64_t problem, int64_t *idx_out, int64_t cap) {
+    if (!ctx || !idx_out) return -GOMILP_ERR_BAD_SHAPE;
+    std::vector<int32_t> idx;
+    const int rc = ctx->eng->debug_find_independent(problem, idx);
+    if (rc != GOMILP_OK && rc != GOMILP_ERR_SINGULAR) return -rc;
+    for (size_t k = 0; k < idx.size() && (int64_t)k < cap; k++) idx_out[k] = idx[k];
+    return (int64_t)idx.size();
+}
+
 int64_t gomilp_lp_last_trace(gomilp_ctx *ctx, gomilp_pivot *out, int64_t cap) {
     if (!ctx) return -1;
     return ctx->eng->last_trace(out, cap);

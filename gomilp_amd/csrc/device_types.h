@@ -192,6 +192,19 @@ struct BatchOut {
     int64_t piv1, piv2, bland;
 };
 
+// State of the device column search (general_kernels.hip)
+struct GsState {
+    int32_t k;         // columns accepted so far
+    int32_t accept;    // decision about the candidate in flight
+    int32_t kacc;      // its position when accepted
+    int32_t done;      // m - 1 columns accepted: the host takes the last (square) step
+    int32_t stop_col;  // first column the host still has to examine
+    int32_t scanned;   // candidates examined
+    double nR, nRinv;  // |R|_1, |R^-1|_1
+    double vv;         // v^T v of the reflector in flight
+    double beta_last;  // diagonal entry of R produced by the square step (0: the candidate is dependent)
+};
+
 // Control block of the compressed LU schedule (lu_compressed.hip): written by the panel kernel of a round, read by the
 // U-solve / trailing kernels of the same round and by the host between batches of rounds.
 struct LUCtl {

@@ -51,6 +51,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "bt_old") bt_old_ = v ? 1 : 0;
     else if (key == "bt_upd_valu") bt_upd_valu_ = v ? 1 : 0;
     else if (key == "bt_fault") bt_fault_ = v ? 1 : 0;
+    else if (key == "general_device") general_device_ = v ? 1 : 0;
     else if (key == "bt_groups") { if (v != -1 && v != 0 && v != 2 && v != 4 && v != 8) return GOMILP_ERR_BAD_SHAPE; bt_groups_ = v; }
     else if (key == "bt_stamps") bt_stamps_ = v ? 1 : 0;
     else if (key == "cond_guard") cond_guard_ = v ? 1 : 0;
@@ -1000,10 +1001,11 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
         // general case (engine_general.cpp): host search over a kept copy of A, small problems on the tableau pipelines
         if (!use_tab || !ensure_host_A(P)) return finish(GOMILP_ERR_UNSUPPORTED);
         if (!initial_basic) {
-            rc = general_find_linearly_independent(P.hA, m, n, basic);
+            // 256 rows and more: the scan runs on the device (host: 46 ms at 600 rows, 180 ms at 1000); the search's last step inverts the basis
+            rc = (m >= 256 && general_device_) ? find_independent_device(P, basic, &binv_host) : general_find_linearly_independent(P.hA, m, n, basic, &binv_host);
             if (rc != GOMILP_OK) return finish(rc);  // ErrSingular, simplex.go:495-497
         }
-        if (!general_basis_inverse(P.hA, m, n, basic, n, std::vector<double>(), binv_host))
+        if (binv_host.size() != (size_t)m * m && !general_basis_inverse(P.hA, m, n, basic, n, std::vector<double>(), binv_host))
             return finish(initial_basic ? GOMILP_ERR_PANIC : GOMILP_ERR_SINGULAR);
         // xb = ab^-1 b with the reference's own arithmetic (gonum-order LU on the device): the feasibility test of
         // simplex.go:459-469 then sees the same bits
@@ -1340,6 +1342,98 @@ int64_t Engine::last_trace(gomilp_pivot *out, int64_t cap) {
     const int64_t cnt = std::min<int64_t>((int64_t)last_trace_.size(), cap);
     if (out && cnt > 0) memcpy(out, last_trace_.data(), (size_t)cnt * sizeof(gomilp_pivot));
     return last_trace_total_;
+}
+
+
+// findLinearlyIndependent: the column scan on the device (general_kernels.hip), five launches per candidate and one look at the
+// state block per chunk of candidates; Q^T and R^-1 live in the two B^-1 buffers of the revised pipelines (free at this point)
+int Engine::find_independent_device(const Problem &P, std::vector<int32_t> &basic, std::vector<double> *binv_out) {
+    Work &w = *w_;
+    const int m = P.m, n = P.n, ldq = P.ld;
+    const double t_gs0 = now_s();
+    basic.clear();
+    if (!w.gs_state) {
+        HIP_TRY(dmalloc(&w.gs_state, 1));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.gs_host), sizeof(GsState), hipHostMallocDefault));
+    }
+    if (w.cap_gs_idx < m) {
+        if (w.gs_idx) hipFree(w.gs_idx);
+        w.gs_idx = nullptr;
+        HIP_TRY(dmalloc(&w.gs_idx, (size_t)m + 64));
+        w.cap_gs_idx = m + 64;
+    }
+    double *QT = w.binv[0], *Rinv = w.binv[1];
+    double *wv = w.yscratch, *tv = w.yscratch + P.ld, *yv = w.yscratch + 2 * (size_t)P.ld;   // 64 rows of ld doubles: w, t, 16 partial y
+    HIP_TRY(hipMemsetAsync(Rinv, 0, (size_t)m * ldq * sizeof(double), stream_));
+    launch_gs_init(QT, ldq, m, w.gs_state, stream_);
+    launches_++;
+    int col = n - 1;
+    for (;;) {
+        const int chunk = std::min(col + 1, 128);
+        for (int q = 0; q < chunk; q++, col--) launch_gs_candidate(P.dAt + (size_t)col * P.ld, QT, Rinv, ldq, m, wv, tv, yv, col, w.gs_idx, w.gs_state, stream_);
+        launches_ += 5 * chunk;
+        HIP_TRY(hipMemcpyAsync(w.gs_host, w.gs_state, sizeof(GsState), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(sync_stream());
+        HIP_TRY(hipGetLastError());
+        if (w.gs_host->done || col < 0) break;
+    }
+    const int k = w.gs_host->k;
+    std::vector<int32_t> idx(k);
+    if (k) HIP_TRY(hipMemcpy(idx.data(), w.gs_idx, (size_t)k * sizeof(int32_t), hipMemcpyDeviceToHost));
+    basic = idx;
+    if (k < m - 1 || !w.gs_host->done) return GOMILP_ERR_SINGULAR;   // the columns ran out: simplex.go:495-497
+    const double t_scan = now_s();
+    // the square step: the first remaining candidate is taken tentatively on the device (reflector, new column of R^-1), B^-1 =
+    // R^-1 Q^T is formed there, and the host judges kappa_1 of the matrix itself, |C|_1 |C^-1|_1 (mat.Cond of a square matrix
+    // goes through its LU in the reference).  A rejected candidate sends the rest of the scan to the host form.
+    int cand = w.gs_host->stop_col;
+    int rcl = GOMILP_ERR_SINGULAR;
+    if (cand >= 0) {
+        launch_gs_candidate(P.dAt + (size_t)cand * P.ld, QT, Rinv, ldq, m, wv, tv, yv, cand, w.gs_idx, w.gs_state, stream_, 1);
+        launch_gs_binv(Rinv, QT, ldq, m, w.W, stream_);
+        launches_ += 6;
+        HIP_TRY(hipMemcpyAsync(w.h_W, w.W, (size_t)m * ldq * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipMemcpyAsync(w.gs_host, w.gs_state, sizeof(GsState), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(sync_stream());
+        HIP_TRY(hipGetLastError());
+        double nC = 0, nI = 0;
+        bool finite = w.gs_host->beta_last != 0;
+        for (int p = 0; p < m && finite; p++) {   // |C|_1: largest absolute column sum over the m basis columns
+            const int j = p < m - 1 ? basic[p] : cand;
+            double sc = 0;
+            for (int r = 0; r < m; r++) sc += fabs(P.hA[(size_t)r * n + j]);
+            nC = std::max(nC, sc);
+        }
+        if (finite) {
+            std::vector<double> colsum(m, 0.0);
+            for (int r = 0; r < m; r++) { const double *row = w.h_W + (size_t)r * ldq; for (int c2 = 0; c2 < m; c2++) colsum[c2] += fabs(row[c2]); }
+            for (int c2 = 0; c2 < m; c2++) { if (!std::isfinite(colsum[c2])) finite = false; nI = std::max(nI, colsum[c2]); }
+        }
+        const double cond = finite ? nC * nI : std::numeric_limits<double>::infinity();
+        if (!(cond > 1e12)) {   // simplex.go:630
+            basic.push_back(cand);
+            if (binv_out) {
+                binv_out->resize((size_t)m * m);
+                for (int r = 0; r < m; r++) memcpy(binv_out->data() + (size_t)r * m, w.h_W + (size_t)r * ldq, (size_t)m * sizeof(double));
+            }
+            rcl = GOMILP_OK;
+        } else {
+            rcl = general_finish_last_column(P.hA, m, n, basic, cand - 1, binv_out);
+        }
+    }
+    if (getenv("GOMILP_DEBUG_GS")) fprintf(stderr, "gs: m %d scanned %d scan %.2f ms last column %.2f ms\n", m, w.gs_host->scanned, 1e3 * (t_scan - t_gs0), 1e3 * (now_s() - t_scan));
+    return rcl;
+}
+
+int Engine::debug_find_independent(int64_t id, std::vector<int32_t> &idxs) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (id < 0 || (size_t)id >= problems_.size() || !problems_[id]) return GOMILP_ERR_BAD_SHAPE;
+    const Problem &P = *problems_[id];
+    HIP_TRY(hipSetDevice(device_));
+    int rc = ensure_work(P.m, P.n + 1);
+    if (rc != GOMILP_OK) return rc;
+    if (!ensure_host_A(P)) return GOMILP_ERR_UNSUPPORTED;
+    return find_independent_device(P, idxs, nullptr);
 }
 
 }  // namespace gomilp

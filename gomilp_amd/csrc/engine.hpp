@@ -86,6 +86,8 @@ class Engine {
     // `basic` (m entries) and updated x_B in, gonum-order solve of that basis, z, x out; `loop_rc` as Engine::solve
     int finish_from_basis(int64_t id, const int32_t *basic, const double *xb_updated, int loop_rc, double *opt_f, double *opt_x,
                           int32_t *has_x, int64_t *basis_out, gomilp_lp_stats *stats);
+    // diagnostic: the device column search on a resident problem (tests compare it with the host forms)
+    int debug_find_independent(int64_t id, std::vector<int32_t> &idxs);
 
    private:
     struct Work;  // device work buffers, sized for the largest problem seen
@@ -116,6 +118,8 @@ class Engine {
                  int32_t *has_x, int64_t *basis_out, gomilp_lp_stats *st);
     int final_solve(const Problem &P, int ncols_rows, std::vector<double> &xb_exact, bool *singular, const int32_t *basic_host = nullptr);
     bool ensure_host_A(const Problem &P);
+    // findLinearlyIndependent with the scan on the device (general_kernels.hip) and the last, square step on the host
+    int find_independent_device(const Problem &P, std::vector<int32_t> &basic, std::vector<double> *binv_out);
     int stage_upload(void *dst, const void *src, size_t bytes);
     hipError_t sync_stream();
     int upload_index_lists(const std::vector<int32_t> &basic, const std::vector<int32_t> &nonbasic);
@@ -135,7 +139,7 @@ class Engine {
     std::unique_ptr<Work> w_;
     // knobs
     int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 2, tableau_ = 1, blocked_ = 1, block_k_ = 0,  // block_k_ 0 = auto
-            bt_nt_ = 0, bt_old_ = 0, bt_stamps_ = 0, bt_upd_valu_ = 0, bt_fault_ = 0, bt_groups_ = 0,   // bt_groups_: -1 never, 0 by shape, 2 / 4 / 8 forced
+            bt_nt_ = 0, bt_old_ = 0, bt_stamps_ = 0, bt_upd_valu_ = 0, bt_fault_ = 0, general_device_ = 1, bt_groups_ = 0,   // bt_groups_: -1 never, 0 by shape, 2 / 4 / 8 forced
             cond_guard_ = 1;   // replay the condition guards of the reference on the host for bases of up to 64 rows
     bool shadow_trace_ = false;   // this solve records its pivots for the replay even when the caller did not ask for a trace   // developer knobs of the block kernels (per context: tests force the 1024-thread instance)
     // per-solve state
@@ -155,7 +159,8 @@ class Engine {
 };
 
 // engine_general.cpp
-int general_find_linearly_independent(const std::vector<double> &A, int m, int n, std::vector<int32_t> &idxs);
+int general_find_linearly_independent(const std::vector<double> &A, int m, int n, std::vector<int32_t> &idxs, std::vector<double> *binv_out = nullptr);
+int general_finish_last_column(const std::vector<double> &A, int m, int n, std::vector<int32_t> &idxs, int start_col, std::vector<double> *binv_out);
 int general_find_linearly_independent_slow(const std::vector<double> &A, int m, int n, std::vector<int32_t> &idxs);
 bool general_basis_inverse(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, int ncols_with_art,
                            const std::vector<double> &art, std::vector<double> &binv);
@@ -192,6 +197,12 @@ void launch_tab_r(const double *T, int ldt, int m, int nn, const double *cost, c
                   double *scratch, double *r, bool tiled, hipStream_t s);
 void launch_tab_row_colmax(const double *T, int ldt, int m, int nn, int row, double *out, bool tiled, hipStream_t s);
 void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb, double *dvec, double *move, bool tiled, hipStream_t s);
+// general_kernels.hip
+void launch_gs_init(double *QT, int ldq, int m, GsState *st, hipStream_t s);
+void launch_gs_candidate(const double *acol, double *QT, double *Rinv, int ldq, int m, double *w, double *t, double *ypart, int cand, int32_t *idxs, GsState *st, hipStream_t s,
+                         int last = 0);
+int gs_scratch_rows();
+void launch_gs_binv(const double *Rinv, const double *QT, int ldq, int m, double *C, hipStream_t s);
 // bt_kernels.hip
 bool bt_supported(int m, int nn);
 int bt_max_k();

@@ -102,9 +102,27 @@ double cond1_exact(const std::vector<double> &C, int m, int k) {
 // kappa_1(R') = |R'|_1 |R'^-1|_1 of the decision `mat.Cond(columns, 1) <= 1e12` (simplex.go:630; R of a full-rank matrix is unique
 // up to row signs, which no norm sees) costs O(m k + k^2) per candidate, O(m^2 n) in all.  The last column makes the matrix
 // square, where the reference measures kappa_1 of the matrix itself through its LU: |A|_1 |R^-1 Q^T|_1 here.
-int general_find_linearly_independent(const std::vector<double> &A, int m, int n, std::vector<int32_t> &idxs) {
+// dot product with eight independent partial sums: a single chain of dependent additions (the compiler may not reassociate)
+// made the search latency-bound — 125 ms for 600 rows, 580 ms for 1000; these are the engine's own quantities (the decision
+// is a threshold on a condition number), not values the reference defines bit by bit
+static bool invert_threaded(const std::vector<double> &A, int n, std::vector<double> &inv);
+
+static inline double dot8(const double *x, const double *y, int n) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        s0 += x[i] * y[i]; s1 += x[i + 1] * y[i + 1]; s2 += x[i + 2] * y[i + 2]; s3 += x[i + 3] * y[i + 3];
+        s4 += x[i + 4] * y[i + 4]; s5 += x[i + 5] * y[i + 5]; s6 += x[i + 6] * y[i + 6]; s7 += x[i + 7] * y[i + 7];
+    }
+    for (; i < n; i++) s0 += x[i] * y[i];
+    return ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+}
+
+int general_find_linearly_independent(const std::vector<double> &A, int m, int n, std::vector<int32_t> &idxs, std::vector<double> *binv_out) {
     idxs.clear();
-    std::vector<double> V((size_t)m * m, 0.0);      // reflector k in column k (rows k..m-1), v_k normalised so that H = I - 2 v v^T / (v^T v)
+    if (binv_out) binv_out->clear();
+    // reflector k in ROW k of V (entries k..m-1; contiguous: unit-stride dot / axpy), H = I - 2 v v^T / (v^T v)
+    std::vector<double> V((size_t)m * m, 0.0);
     std::vector<double> vnorm2(m, 0.0);
     std::vector<double> R((size_t)m * m, 0.0), Rinv((size_t)m * m, 0.0);   // upper triangular, row-major m x m (leading k x k used)
     std::vector<double> colsum_R(m, 0.0), colsum_Rinv(m, 0.0);              // 1-norm bookkeeping: absolute column sums
@@ -119,11 +137,9 @@ int general_find_linearly_independent(const std::vector<double> &A, int m, int n
             double nrm = 0;
             for (int r = 0; r < m; r++) nrm = hypot(nrm, w[r]);
             const double alpha = w[0], beta = alpha >= 0 ? -nrm : nrm;
-            for (int r = 0; r < m; r++) V[(size_t)r * m + 0] = w[r];
+            for (int r = 0; r < m; r++) V[r] = w[r];
             V[0] = alpha - beta;
-            double vv = 0;
-            for (int r = 0; r < m; r++) vv += V[(size_t)r * m] * V[(size_t)r * m];
-            vnorm2[0] = vv;
+            vnorm2[0] = dot8(V.data(), V.data(), m);
             R[0] = beta; Rinv[0] = beta != 0 ? 1 / beta : std::numeric_limits<double>::infinity();
             colsum_R[0] = fabs(beta); colsum_Rinv[0] = fabs(Rinv[0]);
             nR = colsum_R[0]; nRinv = colsum_Rinv[0];
@@ -134,10 +150,9 @@ int general_find_linearly_independent(const std::vector<double> &A, int m, int n
         // w = H_{k-1} ... H_0 a
         for (int j = 0; j < k; j++) {
             if (vnorm2[j] == 0) continue;
-            double dot = 0;
-            for (int r = j; r < m; r++) dot += V[(size_t)r * m + j] * w[r];
-            const double f = 2 * dot / vnorm2[j];
-            for (int r = j; r < m; r++) w[r] -= f * V[(size_t)r * m + j];
+            const double *vj = V.data() + (size_t)j * m;
+            const double f = 2 * dot8(vj + j, w.data() + j, m - j) / vnorm2[j];
+            for (int r = j; r < m; r++) w[r] -= f * vj[r];
         }
         double nrm = 0;
         for (int r = k; r < m; r++) nrm = hypot(nrm, w[r]);
@@ -147,8 +162,7 @@ int general_find_linearly_independent(const std::vector<double> &A, int m, int n
         for (int r = 0; r < k; r++) cs += fabs(w[r]);
         double csi = beta != 0 ? fabs(1 / beta) : std::numeric_limits<double>::infinity();
         for (int r = 0; r < k; r++) {
-            double acc = 0;
-            for (int c2 = r; c2 < k; c2++) acc += Rinv[(size_t)r * m + c2] * w[c2];
+            const double acc = dot8(Rinv.data() + (size_t)r * m + r, w.data() + r, k - r);
             t[r] = beta != 0 ? -acc / beta : std::numeric_limits<double>::infinity();
             csi += fabs(t[r]);
         }
@@ -162,9 +176,11 @@ int general_find_linearly_independent(const std::vector<double> &A, int m, int n
             for (int r = 0; r < m; r++) Acols[(size_t)r * m + k] = A[(size_t)r * n + i];
             if (!(nrm > 0) && !(fabs(alpha) > 0)) cond = std::numeric_limits<double>::infinity();
             else {
-                std::vector<double> C((size_t)m * m), inv;
-                for (size_t q = 0; q < C.size(); q++) C[q] = Acols[q];
-                cond = invert(C, m, inv) ? norm1(C, m, m, m) * norm1(inv, m, m, m) : std::numeric_limits<double>::infinity();
+                // (threaded LU above 256 rows: this one inversion used to cost more than the whole incremental search; the caller
+                // reuses it as B^-1 of the starting basis — the columns of C are the basis in position order)
+                std::vector<double> inv;
+                cond = invert_threaded(Acols, m, inv) ? norm1(Acols, m, m, m) * norm1(inv, m, m, m) : std::numeric_limits<double>::infinity();
+                if (!(cond > 1e12) && binv_out) binv_out->swap(inv);
             }
         }
         if (cond > 1e12) continue;   // :630 not linearly independent (a NaN passes, as in the reference)
@@ -173,13 +189,33 @@ int general_find_linearly_independent(const std::vector<double> &A, int m, int n
         R[(size_t)k * m + k] = beta; Rinv[(size_t)k * m + k] = 1 / beta;
         colsum_R[k] = cs; colsum_Rinv[k] = csi;
         nR = std::max(nR, cs); nRinv = std::max(nRinv, csi);
-        double vv = 0;
-        for (int r = k; r < m; r++) { const double v = (r == k) ? alpha - beta : w[r]; V[(size_t)r * m + k] = v; vv += v * v; }
-        vnorm2[k] = vv;
+        double *vk = V.data() + (size_t)k * m;
+        for (int r = k; r < m; r++) vk[r] = (r == k) ? alpha - beta : w[r];
+        vnorm2[k] = dot8(vk + k, vk + k, m - k);
         if (k + 1 < m) for (int r = 0; r < m; r++) Acols[(size_t)r * m + k] = A[(size_t)r * n + i];
         idxs.push_back(i);
     }
     return (int)idxs.size() == m ? GOMILP_OK : GOMILP_ERR_SINGULAR;  // :495-497
+}
+
+// The last step of the search when the device form (general_kernels.hip) has accepted m - 1 columns: the candidate makes the
+// matrix square, where the reference measures kappa_1 of the matrix itself through its LU (mat.Cond of a square matrix) —
+// |C|_1 |C^-1|_1 with the inversion the caller needs as B^-1 anyway.  Candidates from `start_col` downwards.
+int general_finish_last_column(const std::vector<double> &A, int m, int n, std::vector<int32_t> &idxs, int start_col, std::vector<double> *binv_out) {
+    if ((int)idxs.size() != m - 1) return GOMILP_ERR_SINGULAR;
+    std::vector<double> C((size_t)m * m);
+    for (int k = 0; k < m - 1; k++)
+        for (int r = 0; r < m; r++) C[(size_t)r * m + k] = A[(size_t)r * n + idxs[k]];
+    for (int i = start_col; i >= 0; i--) {
+        for (int r = 0; r < m; r++) C[(size_t)r * m + (m - 1)] = A[(size_t)r * n + i];
+        std::vector<double> inv;
+        const double cond = invert_threaded(C, m, inv) ? norm1(C, m, m, m) * norm1(inv, m, m, m) : std::numeric_limits<double>::infinity();
+        if (cond > 1e12) continue;   // simplex.go:630
+        if (binv_out) binv_out->swap(inv);
+        idxs.push_back(i);
+        return GOMILP_OK;
+    }
+    return GOMILP_ERR_SINGULAR;   // :495-497
 }
 
 // reference form of the same decisions: a fresh exact condition number per candidate (O(m^4); kept for the tests that pin

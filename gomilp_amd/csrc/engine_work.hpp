@@ -71,6 +71,8 @@ struct Engine::Work {
     double *T[2] = {nullptr, nullptr}, *R[2] = {nullptr, nullptr}, *tscratch = nullptr;  // tableau pipelines
     double *btU = nullptr, *btV = nullptr;  // blocked tableau: rank-1 terms of the running block
     double *xbuf = nullptr;                 // multi-workgroup block kernel: exchange records (btg_kernels.hip)
+    GsState *gs_state = nullptr, *gs_host = nullptr;   // device column search (general_kernels.hip): state block + pinned mirror
+    int32_t *gs_idx = nullptr; int cap_gs_idx = 0;
     int32_t *srcpos = nullptr;
     int32_t *unitrow = nullptr;  // final solve: unit-column rows per basis position
     int32_t *denseflag = nullptr, *dlist = nullptr;  // final solve: steps that did arithmetic / their compact list
@@ -124,6 +126,9 @@ struct Engine::Work {
         for (double **p : {&T[0], &T[1], &R[0], &R[1], &tscratch, &btU, &btV, &xbuf}) { if (*p) hipFree(*p); *p = nullptr; }
         if (srcpos) hipFree(srcpos); srcpos = nullptr;
         cap_T = 0; cap_ldt = 0; cap_btU = 0;
+        if (gs_state) hipFree(gs_state); gs_state = nullptr;
+        if (gs_host) hipHostFree(gs_host); gs_host = nullptr;
+        if (gs_idx) hipFree(gs_idx); gs_idx = nullptr; cap_gs_idx = 0;
         if (stamps) hipFree(stamps); stamps = nullptr;
         if (stamps_host) hipHostFree(stamps_host); stamps_host = nullptr;
         if (st) hipFree(st); st = nullptr;

@@ -57,7 +57,7 @@ class FrontierStats(C.Structure):
 
 
 EXPORTS = [
-    "gomilp_lp_upload_child", "gomilp_pool_create", "gomilp_pool_destroy", "gomilp_pool_set", "gomilp_pool_set_root", "gomilp_frontier_solve", "gomilp_pool_add_root", "gomilp_frontier_solve_roots", "gomilp_pool_solve_root", "gomilp_debug_find_independent",
+    "gomilp_lp_upload_child", "gomilp_pool_create", "gomilp_pool_destroy", "gomilp_pool_set", "gomilp_pool_set_root", "gomilp_frontier_solve", "gomilp_pool_add_root", "gomilp_frontier_solve_roots", "gomilp_pool_solve_root", "gomilp_debug_find_independent", "gomilp_debug_find_independent_device",
     "gomilp_lp_simplex", "gomilp_ctx_create", "gomilp_ctx_destroy", "gomilp_ctx_device", "gomilp_ctx_set",
     "gomilp_lp_upload", "gomilp_lp_free", "gomilp_lp_solve_resident", "gomilp_lp_last_trace", "gomilp_version",
     "gomilp_device_count", "gomilp_compiled_arch", "gomilp_comm_unique_id", "gomilp_comm_create", "gomilp_comm_destroy",
@@ -107,6 +107,8 @@ def lib():
     L.gomilp_frontier_solve_roots.argtypes = [C.c_void_p, C.c_int64, i32p, ip, i32p, dp, dp, C.c_double, dp, dp, C.c_int64, i32p, i32p,
                                               C.POINTER(FrontierStats)]
     L.gomilp_debug_find_independent.restype = C.c_int64
+    L.gomilp_debug_find_independent_device.restype = C.c_int64
+    L.gomilp_debug_find_independent_device.argtypes = [C.c_void_p, C.c_int64, ip, C.c_int64]
     L.gomilp_debug_find_independent.argtypes = [dp, C.c_int64, C.c_int64, C.c_int64, ip, C.c_int]
     L.gomilp_comm_unique_id.argtypes = [C.c_char_p]
     L.gomilp_comm_create.restype = C.c_void_p
@@ -378,6 +380,22 @@ def find_independent(A, fast: bool = True):
     if cnt < 0:
         raise ValueError("bad shape")
     return [int(v) for v in idx[:cnt]]
+
+
+def find_independent_device(A, device: int = -1):
+    """The same search with the column scan on the GPU (general_kernels.hip; the last, square step on the host)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    m, n = A.shape
+    cx = Context(device)
+    try:
+        p = cx.upload(np.zeros(n), A, np.zeros(m))
+        idx = np.zeros(m, dtype=np.int64)
+        cnt = lib().gomilp_debug_find_independent_device(cx._h, p.pid, _ip(idx), m)
+        if cnt < 0:
+            raise RuntimeError("device search failed: %s" % STATUS_NAMES.get(-cnt, -cnt))
+        return [int(v) for v in idx[:cnt]]
+    finally:
+        cx.close()
 
 
 def comm_unique_id() -> bytes:

@@ -218,6 +218,8 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
  * non-slack starting bases (exact kappa_1 instead of the Hager estimate).  fast = 1: one Householder QR carried along,
  * O(m^2 n); fast = 0: a fresh factorisation per candidate, O(m^4).  idx_out has room for m entries; returns their count. */
 int64_t gomilp_debug_find_independent(const double *A, int64_t lda, int64_t m, int64_t n, int64_t *idx_out, int fast);
+/* the same search with the column scan on the device, on a resident problem (tests compare the two) */
+int64_t gomilp_debug_find_independent_device(gomilp_ctx *ctx, int64_t problem, int64_t *idx_out, int64_t cap);
 
 /* Library / device probes (no compute): used by the loader checks and by __graft_entry__. */
 const char *gomilp_version(void);

@@ -86,3 +86,26 @@ def test_comm_needs_a_device():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         lp.comm_unique_id()
+
+
+def _search_case(seed):
+    r = np.random.default_rng(seed)
+    m = int(r.integers(2, 9)); n = int(r.integers(m, m + 8))
+    if seed % 2:
+        return r.integers(-2, 3, (m, n)).astype(float)        # small integers: exact dependencies, zero columns
+    A = r.standard_normal((m, n))
+    A[r.random((m, n)) < 0.3] = 0
+    return A
+
+
+def test_column_search_host_forms_agree_with_the_oracle():
+    """findLinearlyIndependent (simplex.go:611-637): the engine's incremental-QR search (host form, also the fallback of the
+    device form), its O(m^4) reference form and the oracle's restatement keep the same columns on 400 small matrices with
+    exact dependencies and zero columns.  Host-only entry of the library: no GPU needed."""
+    from gomilp_amd import lp
+    from oracle import oracle as O
+    for seed in range(400):
+        A = _search_case(seed)
+        f, s, o = lp.find_independent(A, True), lp.find_independent(A, False), O.find_linearly_independent(A)
+        assert list(f) == list(s) == list(o), seed
+
