@@ -1001,8 +1001,8 @@ int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *
         // general case (engine_general.cpp): host search over a kept copy of A, small problems on the tableau pipelines
         if (!use_tab || !ensure_host_A(P)) return finish(GOMILP_ERR_UNSUPPORTED);
         if (!initial_basic) {
-            // 256 rows and more: the scan runs on the device (host: 46 ms at 600 rows, 180 ms at 1000); the search's last step inverts the basis
-            rc = (m >= 256 && general_device_) ? find_independent_device(P, basic, &binv_host) : general_find_linearly_independent(P.hA, m, n, basic, &binv_host);
+            // 224 rows and more: the scan runs on the device (180 rows: host 4.2 ms, device 5.8; 256 rows: 25 / 7.7; 600: 46 / 13; 1000: 180 / 31)
+            rc = (m >= 224 && general_device_) ? find_independent_device(P, basic, &binv_host) : general_find_linearly_independent(P.hA, m, n, basic, &binv_host);
             if (rc != GOMILP_OK) return finish(rc);  // ErrSingular, simplex.go:495-497
         }
         if (binv_host.size() != (size_t)m * m && !general_basis_inverse(P.hA, m, n, basic, n, std::vector<double>(), binv_host))
