@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--milp-nodes", type=int, default=127, help="C3: node budget of the host B&B over GPU relaxations (0 = skip)")
     ap.add_argument("--debug-one-gpu", action="store_true", help="rehearsal of the N > 1 control flow on a one-GPU box: every rank uses GPU 0, "
                     "torch.distributed over gloo, incumbent table over gloo + gomilp_incumbent_pick (RCCL refuses two ranks on one device)")
+    ap.add_argument("--general", type=int, default=1, help="extra figure: an equality-constrained LP (no slack basis: the findLinearlyIndependent path) (0 = skip)")
     ap.add_argument("--c4", type=int, default=1, help="extra figure: one timed solve of the 4096x8192 LP (BASELINE config 4) (0 = skip)")
     return ap.parse_args()
 
@@ -508,6 +509,33 @@ def main() -> int:
         p4.free()
         cx4.close()
         del c4, A4, b4
+
+    # ---- a standard form WITHOUT a slack basis (equality rows): findLinearlyIndependent (simplex.go:611-637) decides the start
+    if args.general:
+        rng = np.random.default_rng(5)
+        mg, ng = 500, 700
+        x0 = np.abs(rng.standard_normal(ng))
+        Ae = rng.standard_normal((mg, ng)); Ge = rng.standard_normal((mg, ng))
+        ce = np.abs(rng.standard_normal(ng))
+        # [Ae 0; Ge I] [x; s] = [Ae x0; Ge x0 + slack]: 1000 rows, 1200 columns, feasible and bounded by construction
+        A0 = np.zeros((2 * mg, ng + mg)); A0[:mg, :ng] = Ae; A0[mg:, :ng] = Ge; A0[mg:, ng:] = np.eye(mg)
+        b0 = np.concatenate([Ae @ x0, Ge @ x0 + np.abs(rng.standard_normal(mg))])
+        c0 = np.concatenate([ce, np.zeros(mg)])
+        gres = {}
+        for devsearch in (1, 0):
+            cxg = lp.Context(device=local_rank, general_device=devsearch)
+            pg = cxg.upload(c0, A0, b0)
+            pg.solve(0.0)
+            t1 = time.perf_counter(); rg = pg.solve(0.0); tg = time.perf_counter() - t1
+            gres[devsearch] = (tg, rg)
+            cxg.close()
+        (tdev, rdev), (thost, rhost) = gres[1], gres[0]
+        out["general_basis"] = {"workload": "%dx%d standard form with %d equality rows and no slack basis (seed 5), one full solve" % (2 * mg, ng + mg, mg),
+                                "status": int(rdev.status), "pivots": int(rdev.stats["pivots_phase1"] + rdev.stats["pivots_phase2"]),
+                                "seconds": tdev, "seconds_pivot_loops": rdev.stats["seconds_pivot_loop"], "seconds_with_host_search": thost,
+                                "same_result_as_host_search": bool(rdev.status == rhost.status and rdev.z == rhost.z and np.array_equal(rdev.x, rhost.x)),
+                                "note": "initial-basis search on the device (general_kernels.hip: explicit Q^T, five launches per candidate column); "
+                                        "the reference form of the search is O(m^4)"}
 
     # ---- BASELINE config 5 on one GPU (the figure the N > 1 lines scale from)
     if args.frontier_vars > 0:

@@ -6,7 +6,7 @@ mkdir -p $OUT
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 cd $R
-HEAD="--no-cpu-baseline --concurrent 0 --milp-nodes 0 --c4 0 --frontier-vars 0"
+HEAD="--no-cpu-baseline --concurrent 0 --milp-nodes 0 --c4 0 --frontier-vars 0 --general 0"
 # 1. default bench, unprofiled (the numbers DESIGN.md quotes)
 python bench.py > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
 # 2. kernel stats of the headline region alone (metric LP) and of the frontier leg alone
@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_M -- python3 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_C5 -- python3 tools/wave_prof.py 8 4 > $OUT/wave_profiled.out 2> $OUT/stats_C5.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_C4 -- python3 bench.py --workload C4 --steps 2 --warmup 1 $HEAD > $OUT/bench_C4_profiled.json 2> $OUT/stats_C4.err
 # 3. PMC passes (separate runs; counters only)
-SMALL="--steps 1 --warmup 0 --no-cpu-baseline --concurrent 0 --milp-nodes 0 --c4 0"
+SMALL="--steps 1 --warmup 0 --no-cpu-baseline --concurrent 0 --milp-nodes 0 --c4 0 --general 0"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $SMALL > $OUT/pmc_f.json 2> $OUT/pmc_f.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py $SMALL > $OUT/pmc_w.json 2> $OUT/pmc_w.err
 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/pmc_mfma -- python3 bench.py $SMALL > $OUT/pmc_m.json 2> $OUT/pmc_m.err
