@@ -1365,10 +1365,47 @@ int Engine::find_independent_device(const Problem &P, std::vector<int32_t> &basi
     double *QT = w.binv[0], *Rinv = w.binv[1];
     double *wv = w.yscratch, *tv = w.yscratch + P.ld, *yv = w.yscratch + 2 * (size_t)P.ld;   // 64 rows of ld doubles: w, t, 16 partial y
     HIP_TRY(hipMemsetAsync(Rinv, 0, (size_t)m * ldq * sizeof(double), stream_));
-    launch_gs_init(QT, ldq, m, w.gs_state, stream_);
+    // The scan starts at the slack columns (simplex.go:618).  A unit column e_r after k unit columns with other rows is kept with
+    // kappa_1 = 1, one with a row already taken is exactly dependent and dropped; its Householder step only negates a row of Q^T
+    // or swaps two (the rank-1 update acts on 0 / +-1 entries: no rounding), so the leading run of unit columns is decided here
+    // in O(1) each and the device scan starts behind it with Q^T = that signed permutation, R = R^-1 = diag(beta).
+    int col = n - 1, s0 = 0;
+    {
+        std::vector<int32_t> perm(m), inv(m);
+        std::vector<double> sgn(m, 1.0), beta(m, 1.0);
+        for (int i = 0; i < m; i++) { perm[i] = i; inv[i] = i; }
+        std::vector<int32_t> acc;
+        for (; col >= 0 && s0 < m - 1; col--) {
+            if (!(P.nnz[col] == 1 && P.allone[col])) break;
+            const int r = P.lastrow[col], p = inv[r], k = s0;
+            if (p < k) continue;                       // row r already carries an accepted unit column: beta = 0, cond = inf, dropped
+            if (p == k) { beta[k] = sgn[k] >= 0 ? -1.0 : 1.0; sgn[k] = -sgn[k]; }
+            else {                                     // alpha = 0, beta = -1, v = e_k + sgn[p] e_p: rows k and p trade places
+                const int pk = perm[k];
+                const double sk = sgn[k], sp = sgn[p];
+                beta[k] = -1.0;
+                perm[k] = r; sgn[k] = -1.0;
+                perm[p] = pk; sgn[p] = -sp * sk;
+                inv[r] = k; inv[pk] = p;
+            }
+            acc.push_back(col);
+            s0++;
+        }
+        if (s0) {
+            int rcp = stage_upload(w.gs_idx, acc.data(), (size_t)s0 * sizeof(int32_t));
+            if (rcp == GOMILP_OK) rcp = stage_upload(w.lpos, perm.data(), (size_t)m * sizeof(int32_t));
+            if (rcp == GOMILP_OK) rcp = stage_upload(yv + 20 * (size_t)P.ld, sgn.data(), (size_t)m * sizeof(double));
+            if (rcp == GOMILP_OK) rcp = stage_upload(yv + 21 * (size_t)P.ld, beta.data(), (size_t)m * sizeof(double));
+            if (rcp != GOMILP_OK) return rcp;
+            launch_gs_init_perm(QT, Rinv, ldq, m, w.lpos, yv + 20 * (size_t)P.ld, yv + 21 * (size_t)P.ld, s0, w.gs_state, stream_);
+        } else {
+            launch_gs_init(QT, ldq, m, w.gs_state, stream_);
+        }
+    }
     launches_++;
-    int col = n - 1;
-    for (;;) {
+    bool scan_done = s0 >= m - 1;
+    int stop_after_prefix = col;
+    for (; !scan_done;) {
         const int chunk = std::min(col + 1, 128);
         for (int q = 0; q < chunk; q++, col--) launch_gs_candidate(P.dAt + (size_t)col * P.ld, QT, Rinv, ldq, m, wv, tv, yv, col, w.gs_idx, w.gs_state, stream_);
         launches_ += 5 * chunk;
@@ -1376,6 +1413,11 @@ int Engine::find_independent_device(const Problem &P, std::vector<int32_t> &basi
         HIP_TRY(sync_stream());
         HIP_TRY(hipGetLastError());
         if (w.gs_host->done || col < 0) break;
+    }
+    if (scan_done) {   // the unit columns alone filled m - 1 positions: the device never scanned
+        HIP_TRY(hipMemcpyAsync(w.gs_host, w.gs_state, sizeof(GsState), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(sync_stream());
+        w.gs_host->stop_col = stop_after_prefix;
     }
     const int k = w.gs_host->k;
     std::vector<int32_t> idx(k);

@@ -199,6 +199,7 @@ void launch_tab_row_colmax(const double *T, int ldt, int m, int nn, int row, dou
 void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb, double *dvec, double *move, bool tiled, hipStream_t s);
 // general_kernels.hip
 void launch_gs_init(double *QT, int ldq, int m, GsState *st, hipStream_t s);
+void launch_gs_init_perm(double *QT, double *Rinv, int ldq, int m, const int32_t *perm, const double *sgn, const double *beta, int s0, GsState *st, hipStream_t s);
 void launch_gs_candidate(const double *acol, double *QT, double *Rinv, int ldq, int m, double *w, double *t, double *ypart, int cand, int32_t *idxs, GsState *st, hipStream_t s,
                          int last = 0);
 int gs_scratch_rows();

@@ -44,6 +44,22 @@ __global__ __launch_bounds__(256) void k_gs_init(double *QT, int ldq, int m, GsS
     }
 }
 
+// state after a leading run of `s0` accepted UNIT columns (decided on the host in O(1) each: engine.cpp): Q^T is the signed
+// permutation the Householder steps of those columns produce (row i = sgn[i] * e_perm[i]^T, exactly what the rank-1 updates
+// would have left: they only move and negate 0 / +-1 entries), R = R^-1 = diag(beta), |R|_1 = |R^-1|_1 = 1
+__global__ __launch_bounds__(256) void k_gs_init_perm(double *QT, double *Rinv, int ldq, int m, const int32_t *__restrict__ perm, const double *__restrict__ sgn,
+                                                      const double *__restrict__ beta, int s0, GsState *st) {
+    const int r = blockIdx.x;
+    const int pc = perm[r];
+    const double sv = sgn[r];
+    for (int c = threadIdx.x; c < ldq; c += 256) QT[(size_t)r * ldq + c] = (c == pc) ? sv : 0.0;
+    if (r < s0 && threadIdx.x == 0) Rinv[(size_t)r * ldq + r] = 1.0 / beta[r];
+    if (r == 0 && threadIdx.x == 0) {
+        st->k = s0; st->accept = 0; st->kacc = 0; st->done = (s0 >= m - 1) ? 1 : 0; st->stop_col = -1; st->scanned = 0;
+        st->nR = s0 ? 1.0 : 0.0; st->nRinv = s0 ? 1.0 : 0.0; st->vv = 0;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gs_w(const double *__restrict__ acol, const double *__restrict__ QT, int ldq, int m, double *__restrict__ w, const GsState *st, int force) {
     if (st->done && !force) return;
     const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -207,6 +223,9 @@ __global__ __launch_bounds__(256) void k_gs_binv(const double *__restrict__ Rinv
 }
 
 void launch_gs_init(double *QT, int ldq, int m, GsState *st, hipStream_t s) { hipLaunchKernelGGL(k_gs_init, dim3(m), dim3(256), 0, s, QT, ldq, m, st); }
+void launch_gs_init_perm(double *QT, double *Rinv, int ldq, int m, const int32_t *perm, const double *sgn, const double *beta, int s0, GsState *st, hipStream_t s) {
+    hipLaunchKernelGGL(k_gs_init_perm, dim3(m), dim3(256), 0, s, QT, Rinv, ldq, m, perm, sgn, beta, s0, st);
+}
 // one candidate column: 5 launches
 void launch_gs_candidate(const double *acol, double *QT, double *Rinv, int ldq, int m, double *w, double *t, double *ypart, int cand, int32_t *idxs, GsState *st, hipStream_t s,
                          int last) {
