@@ -512,7 +512,7 @@ BtGroupCfg bt_group_cfg(int m, int ldt, int knob) {
     // measured per 16 pivots at 2048 x 2048 (MI355X): 8 workgroups x 256 threads 70.9 us, 4 x 512 80.2, 4 x 256 x 2 rows 75.9,
     // 8 x 128 x 2 rows 87.1, 2 x 512 x 2 rows 91.2 — against 2 x 37.2 us of k_bt_inner2<512,4,4,8> and a rank-8 update more
     // per 16 pivots; at 4096 x 4096: 8 x 512 83.9 us, 8 x 256 x 2 rows 95.1.  One row + one column per thread, 8 workgroups.
-    if (need <= 1024) return c;   // one workgroup holds these (k_bt_inner2<512,2,2,8>: 3.1 us per pivot)
+    if (need <= 1024) return c;   // one workgroup holds these (k_bt_inner2<512,2,2,8>: 3.1 us per pivot; 8 workgroups x 128 threads: 4.1)
     if (need <= 2048) return {8, 256, 1};
     if (need <= 4096) return {8, 512, 1};
     if (need <= 8192) return {8, 512, 2};
