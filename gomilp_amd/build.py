@@ -1,38 +1,62 @@
-"""In-tree build of the gfx950 engine: gomilp_amd/libgomilp_hip.so (hipcc cross-compiles without a GPU)."""
+"""In-tree build of the gfx950 engine: gomilp_amd/libgomilp_hip.so (hipcc cross-compiles without a GPU).
+
+Every source is compiled to an object of its own under gomilp_amd/build/ (in parallel, only what is out of date) and the
+objects are linked into the shared library."""
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libgomilp_hip.so")
-SOURCES = ["simplex_kernels.hip", "fused_kernels.hip", "lu_kernels.hip", "lu_compressed.hip", "tableau_kernels.hip", "bt_kernels.hip", "btg_kernels.hip", "batch_kernels.hip", "general_kernels.hip", "engine.cpp", "engine_batch.cpp", "engine_tableau.cpp", "engine_general.cpp", "c_api.cpp", "comm.cpp"]
+SOURCES = ["simplex_kernels.hip", "fused_kernels.hip", "lu_kernels.hip", "lu_compressed.hip", "tableau_kernels.hip", "bt_kernels.hip", "btg_kernels.hip",
+           "batch_kernels.hip", "general_kernels.hip", "engine.cpp", "engine_batch.cpp", "engine_tableau.cpp", "engine_general.cpp", "c_api.cpp", "comm.cpp"]
 HEADERS = ["device_types.h", "kernels_common.h", "engine.hpp", "engine_work.hpp", "engine_batch.hpp", os.path.join(ROOT, "include", "gomilp_lp.h")]
 # -ffp-contract=off: the final basis solve must round every multiply and add separately, like the
 # reference's SSE2 kernels (DESIGN.md "bit-exact final solve"); the streaming kernels are HBM-bound
 # and do not miss the FMAs.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-pragma-unroll-threshold=1000000",
-         "-Wno-unused-result", "-Wno-unused-value", "-ldl", "-I" + os.path.join(ROOT, "include")]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-pragma-unroll-threshold=1000000",
+          "-Wno-unused-result", "-Wno-unused-value", "-Wno-return-type-c-linkage", "-I" + os.path.join(ROOT, "include")]
+LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-ldl"]
 
 
 def _hipcc() -> str | None:
     return shutil.which("hipcc") or (os.path.exists("/opt/rocm/bin/hipcc") and "/opt/rocm/bin/hipcc") or None
 
 
+def _deps() -> list[str]:
+    return [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+
+
+def _obj(src: str) -> str:
+    return os.path.join(OBJ, src + ".o")
+
+
+def _obj_stale(src: str) -> bool:
+    o = _obj(src)
+    if not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    return any(os.path.getmtime(d) > t for d in [os.path.join(CSRC, src)] + _deps())
+
+
 def stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + _deps()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile to a temporary file next to the target and rename it into place, under a file lock: several ranks that import
-    the package on a fresh checkout at once (torchrun) neither compile concurrently into one file nor load a half-written one."""
+    """Compile what is out of date (everything with force=True), link into a temporary file next to the target and rename it
+    into place, under a file lock: several ranks that import the package on a fresh checkout at once (torchrun) neither
+    compile concurrently into one file nor load a half-written one."""
     if not (force or stale()):
         return LIB
     hipcc = _hipcc()
@@ -44,8 +68,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
         try:
             if not force and not stale():      # another process built it while this one waited for the lock
                 return LIB
+            os.makedirs(OBJ, exist_ok=True)
+            todo = [s for s in SOURCES if force or _obj_stale(s)]
+
+            def compile_one(src: str) -> None:
+                tmp = "%s.tmp.%d" % (_obj(src), os.getpid())
+                cmd = [hipcc] + CFLAGS + ["-c", os.path.join(CSRC, src), "-o", tmp]
+                if verbose:
+                    print(" ".join(cmd))
+                try:
+                    subprocess.run(cmd, check=True)
+                    os.replace(tmp, _obj(src))
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+
+            with ThreadPoolExecutor(max_workers=min(len(todo), max(1, (os.cpu_count() or 2) - 1)) or 1) as ex:
+                list(ex.map(compile_one, todo))
             tmp = "%s.tmp.%d" % (LIB, os.getpid())
-            cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            cmd = [hipcc] + LDFLAGS + [_obj(s) for s in SOURCES] + ["-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             try:
@@ -60,4 +101,5 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -27,6 +27,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "device_types.h"
@@ -39,6 +40,14 @@ namespace {
 constexpr int kXSlots = 8;             // slots per record (one 128-byte line): min, first index, 3 scalars of the winner
 constexpr int kXHeader = 16;           // doubles in front of the records: [0] = exchanges completed so far
 constexpr int kXSpinLimit = 2000000;   // polls (~0.5 us each) before a launch gives up
+// Persistent loop kernel (k_bt_loop): header [1 + 2 par] / [2 + 2 par] = arrivals expected before the first block of the launch
+// with parity par on the two counters below (written by workgroup 0 of the previous launch: a launch never rewrites what its
+// own late starters still have to read); the counters sit on lines of their own
+// behind the records: blocks finished by the pivot workgroups (G arrivals per block), blocks applied by the update
+// workgroups (one arrival per update workgroup and block)
+constexpr int kXSync = kXHeader + 2 * 8 * kXSlots * 2;   // doubles in front of the counters
+constexpr int kXSyncDoubles = 32;
+constexpr int kLoopSpinLimit = 600000;   // polls (~1.5 us each) of a block / update counter before a workgroup gives up
 
 typedef double xpair __attribute__((ext_vector_type(2)));   // {sequence number, value}
 
@@ -61,20 +70,39 @@ template <> struct XLoad<1> {
         else asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(p) : "memory");
     }
 };
+__device__ __forceinline__ double ld_agent(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wait until a monotonic arrival counter has reached `target` (wrap-safe); false: no progress within the limit
+__device__ __forceinline__ bool spin_counter(const unsigned int *p, unsigned int target, int sleep_ticks) {
+    for (int it = 0; it < kLoopSpinLimit; it++) {
+        const unsigned int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(v - target) >= 0) return true;
+        if (sleep_ticks > 8) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(4);
+    }
+    return false;
+}
 struct XWin { double m; unsigned int i; double p0, p1, p2; };    // winner of an exchange: value, first index, its scalars
 struct BtWinG { double m; unsigned int i; };                   // a wave's own winner
 
 }  // namespace
 
 // G workgroups x NT threads, RI rows and RI columns per thread (m <= G*NT*RI, ldt <= G*NT*RI), KR block terms in registers
-template <int G, int NT, int RI, int KR, bool STAMP>
-__device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g) {
+// LOOP: the pivot role of the persistent loop kernel (k_bt_loop): up to a.nblocks blocks of 8 pivots in one launch, the terms
+// of the previous block carried along as lagging terms while the update workgroups of the same launch apply them
+template <int G, int NT, int RI, int KR, bool STAMP, bool LOOP = false>
+__device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, const int nupd = 0) {
     constexpr int NW = NT / 64;
+    static_assert(!LOOP || (KR == 16 && !STAMP), "loop mode: 8 lagging + 8 current terms");
     static_assert(G == 2 || G == 4 || G == 8, "G");
     if (a.fault && g == 1) return;   // test hook: a workgroup that never takes part -> the others must give up (ST_XCHG_TIMEOUT)
     __shared__ double redM[16];
     __shared__ unsigned int redI[16];
     __shared__ double pay[16][4];
+    __shared__ int s_ok;
     // STAMP: diagnostic build (knob "bt_stamps"): cycles per pivot segment and wave of workgroup 0 (s_memtime), summed in LDS
     __shared__ unsigned long long s_acc[STAMP ? 16 : 1][16];
     unsigned long long tprev = 0;
@@ -96,16 +124,17 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g) {
     xpair *recs = reinterpret_cast<xpair *>(a.xbuf + kXHeader);   // [parity][G][kXSlots]
     const double inf = __builtin_inf();
     const unsigned int ldt = (unsigned int)a.ldt;
+    // the tableau this block reads: a.T, or in loop mode the buffer the update workgroups finished two blocks ago (they write
+    // it with agent-scope stores from other XCDs while this launch runs: agent-scope loads)
     const char *Tb = reinterpret_cast<const char *>(a.T);
-    auto ldT = [&](unsigned int elem) -> double { return *reinterpret_cast<const double *>(Tb + (elem << 3)); };
+    auto ldT = [&](unsigned int elem) -> double {
+        if constexpr (LOOP) return ld_agent(reinterpret_cast<const double *>(Tb + (elem << 3)));
+        else return *reinterpret_cast<const double *>(Tb + (elem << 3));
+    };
     // block terms of OTHER workgroups' rows / columns come from the U / V rows of the running block in global memory:
     // agent-scope (sc1) stores by the owner, agent-scope loads here — never a stale L1 line, correct on any XCD
-    auto ld_term = [&](const double *p) -> double {
-        return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    };
-    auto st_term = [&](double *p, double v) {
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
+    auto ld_term = [&](const double *p) -> double { return ld_agent(p); };
+    auto st_term = [&](double *p, double v) { st_agent(p, v); };
     auto gidx = [&](int s) -> int { return (s * G + g) * NT + tid; };   // row / column index of this thread's slot s
     // `fast` is decided by the first exchange of the launch, which carries every workgroup's XCC id: all equal -> the
     // same-XCD record accesses from then on (every workgroup sees the same ids, so all switch together)
@@ -123,8 +152,30 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g) {
         rv[s] = i < a.nn ? a.r[i] : inf;   // padding never wins an argmin
         nbasv[s] = i < a.nn ? a.nonbasic[i] : 0;
     }
+    // loop mode: rows [cur0, cur0 + 8) of U / V take the terms of the running block, rows [lag0, lag0 + nl) hold those of the
+    // previous one (not yet in the tableau this block reads)
+    int cur0 = 0, lag0 = 8, nl = 0;
+    const int sel0 = LOOP ? (a.par ? st->tsel2[1] : st->tsel2[0]) : 0;
+    const unsigned int blk_base = LOOP ? (unsigned int)(unsigned long long)a.xbuf[1 + 2 * a.par] : 0u, upd_base = LOOP ? (unsigned int)(unsigned long long)a.xbuf[2 + 2 * a.par] : 0u;
+    unsigned int *blk_cnt = reinterpret_cast<unsigned int *>(a.xbuf + kXSync), *upd_cnt = reinterpret_cast<unsigned int *>(a.xbuf + kXSync + 16);
     if (done) {
-        if (g == 0 && tid == 0) st->kdone = 0;
+        if constexpr (LOOP) {
+            // a launch enqueued behind the end of the loop: the update workgroups wait for block 0 — release them (no pivots to
+            // apply) and keep counters and buffer choice in step for the next launch
+            if (tid == 0) {
+                if (g == 0) {
+                    __hip_atomic_store(&st->kdone2[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __hip_atomic_fetch_add(blk_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (g == 0) {
+                    st->tsel2[a.par ^ 1] = sel0;
+                    st->loop_blocks = 0;
+                    a.xbuf[1 + 2 * (a.par ^ 1)] = (double)(unsigned int)(blk_base + (unsigned int)G);
+                    a.xbuf[2 + 2 * (a.par ^ 1)] = (double)(unsigned int)(upd_base + (unsigned int)nupd);
+                }
+            }
+        } else if (g == 0 && tid == 0) st->kdone = 0;
         return;
     }
     double ureg[RI][KR], vreg[RI][KR];
@@ -269,8 +320,18 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g) {
             d0[s] = ldT(tile_off_g(ic, (unsigned int)q, ldt));
         }
         double vq[KR];
+        if constexpr (LOOP) {
+            // lane l fetches term l (newest first: this block's k terms, then the nl lagging ones): ONE load instruction
+            // instead of 16 with scalar addresses each; the terms reach the multiply-adds as scalar operands
+            const int l = lane & 15;
+            const int trow = l < k ? cur0 + k - 1 - l : lag0 + nl - 1 - (l - k);
+            const double tv = l < k + nl ? ld_term(a.V + (size_t)trow * a.ldt + q) : 0.0;
 #pragma unroll
-        for (int jj = 0; jj < KR; jj++) vq[jj] = jj < k ? ld_term(a.V + (size_t)(k - 1 - jj) * a.ldt + q) : 0.0;
+            for (int jj = 0; jj < KR; jj++) vq[jj] = readlane_f64(tv, jj);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < KR; jj++) vq[jj] = jj < k ? ld_term(a.V + (size_t)(k - 1 - jj) * a.ldt + q) : 0.0;
+        }
 #pragma unroll
         for (int s = 0; s < RI; s++) {
             double d = d0[s];
@@ -291,9 +352,32 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g) {
         }
     };
 
+    int nbe = 0;   // loop mode: blocks run by this launch
+    for (int blk = 0; blk < (LOOP ? a.nblocks : 1); blk++) {
+    if constexpr (LOOP) {
+        // block blk reads the tableau after blk - 1 blocks: the update of block blk - 2 must be through (nupd arrivals per block)
+        if (blk >= 2) {   // (one verdict per workgroup: a wave that gave up alone would leave the others at a barrier)
+            if (wv == 0) {
+                const bool ok = spin_counter(upd_cnt, upd_base + (unsigned int)nupd * (unsigned int)(blk - 1), 0);
+                if (lane == 0) s_ok = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (!s_ok) { dead = true; break; }
+        }
+        Tb = reinterpret_cast<const char *>(((sel0 ^ (blk > 0 ? blk - 1 : 0)) & 1) ? a.Tbuf[1] : a.Tbuf[0]);   // (no dynamic index into the argument block: scratch)
+        cur0 = (blk & 1) * 8; lag0 = cur0 ^ 8; nl = blk > 0 ? 8 : 0;
+        if (blk > 0) {   // entries 0..7 = the previous block (now lagging), 8..15 = the block before it: in the tableau by now
+#pragma unroll
+            for (int s = 0; s < RI; s++) {
+#pragma unroll
+                for (int j = 8; j < KR; j++) { ureg[s][j] = 0; vreg[s][j] = 0; }
+            }
+        }
+        kd = 0;
+    }
     for (int k = 0; k < a.kmax; k++) {
         stamp(-1);
-        const bool forced = (k == 0 && a.forced_q >= 0);
+        const bool forced = (k == 0 && blk == 0 && a.forced_q >= 0);
         int q, p, ent = 0, lea = 0;
         double rq = 0, dpv = 1.0, xbp = 0;
         bool bland = false;
@@ -386,8 +470,8 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g) {
         const double rinv = 1.0 / dpv, nrinv = -rinv;
         const double mult = rq * rinv;
         const double theta = xbp * rinv;
-        double *Vk = a.V + (size_t)k * a.ldt;
-        double *Uk = a.U + (size_t)k * a.ldu;
+        double *Vk = a.V + (size_t)(cur0 + k) * a.ldt;
+        double *Uk = a.U + (size_t)(cur0 + k) * a.ldu;
         const bool commit_lists = !(forced && a.forced_nocommit) || (forced && a.forced_nocommit >= 2);
         double vrow[RI];
 #pragma unroll
@@ -395,9 +479,17 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g) {
             const int j = gidx(s);
             vrow[s] = j < a.ldt ? ldT(tile_off_g((unsigned int)p, (unsigned int)j, ldt)) : 0.0;
         }
-        double up[KR];   // u_j[p] of the block's k earlier pivots, newest first
+        double up[KR];   // u_j[p] of the block's k earlier pivots, newest first (loop mode: then the lagging ones)
+        if constexpr (LOOP) {
+            const int l = lane & 15;
+            const int trow = l < k ? cur0 + k - 1 - l : lag0 + nl - 1 - (l - k);
+            const double tv = l < k + nl ? ld_term(a.U + (size_t)trow * a.ldu + p) : 0.0;
 #pragma unroll
-        for (int jj = 0; jj < KR; jj++) up[jj] = jj < k ? ld_term(a.U + (size_t)(k - 1 - jj) * a.ldu + p) : 0.0;
+            for (int jj = 0; jj < KR; jj++) up[jj] = readlane_f64(tv, jj);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < KR; jj++) up[jj] = jj < k ? ld_term(a.U + (size_t)(k - 1 - jj) * a.ldu + p) : 0.0;
+        }
 #pragma unroll
         for (int s = 0; s < RI; s++) {
             const int i = gidx(s);
@@ -440,6 +532,27 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g) {
         }
         kd = k + 1;
     }
+    nbe = blk + 1;
+    if constexpr (LOOP) {
+        // hand the block to the update workgroups: every term store of this workgroup has landed (agent scope), workgroup 0
+        // publishes the pivot count (and the end of the loop) BEFORE its arrival, the arrivals of all G workgroups release them
+        if (dead) status = ST_XCHG_TIMEOUT;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (g == 0) {
+                __hip_atomic_store(&st->kdone2[blk & 1], kd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (status != ST_RUNNING) {
+                    __hip_atomic_store(&st->status, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&st->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __hip_atomic_fetch_add(blk_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (status != ST_RUNNING) break;
+    }
+    }
     if (dead) status = ST_XCHG_TIMEOUT;
     if constexpr (STAMP) {
         if (a.stamps && g == 0 && lane == 0) {
@@ -459,7 +572,16 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g) {
         if (g == 0) {
             st->trace_len = trace_len;
             st->pivots = npiv;
-            st->kdone = kd;
+            if constexpr (LOOP) {
+                // the update workgroups apply every block with pivots before the launch ends: the tableau after them
+                const int napplied = kd > 0 ? nbe : nbe - 1;
+                st->tsel2[a.par ^ 1] = sel0 ^ (napplied & 1);
+                st->loop_blocks = nbe;
+                a.xbuf[1 + 2 * (a.par ^ 1)] = (double)(unsigned int)(blk_base + (unsigned int)G * (unsigned int)nbe);
+                a.xbuf[2 + 2 * (a.par ^ 1)] = (double)(unsigned int)(upd_base + (unsigned int)nupd * (unsigned int)nbe);
+            } else {
+                st->kdone = kd;
+            }
             st->bland_steps += blands;
             a.xbuf[0] = (double)xs;
         }
@@ -472,6 +594,96 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
     if (blockIdx.x & 7u) return;   // blocks 0, 8, 16, ...: all on XCD 0
     bt_innerG_body<G, NT, RI, KR, STAMP>(a, (int)(blockIdx.x >> 3));
 }
+// ---- persistent loop kernel ----------------------------------------------------------------------------------------------------
+// Update role: workgroup u of nupd applies T_next = T + sum_k u_k v'_k^T for block after block of the SAME launch, each as soon as
+// the G pivot workgroups have arrived at the end of that block, on the matrix cores (a 16 x 16 block of the 4x4-tiled tableau is the
+// C/D operand of v_mfma_f64_16x16x4_f64, two MFMAs for the 8 terms of a block: bt_kernels.hip k_bt_update_mfma16 has the layout).
+// Everything that crosses workgroups inside the launch — the terms, the pivot count, both tableau buffers — moves with agent-scope
+// accesses; a workgroup always owns the same units of the tableau, so it only ever re-reads what it wrote itself.
+typedef double btg_d4 __attribute__((ext_vector_type(4)));
+template <int NT>
+__device__ __forceinline__ void bt_loop_update_role(const BTArgs &a, const int u, const int nupd, const int G) {
+    constexpr int NWV = NT / 64, CW = 2;   // column blocks per wave and unit
+    DevState *st = a.st;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // (no look at `done` here: a launch behind the end of the loop is released by the pivot workgroups' arrival for block 0,
+    // and a loop that ends in block 0 of THIS launch still has that block's terms to apply)
+    __shared__ int s_go;
+    const int sel0 = st->tsel2[a.par];
+    const unsigned int blk_base = (unsigned int)(unsigned long long)a.xbuf[1 + 2 * a.par];
+    unsigned int *blk_cnt = reinterpret_cast<unsigned int *>(a.xbuf + kXSync), *upd_cnt = reinterpret_cast<unsigned int *>(a.xbuf + kXSync + 16);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ncb = a.ldt >> 4;
+    const int groups = (ncb + NWV * CW - 1) / (NWV * CW), strips = (a.m + 15) >> 4, nunits = groups * strips;
+    const int ntr = (a.m + 3) >> 2;                  // tile rows that exist
+    const size_t trow = (size_t)(a.ldt >> 2) * 16;   // doubles per tile row
+    for (int blk = 0; blk < a.nblocks; blk++) {
+        if (tid == 0) s_go = spin_counter(blk_cnt, blk_base + (unsigned int)G * (unsigned int)(blk + 1), 32) ? 1 : 0;
+        __syncthreads();
+        if (!s_go) return;   // the pivot workgroups never arrived: give up (they report the failure, or nobody is left to)
+        const int kd = __hip_atomic_load(&st->kdone2[blk & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int dn = __hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (kd > 0) {
+            const double *src = ((sel0 ^ blk) & 1) ? a.Tbuf[1] : a.Tbuf[0];
+            double *dst = ((sel0 ^ blk) & 1) ? a.Tbuf[0] : a.Tbuf[1];
+            const int k0 = (blk & 1) * 8;
+            for (int unit = u; unit < nunits; unit += nupd) {
+                const int strip = unit / groups, cb0 = ((unit % groups) * NWV + wv) * CW;
+                if (cb0 >= ncb) continue;
+                const int row = strip * 16 + l15;
+                double av[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    const int k = 4 * s2 + l4;
+                    av[s2] = (k < kd && row < a.m) ? ld_agent(a.U + (size_t)(k0 + k) * a.ldu + row) : 0.0;
+                }
+                const size_t boff = (size_t)(strip * 4) * trow + (size_t)(l15 >> 2) * 16 + l4 * 4 + (l15 & 3);
+                btg_d4 c[CW];
+                double bv[CW][2];
+#pragma unroll
+                for (int x = 0; x < CW; x++) {
+                    const bool in = cb0 + x < ncb;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) c[x][r] = (in && strip * 4 + r < ntr) ? ld_agent(src + boff + (size_t)r * trow + (size_t)(cb0 + x) * 64) : 0.0;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; s2++) {
+                        const int k = 4 * s2 + l4;
+                        bv[x][s2] = (in && k < kd) ? ld_agent(a.V + (size_t)(k0 + k) * a.ldt + (cb0 + x) * 16 + l15) : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int x = 0; x < CW; x++) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; s2++) c[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[x][s2], c[x], 0, 0, 0);
+                }
+#pragma unroll
+                for (int x = 0; x < CW; x++) {
+                    if (cb0 + x < ncb) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (strip * 4 + r < ntr) st_agent(dst + boff + (size_t)r * trow + (size_t)(cb0 + x) * 64, c[x][r]);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's tableau stores have landed
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(upd_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (dn) return;
+    }
+}
+
+// Blocks 0, 8, ..., 8 (G - 1) — one XCD under the round-robin placement of blocks — are the pivot workgroups, every other block
+// of the grid an update workgroup.  All workgroups of the launch must be resident (they wait for each other): the grid is one
+// workgroup per CU (launch_bt_loop), and every wait is bounded.
+template <int G, int NT, int RI>
+__global__ __launch_bounds__(NT) void k_bt_loop(BTArgs a) {
+    const int b = (int)blockIdx.x, nupd = (int)gridDim.x - G;
+    if ((b & 7) == 0 && (b >> 3) < G) { bt_innerG_body<G, NT, RI, 16, false, true>(a, b >> 3, nupd); return; }
+    const int before = min(G, (b + 7) >> 3);   // pivot blocks in front of block b
+    bt_loop_update_role<NT>(a, b - before, nupd, G);
+}
+
 // Batched form (device-batched waves of large relaxations, engine_batch.cpp): the relaxation at position p of the active list
 // runs on XCD p % 8 — block b = x + 8 j serves position (j / G) * 8 + x as its workgroup j % G — so up to 8 relaxations
 // advance at once, each inside one L2.  Blocks are dispatched in index order and all G workgroups of a relaxation lie in one
@@ -494,7 +706,7 @@ __global__ __launch_bounds__(NT) void k_bt_innerG_batch(const BatchLP *__restric
 // per pivot alone on a SIMD, and an exchange among 16 participants waits for the slowest of 16.
 
 // ---- host side ---------------------------------------------------------------------------------
-size_t bt_xbuf_doubles() { return (size_t)kXHeader + (size_t)2 * 8 * kXSlots * 2; }
+size_t bt_xbuf_doubles() { return (size_t)kXSync + kXSyncDoubles; }
 
 // workgroups for a shape (knob "bt_groups": -1 = never, 0 = by shape, 2 / 4 / 8 = forced where the shape fits)
 BtGroupCfg bt_group_cfg(int m, int ldt, int knob) {
@@ -532,6 +744,16 @@ void launch_bt_inner_groups(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEv
     if (G == 2) { if (ri == 1) btg_launch<2, 512, 1>(a, s, e0, e1); else btg_launch<2, 512, 2>(a, s, e0, e1); }
     else if (G == 4) { if (ri == 1) btg_launch<4, 512, 1>(a, s, e0, e1); else btg_launch<4, 512, 2>(a, s, e0, e1); }
     else { if (ri == 1) btg_launch<8, 512, 1>(a, s, e0, e1); else btg_launch<8, 512, 2>(a, s, e0, e1); }
+}
+// persistent loop kernel: one workgroup per CU (the pivot workgroups among them); only the one-row-per-thread instances
+bool bt_loop_supported(const BtGroupCfg &c) { return c.groups > 0 && c.ri == 1; }
+void launch_bt_loop(const BTArgs &a, int ncu, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const int G = a.groups;
+    const unsigned int grid = (unsigned int)std::max(ncu, 8 * G);
+    if (a.group_nt == 256) { hipExtLaunchKernelGGL((k_bt_loop<8, 256, 1>), dim3(grid), dim3(256), 0, s, e0, e1, 0, a); return; }
+    if (G == 2) hipExtLaunchKernelGGL((k_bt_loop<2, 512, 1>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);
+    else if (G == 4) hipExtLaunchKernelGGL((k_bt_loop<4, 512, 1>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);
+    else hipExtLaunchKernelGGL((k_bt_loop<8, 512, 1>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);
 }
 // batched launch: the whole wave has the shape class of its largest relaxation (8 workgroups; 256 or 512 threads)
 void launch_bt_inner_groups_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, const BtGroupCfg &c, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {

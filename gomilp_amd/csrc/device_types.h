@@ -51,6 +51,10 @@ struct DevState {
     // blocked tableau pipeline: pivots of the last inner-kernel block whose rank-1 terms the update kernel must apply
     int32_t kdone;
     int32_t bland_steps;  // degenerate steps resolved inside the inner kernel (cumulative over the loop)
+    // persistent loop kernel (BTArgs::loop): pivots of the block of each parity (the update of block t runs beside block
+    // t+1), which of BTArgs::Tbuf holds the current tableau between launches, blocks run by the last launch
+    int32_t kdone2[2];
+    int32_t tsel2[2], loop_blocks, pad3;   // launch i reads tsel2[i & 1] and writes tsel2[(i & 1) ^ 1]: a workgroup that starts late still sees its input
 };
 
 struct DevPivot {  // mirrors gomilp_pivot
@@ -131,6 +135,14 @@ struct BTArgs {
     int32_t groups, group_ri;     // its workgroup count (0: single-workgroup kernels) and rows / columns per thread
     int32_t fault, pad_f;         // knob "bt_fault" (tests): workgroup 1 of the multi-workgroup block kernel leaves at once
     int32_t group_nt, upd_valu;   // threads per workgroup; knob "bt_upd_valu": rank-16 update on the VALU instead of the matrix cores
+    // Persistent loop kernel (btg_kernels.hip k_bt_loop; engine_tableau.cpp run_loop_bt): ONE launch runs up to `nblocks` blocks of
+    // 8 pivots on the G workgroups of one XCD while the other workgroups of the same launch apply the rank-8 update of block
+    // t beside block t+1 (ping-pong between Tbuf[0] and Tbuf[1]; DevState::tsel says which one holds the tableau when a
+    // launch starts / ends).  Block t+1 therefore reads a tableau WITHOUT the terms of block t and corrects columns / rows
+    // with 8 lagging + up to 8 current terms.  U / V rows [8 (t & 1), 8 (t & 1) + 8) take the terms of block t.
+    double *Tbuf[2];
+    int32_t loop, nblocks;
+    int32_t par, pad_p;   // launch parity (DevState::tsel2, and the counter bases in the exchange buffer's header)
 };
 
 // shape of the multi-workgroup block kernel for a tableau (btg_kernels.hip): groups == 0 -> single-workgroup kernels

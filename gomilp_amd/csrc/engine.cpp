@@ -36,6 +36,14 @@ Engine::~Engine() {
     if (stream_) hipStreamDestroy(stream_);
 }
 
+namespace { std::atomic<int> g_loop_inflight[64]; }
+bool Engine::loop_slot_acquire_static(int dev) {
+    std::atomic<int> &c = g_loop_inflight[dev & 63];
+    int expected = 0;
+    return c.compare_exchange_strong(expected, 1);
+}
+void Engine::loop_slot_release_static(int dev) { g_loop_inflight[dev & 63].store(0); }
+
 int Engine::set(const std::string &key, int64_t v) {
     std::lock_guard<std::mutex> g(mu_);
     if (key == "chunk") { if (v < 1) return GOMILP_ERR_BAD_SHAPE; chunk_ = v; }
@@ -54,6 +62,8 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "general_device") general_device_ = v ? 1 : 0;
     else if (key == "bt_groups") { if (v != -1 && v != 0 && v != 2 && v != 4 && v != 8) return GOMILP_ERR_BAD_SHAPE; bt_groups_ = v; }
     else if (key == "bt_stamps") bt_stamps_ = v ? 1 : 0;
+    else if (key == "bt_lag") bt_lag_ = v ? 1 : 0;
+    else if (key == "loop_chunk") { if (v < 32) return GOMILP_ERR_BAD_SHAPE; loop_chunk_ = v; }
     else if (key == "cond_guard") cond_guard_ = v ? 1 : 0;
     else if (key == "block_k") { if (v < 0 || v > bt_max_k()) return GOMILP_ERR_BAD_SHAPE; block_k_ = v; }
     else return GOMILP_ERR_BAD_SHAPE;
@@ -65,6 +75,8 @@ int Engine::ensure_work(int m, int ncols) {
     if (!stream_) HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     Work &w = *w_;
     if (!w.st) {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_) == hipSuccess && ncu > 0) ncu_ = ncu;
         HIP_TRY(dmalloc(&w.pk_price, kMaxPartials)); HIP_TRY(dmalloc(&w.pk_ratio, kMaxPartials));
         HIP_TRY(dmalloc(&w.pi_price, kMaxPartials)); HIP_TRY(dmalloc(&w.pi_ratio, kMaxPartials));
         HIP_TRY(dmalloc(&w.pv_price, kMaxPartials)); HIP_TRY(dmalloc(&w.pb_ratio, kMaxPartials)); HIP_TRY(dmalloc(&w.pd_ratio, kMaxPartials)); HIP_TRY(dmalloc(&w.px_ratio, kMaxPartials));

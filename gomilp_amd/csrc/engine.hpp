@@ -46,6 +46,10 @@ class Engine {
     explicit Engine(int device);
     ~Engine();
     int device() const { return device_; }
+    // The persistent loop kernel needs all its workgroups resident (they wait for each other): one per device at a time, a
+    // second concurrent solve of a large LP takes the launch-per-block path
+    static bool loop_slot_acquire_static(int dev);
+    static void loop_slot_release_static(int dev);
     int set(const std::string &key, int64_t v);
 
     int64_t upload(const double *c, const double *A, int64_t lda, const double *b, int64_t m, int64_t n);
@@ -108,7 +112,7 @@ class Engine {
     void bt_layout(const Problem &P, bool tiled);
     BTArgs make_bt_args(const Problem &P, int phase, double tol, int nn, int kmax);
     // block size and tableau layout of the blocked pipeline for the current ldt_ (knobs block_k / bt_nt / bt_old / bt_groups)
-    void bt_plan(const Problem &P, int *K, bool *tiled) const;
+    void bt_plan(const Problem &P, int *K, bool *tiled, bool *lag = nullptr) const;
     int bt_forced_pivot(const Problem &P, int phase, double tol, int nn, int q, int p, int nocommit);
     int run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_lp_stats *st);
     void account_samples(gomilp_lp_stats *st, const std::vector<int64_t> &sample_t, int64_t executed, int nk);
@@ -127,6 +131,7 @@ class Engine {
 
     int device_;
     hipStream_t stream_ = nullptr;
+    int ncu_ = 256;   // compute units of the device (grid of the persistent loop kernel)
     std::mutex mu_;
     std::vector<std::unique_ptr<Problem>> problems_;
     std::vector<std::unique_ptr<Problem>> child_pool_;  // released children, buffers kept
@@ -140,6 +145,8 @@ class Engine {
     // knobs
     int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 2, tableau_ = 1, blocked_ = 1, block_k_ = 0,  // block_k_ 0 = auto
             bt_nt_ = 0, bt_old_ = 0, bt_stamps_ = 0, bt_upd_valu_ = 0, bt_fault_ = 0, general_device_ = 1, bt_groups_ = 0,   // bt_groups_: -1 never, 0 by shape, 2 / 4 / 8 forced
+            bt_lag_ = 1,       // persistent loop kernel where the multi-workgroup block kernel runs (0: block kernel + update launches)
+            loop_chunk_ = 512, // pivots per launch of the persistent loop kernel
             cond_guard_ = 1;   // replay the condition guards of the reference on the host for bases of up to 64 rows
     bool shadow_trace_ = false;   // this solve records its pivots for the replay even when the caller did not ask for a trace   // developer knobs of the block kernels (per context: tests force the 1024-thread instance)
     // per-solve state
@@ -218,6 +225,8 @@ constexpr int kBtStampSegs = 16;   // cycle sums per wave written by the diagnos
 void launch_bt_tile(const double *src, double *dst, int m, int ldt, bool to_tiles, hipStream_t s);
 void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 void launch_bt_update(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+bool bt_loop_supported(const BtGroupCfg &c);
+void launch_bt_loop(const BTArgs &a, int ncu, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 bool bt_batch_supported(int m_max, int ldt_max);
 int bt_batch_k(int m_max, int ldt_max);
 void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);

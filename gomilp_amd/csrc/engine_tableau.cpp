@@ -196,11 +196,15 @@ void Engine::bt_layout(const Problem &P, bool tiled) {
     t_tiled_ = tiled;
 }
 
-void Engine::bt_plan(const Problem &P, int *K, bool *tiled) const {
+void Engine::bt_plan(const Problem &P, int *K, bool *tiled, bool *lag) const {
     const BtGroupCfg gc = bt_old_ ? BtGroupCfg{0, 0, 0} : bt_group_cfg(P.m, ldt_, (int)bt_groups_);
+    if (lag) *lag = false;
     if (gc.groups) {   // multi-workgroup block kernel: 16 terms per row / column in registers, tiled layout
         *K = block_k_ > 0 ? (int)std::min<int64_t>(block_k_, 16) : 16;
         *tiled = true;
+        // persistent loop kernel (default, btg_kernels.hip k_bt_loop): blocks of 8 pivots, 8 lagging + 8 current terms, the rank-8
+        // update of block t applied by the other workgroups of the same launch beside block t+1
+        if (lag && bt_lag_ && block_k_ == 0 && max_pivots_ == 0 && !bt_stamps_ && bt_loop_supported(gc) && loop_slot_acquire_static(device_)) { *lag = true; *K = 8; }
         return;
     }
     // block size: 8 when the block's rank-1 terms fit in registers (bt_kernels.hip), else 16
@@ -249,6 +253,12 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
     Work &w = *w_;
     DevState &hs = *w.st_host;
     hs.done = 0; hs.status = ST_RUNNING; hs.pivots = 0; hs.kdone = 0; hs.bland_steps = 0; hs.lu_singular = 0;
+    int K; bool tiled_plan, lag;
+    bt_plan(P, &K, &tiled_plan, &lag);
+    struct SlotGuard { bool held; ~SlotGuard() { if (held) Engine::loop_slot_release_static(dev); } int dev; } slot_guard{lag, device_};
+    bt_layout(P, tiled_plan);
+    // persistent loop kernel: DevState::tsel2 hands the buffer that holds the tableau from launch to launch
+    hs.tsel2[0] = hs.tsel2[1] = tcur_; hs.kdone2[0] = hs.kdone2[1] = 0; hs.loop_blocks = 0;
     sync_state_to_device();
     if (bt_stamps_) {   // diagnostic build of the block kernel: cycle sums per wave and pivot segment
         const size_t nb = (size_t)(16 * kBtStampSegs + 8) * sizeof(unsigned long long);
@@ -260,12 +270,14 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
     }
     const double t_loop0 = now_s();
     int ret = GOMILP_OK;
-    int K; bool tiled_plan;
-    bt_plan(P, &K, &tiled_plan);
-    bt_layout(P, tiled_plan);
-    const int64_t blocks_per_chunk = std::max<int64_t>(1, chunk_ / K);
+    // persistent loop kernel: one launch per chunk of loop_chunk_ pivots (the host learns the buffer choice from the state it
+    // reads anyway)
+    const int64_t blocks_per_chunk = lag ? std::max<int64_t>(4, loop_chunk_ / K) : std::max<int64_t>(1, chunk_ / K);
     const bool sampling = sample_events_ > 0;
     int64_t block_no = 0;
+    // launch parity: a launch reads the counter bases / buffer choice the PREVIOUS launch of this context wrote (whichever loop
+    // that was in), so the count runs over the life of the context
+    int64_t &launch_no = w.loop_launches;
     // Chunks are pipelined: chunk c+1 is enqueued BEFORE the host waits for the state of chunk c, so the GPU never idles
     // for a host round trip; the price is one chunk of no-op launches after the device has set `done`.
     if (!w.pipe_state[0]) {
@@ -274,7 +286,7 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
             HIP_TRY(hipEventCreateWithFlags(&w.pipe_ev[t], hipEventDisableTiming));
         }
     }
-    struct ChunkInfo { int64_t before_pred; size_t samp0, nsamp; int64_t nblocks; };
+    struct ChunkInfo { int64_t before_pred; size_t samp0, nsamp; int64_t nblocks; int par; };
     ChunkInfo info[2];
     size_t samp_total = 0;
     auto enqueue_chunk = [&](int slot, int64_t before_pred, int64_t nblocks) -> int {
@@ -282,6 +294,23 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
         info[slot].samp0 = samp_total;
         info[slot].nsamp = 0;
         info[slot].nblocks = nblocks;
+        info[slot].par = (int)(launch_no & 1);
+        if (lag) {   // the whole chunk is one launch
+            BTArgs ai = make_bt_args(P, phase, tol, nn, K);
+            ai.loop = 1; ai.nblocks = (int)nblocks; ai.par = (int)(launch_no & 1);
+            ai.Tbuf[0] = w.T[0]; ai.Tbuf[1] = w.T[1];
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (sampling) {
+                while (w.sample_ev.size() < (samp_total + 1) * 6) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); w.sample_ev.push_back(ev); }
+                e0 = w.sample_ev[samp_total * 6]; e1 = w.sample_ev[samp_total * 6 + 1];
+                samp_total++; info[slot].nsamp++;
+            }
+            launch_bt_loop(ai, ncu_, stream_, e0, e1);
+            launch_no++; block_no += nblocks; launches_++;
+            HIP_TRY(hipMemcpyAsync(w.pipe_state[slot], w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipEventRecord(w.pipe_ev[slot], stream_));
+            return GOMILP_OK;
+        }
         for (int64_t bkk = 0; bkk < nblocks; bkk++, block_no++) {
             int kmax = K;
             if (max_pivots_ > 0) kmax = (int)std::max<int64_t>(1, std::min<int64_t>(K, max_pivots_ - before_pred - bkk * K));
@@ -303,10 +332,10 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
         HIP_TRY(hipEventRecord(w.pipe_ev[slot], stream_));
         return GOMILP_OK;
     };
-    int cur = 0;
+    int cur = 0, last_par = 0;
     int64_t pred = 0;   // pivots if every enqueued block ran in full
     // small relaxations (B&B children) usually finish Phase I within a handful of pivots: their first chunk is one block
-    const int64_t first_blocks = (P.m <= 1024) ? 1 : blocks_per_chunk;
+    const int64_t first_blocks = (P.m <= 1024 && !lag) ? 1 : blocks_per_chunk;
     { int rc0 = enqueue_chunk(0, 0, first_blocks); if (rc0 != GOMILP_OK) return rc0; }
     pred = first_blocks * K;
     int64_t seen = 0;   // pivots at the end of the previous inspected chunk
@@ -326,6 +355,12 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
             for (size_t s2 = ci.samp0; s2 < ci.samp0 + ci.nsamp; s2++) {
                 float ms0 = 0, ms1 = 0;
                 if (hipEventElapsedTime(&ms0, w.sample_ev[s2 * 6], w.sample_ev[s2 * 6 + 1]) != hipSuccess) continue;
+                if (lag) {   // one launch = the block kernels and (beside them) the updates of ci.nblocks blocks
+                    st->pivot_kernel_seconds[0] += ms0 * 1e-3;
+                    st->pivot_kernel_seconds[1] += (double)ci.nblocks;
+                    st->pivot_kernel_seconds[3] += (double)(K * ci.nblocks);
+                    continue;
+                }
                 if (hipEventElapsedTime(&ms1, w.sample_ev[s2 * 6 + 2], w.sample_ev[s2 * 6 + 3]) != hipSuccess) continue;
                 st->pivot_kernel_seconds[0] += ms0 * 1e-3;  // inner kernel: K pivots
                 st->pivot_kernel_seconds[2] += ms1 * 1e-3;  // rank-K update
@@ -334,6 +369,7 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
             }
         }
         seen = hs.pivots;
+        last_par = ci.par;
         if (!hs.done) {
             if (max_pivots_ > 0 && hs.pivots >= max_pivots_) { ret = GOMILP_ERR_UNSUPPORTED; break; }
             if (!more) { ret = GOMILP_ERR_UNSUPPORTED; break; }
@@ -348,6 +384,11 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
             hipMemsetAsync(w.xbuf, 0, bt_xbuf_doubles() * sizeof(double), stream_);
         ret = GOMILP_ERR_DEVICE;
         break;
+    }
+    if (lag) {
+        // the launch whose state was inspected last left the tableau in the buffer it wrote into tsel2 (launches enqueued
+        // behind it are no-ops that pass the choice on)
+        tcur_ = hs.tsel2[(last_par ^ 1) & 1];
     }
     // host clock from the first launch to the arrival of the final state: no extra event / sync per loop (the loop is
     // GPU-bound: the host only waits for chunk states)

@@ -71,6 +71,7 @@ struct Engine::Work {
     double *T[2] = {nullptr, nullptr}, *R[2] = {nullptr, nullptr}, *tscratch = nullptr;  // tableau pipelines
     double *btU = nullptr, *btV = nullptr;  // blocked tableau: rank-1 terms of the running block
     double *xbuf = nullptr;                 // multi-workgroup block kernel: exchange records (btg_kernels.hip)
+    int64_t loop_launches = 0;              // launches of the persistent loop kernel so far (launch parity)
     GsState *gs_state = nullptr, *gs_host = nullptr;   // device column search (general_kernels.hip): state block + pinned mirror
     int32_t *gs_idx = nullptr; int cap_gs_idx = 0;
     int32_t *srcpos = nullptr;
