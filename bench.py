@@ -16,10 +16,9 @@ ranks (one process per GPU, device-batched pivot loops per rank), closed by ONE 
 through the C-ABI (gomilp_incumbent_allreduce); value = relaxations per second of the whole job, scaling "strong".
 
 Rank 0 prints ONE JSON line.  `roofline` prices the kernel with the largest share of GPU time in the timed region — the
-single-workgroup block kernel k_bt_inner2 (latency-bound: `bound` says so) — by its algorithmic bytes per launch over its
-HIP-event launch duration against the HBM peak; `roofline.loop` does the same for the whole pivot loop (block kernel +
-streaming rank-8 update + boundaries) with the byte model of THIS pipeline, `roofline.streaming_kernel` for the
-HBM-streaming kernel alone.  `cpu_baseline` times the CPU oracle (the reference algorithm: 3 fresh LU per pivot) on a
+persistent loop kernel k_bt_loop (pivot workgroups + update workgroups in one launch; its pace is set by the pivot chain:
+`bound` says "latency") — by its algorithmic bytes per block of 8 pivots over its HIP-event time per block against the HBM
+peak; `roofline.loop` does the same with the wall time of the whole pivot loop (launch boundaries and host waits included).  `cpu_baseline` times the CPU oracle (the reference algorithm: 3 fresh LU per pivot) on a
 bounded sample of the same workload on the host cores.
 """
 from __future__ import annotations
@@ -85,6 +84,17 @@ def mfma_object(m, nn, pipeline, ksec):
     flop and runs at the MALL / HBM rate, so its MFMA pipes are mostly idle by construction."""
     if pipeline != "blocked" or max(m, nn) <= 1024 or ksec[1] <= 0:
         return {"util": 0.0, "why": "this shape runs the rank-8 VALU update (1 flop per byte moved); no MFMA instruction is issued"}
+    if ksec[2] <= 0:
+        # persistent loop kernel: the rank-8 update of a block (two v_mfma_f64_16x16x4_f64 per 16 x 16 block of the tableau) is
+        # applied by the update workgroups of the SAME launch beside the next block's pivots: busy share over the block time
+        t_blk = ksec[0] / ksec[1]
+        n_mfma = (m // 16) * (nn // 16) * 2.0
+        return {"kernel": "k_bt_loop (update role)", "instructions_per_block": n_mfma, "tflops": n_mfma * 2048.0 / t_blk / 1e12,
+                "util": (n_mfma * 64.0) / (1024 * t_blk * 2.4e9),
+                "util_model": "MFMA instructions x 64 busy cycles (f64 16x16x4, counter-checked in round 2) / (1024 SIMDs x block time x 2.4 GHz)",
+                "why_low": "the update moves 16 bytes per 16 flop (rank 8) and is hidden behind the latency-bound pivot chain of the same launch: "
+                           "the matrix cores only have to keep it off the VALU; pricing is one row update per pivot in the tableau form, and sibling "
+                           "relaxations do not share a matrix once their bases differ: there is no batched pricing GEMM"}
     t_upd = ksec[2] / ksec[1]
     n_mfma = (m // 16) * (nn // 16) * 4.0                 # wave-level v_mfma_f64_16x16x4_f64 per update launch
     flops = n_mfma * 2048.0
@@ -388,30 +398,55 @@ def main() -> int:
         bytes_inner = K * 16.0 * (m + nn) + 2 * 12.0 * (m + nn)
         bytes_update = 16.0 * m * nn
         block_s = loop_s / max(pivots / K, 1.0)   # wall time of the loop per block: kernels + boundaries + the host's chunk waits
-        share_inner = t_inner / max(t_inner + t_upd, 1e-30)
-        traffic, tsrc = newest_pmc(inner_name.split("<")[0] + "<")
-        roofline = {
-            "bound": "latency", "kernel": inner_name, "time_share": share_inner * loop_s / dt,
-            "achieved": bytes_inner / t_inner / 1e9 if t_inner > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "traffic": traffic, "traffic_source": tsrc,
-            "bytes_per_launch": bytes_inner, "avg_launch_us": 1e6 * t_inner, "us_per_pivot": 1e6 * t_inner / K, "pivots_per_launch": K,
-            "note": ("single-workgroup kernel (1 of 256 CUs)" if need <= 1024 else "8 workgroups of one XCD (8 of 256 CUs), two exchanges through that XCD's L2 per pivot") +
-                    ": two first-index argmins over all columns / rows and two dependent tableau reads per "
-                    "pivot; its roof is the dependent-latency chain, not HBM bandwidth — `frac` is reported against the HBM peak all the same",
-            "loop": {"bytes_per_block": bytes_inner + bytes_update, "block_us": 1e6 * block_s,
-                     "kernel_us_per_block": 1e6 * (t_inner + t_upd), "achieved_GBs": (bytes_inner + bytes_update) / block_s / 1e9,
-                     "frac": (bytes_inner + bytes_update) / block_s / 1e9 / HBM_PEAK_GBS,
-                     "model": "per block of K pivots: 16*m*(n-m) (rank-K update: T read + written once) + K*16*(m+n-m) + 24*(m+n-m) (block kernel)"},
-            "streaming_kernel": {"bound": "hbm", "kernel": upd_name, "bytes_per_launch": bytes_update, "avg_launch_us": 1e6 * t_upd,
-                                 "achieved": bytes_update / t_upd / 1e9 if t_upd > 0 else 0.0, "frac": bytes_update / t_upd / 1e9 / HBM_PEAK_GBS if t_upd > 0 else 0.0,
-                                 "traffic": newest_pmc(upd_name.split("<")[0])[0], "traffic_source": newest_pmc(upd_name.split("<")[0])[1],
-                                 "time_share": (1 - share_inner) * loop_s / dt,
-                                 "note": "the %.1f MB tableau stays in the 256 MB Infinity Cache between launches: a MALL rate where it exceeds the ~6.3 TB/s HBM copy rate" % (8e-6 * m * nn)},
-            "sampled_blocks": int(ksec[1]), "sampled_pivots": int(ksec[3]),
-            "per_pivot_survey_model": {"bytes": bytes_pivot_survey, "achieved_GBs": value * bytes_pivot_survey / 1e9, "frac": value * bytes_pivot_survey / 1e9 / HBM_PEAK_GBS,
-                                       "note": "SURVEY §8d explicit-inverse model (134 MB per pivot at the metric size); the blocked tableau moves ~%.1f MB per pivot, so this ratio can exceed 1 and is not a roofline" % ((bytes_inner + bytes_update) / K / 1e6)},
-        }
-        roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+        if t_upd <= 0 and need > 1024:
+            # persistent loop kernel: ONE kernel carries the whole pivot loop — the pivot workgroups' chain and, beside it, the
+            # update workgroups' streaming pass over the tableau (read + written once per block of K = 8 pivots)
+            loop_name = "k_bt_loop<8,%d,1>" % (256 if need <= 2048 else 512)
+            traffic, tsrc = newest_pmc("k_bt_loop")
+            bytes_block = bytes_inner + bytes_update
+            roofline = {
+                "bound": "latency", "kernel": loop_name, "time_share": loop_s / dt,
+                "achieved": bytes_block / t_inner / 1e9 if t_inner > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "traffic": traffic, "traffic_source": tsrc, "traffic_unit": "bytes per block of %d pivots" % int(K),
+                "bytes_per_block": bytes_block, "block_us": 1e6 * t_inner, "us_per_pivot": 1e6 * t_inner / K, "pivots_per_block": K,
+                "blocks_per_launch": "up to 64 (knob loop_chunk = 512 pivots)",
+                "note": "persistent kernel, one workgroup per CU or fewer: 8 pivot workgroups on one XCD run the blocks (two exchanges through that XCD's L2 and two "
+                        "dependent tableau reads per pivot: the latency chain that sets the pace), the other workgroups apply the rank-8 update of block t "
+                        "(tableau read + written once, matrix cores) beside block t+1.  achieved = algorithmic bytes per block (16 m (n-m) update + the pivot "
+                        "workgroups' columns, rows and terms) / HIP-event time of the launch per block",
+                "loop": {"bytes_per_block": bytes_block, "block_us": 1e6 * block_s, "kernel_us_per_block": 1e6 * t_inner,
+                         "achieved_GBs": bytes_block / block_s / 1e9, "frac": bytes_block / block_s / 1e9 / HBM_PEAK_GBS, "us_per_pivot_end_to_end": 1e6 * block_s / K,
+                         "model": "per block of K pivots: 16*m*(n-m) (rank-K update: T read + written once) + K*16*(m+n-m) + 24*(m+n-m) (pivot workgroups); wall time of the whole loop / blocks"},
+                "sampled_blocks": int(ksec[1]), "sampled_pivots": int(ksec[3]),
+                "per_pivot_survey_model": {"bytes": bytes_pivot_survey, "achieved_GBs": value * bytes_pivot_survey / 1e9, "frac": value * bytes_pivot_survey / 1e9 / HBM_PEAK_GBS,
+                                           "note": "SURVEY §8d explicit-inverse model (134 MB per pivot at the metric size); the blocked tableau moves ~%.1f MB per pivot, so this ratio can exceed 1 and is not a roofline" % (bytes_block / K / 1e6)},
+            }
+            roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+        else:
+            share_inner = t_inner / max(t_inner + t_upd, 1e-30)
+            traffic, tsrc = newest_pmc(inner_name.split("<")[0] + "<")
+            roofline = {
+                "bound": "latency", "kernel": inner_name, "time_share": share_inner * loop_s / dt,
+                "achieved": bytes_inner / t_inner / 1e9 if t_inner > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "traffic": traffic, "traffic_source": tsrc,
+                "bytes_per_launch": bytes_inner, "avg_launch_us": 1e6 * t_inner, "us_per_pivot": 1e6 * t_inner / K, "pivots_per_launch": K,
+                "note": ("single-workgroup kernel (1 of 256 CUs)" if need <= 1024 else "8 workgroups of one XCD (8 of 256 CUs), two exchanges through that XCD's L2 per pivot") +
+                        ": two first-index argmins over all columns / rows and two dependent tableau reads per "
+                        "pivot; its roof is the dependent-latency chain, not HBM bandwidth — `frac` is reported against the HBM peak all the same",
+                "loop": {"bytes_per_block": bytes_inner + bytes_update, "block_us": 1e6 * block_s,
+                         "kernel_us_per_block": 1e6 * (t_inner + t_upd), "achieved_GBs": (bytes_inner + bytes_update) / block_s / 1e9,
+                         "frac": (bytes_inner + bytes_update) / block_s / 1e9 / HBM_PEAK_GBS,
+                         "model": "per block of K pivots: 16*m*(n-m) (rank-K update: T read + written once) + K*16*(m+n-m) + 24*(m+n-m) (block kernel)"},
+                "streaming_kernel": {"bound": "hbm", "kernel": upd_name, "bytes_per_launch": bytes_update, "avg_launch_us": 1e6 * t_upd,
+                                     "achieved": bytes_update / t_upd / 1e9 if t_upd > 0 else 0.0, "frac": bytes_update / t_upd / 1e9 / HBM_PEAK_GBS if t_upd > 0 else 0.0,
+                                     "traffic": newest_pmc(upd_name.split("<")[0])[0], "traffic_source": newest_pmc(upd_name.split("<")[0])[1],
+                                     "time_share": (1 - share_inner) * loop_s / dt,
+                                     "note": "the %.1f MB tableau stays in the 256 MB Infinity Cache between launches: a MALL rate where it exceeds the ~6.3 TB/s HBM copy rate" % (8e-6 * m * nn)},
+                "sampled_blocks": int(ksec[1]), "sampled_pivots": int(ksec[3]),
+                "per_pivot_survey_model": {"bytes": bytes_pivot_survey, "achieved_GBs": value * bytes_pivot_survey / 1e9, "frac": value * bytes_pivot_survey / 1e9 / HBM_PEAK_GBS,
+                                           "note": "SURVEY §8d explicit-inverse model (134 MB per pivot at the metric size); the blocked tableau moves ~%.1f MB per pivot, so this ratio can exceed 1 and is not a roofline" % ((bytes_inner + bytes_update) / K / 1e6)},
+            }
+            roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
     else:
         nsamp = max(ksec[3], 1.0)
         t_upd = ksec[2] / nsamp
@@ -499,13 +534,15 @@ def main() -> int:
         nb4 = max(k4[1], 1.0)
         out["c4"] = {"workload": "C4: %dx%d dense LP (seed %d), one full solve" % (m4, 2 * m4, seed4), "status": int(r4.status),
                      "pivots": int(r4.stats["pivots_phase2"]), "seconds": t4, "pivots_per_s": r4.stats["pivots_phase2"] / t4,
+                     "loop_us_per_pivot": 1e6 * r4.stats["seconds_pivot_loop"] / max(r4.stats["pivots_phase2"], 1),
+                     "block_GBs": (16.0 * m4 * m4 + (k4[3] / nb4) * 32.0 * m4) / (k4[0] / nb4) / 1e9 if k4[0] > 0 else 0.0,
                      "inner_us_per_launch": 1e6 * k4[0] / nb4, "update_us_per_launch": 1e6 * k4[2] / nb4, "pivots_per_launch": k4[3] / nb4,
                      "update_GBs": 16.0 * m4 * m4 / (k4[2] / nb4) / 1e9 if k4[2] > 0 else 0.0,
                      "update_frac_of_hbm_peak": 16.0 * m4 * m4 / (k4[2] / nb4) / 1e9 / HBM_PEAK_GBS if k4[2] > 0 else 0.0,
-                     "inner_kernel": "k_bt_innerG<8,512,1,16>",
-                     "note": "the 134 MB tableau no longer fits the Infinity Cache with everything else: the update (k_bt_update_mfma16) runs at the HBM rate; block kernel = 8 workgroups "
-                             "of one XCD, two L2 exchanges per pivot, K = 16 terms per row / column in registers (btg_kernels.hip); the single-workgroup "
-                             "k_bt_inner (knob bt_groups = -1) needs 295 us per 16 pivots at this size"}
+                     "inner_kernel": "k_bt_loop<8,512,1>",
+                     "note": "persistent loop kernel (blocks of 8 pivots on 8 pivot workgroups of one XCD, the rank-8 update of block t on the other workgroups beside block "
+                             "t+1; inner_us_per_launch = time per block): the two 134 MB tableau buffers do not fit the Infinity Cache, the update streams at the HBM "
+                             "rate (block_GBs) and sets the block time at this size, not the pivot chain"}
         p4.free()
         cx4.close()
         del c4, A4, b4

@@ -216,10 +216,14 @@ __global__ __launch_bounds__(kBlock) void k_b_ctrl(BatchLP *__restrict__ lps, co
         }
     } else if (stage == BS_P1 && st->done) {
         const int status = st->status;
-        if (status != ST_OPTIMAL) {   // simplex.go:557-559: any error of the recursive call comes back wrapped
+        if (status != ST_OPTIMAL && status != ST_UNBOUNDED && status != ST_BLAND_FAILED) {
+            // not an outcome of the algorithm (an exchange of the multi-workgroup block kernel timed out: a workgroup was not
+            // resident in time): the single-relaxation engine solves this relaxation instead of reporting a device error
+            if (tid == 0) lp.stage = BS_HOST;
+        } else if (status != ST_OPTIMAL) {   // simplex.go:557-559: any error of the recursive call comes back wrapped
             if (tid == 0) {
                 lp.piv1 += st->pivots; lp.bland += st->bland_steps;
-                lp.wrapped = status == ST_UNBOUNDED ? 4 : (status == ST_BLAND_FAILED ? 1 : 12);
+                lp.wrapped = status == ST_UNBOUNDED ? 4 : 1;
                 lp.status = 9;   // GOMILP_ERR_PHASE1_WRAPPED
                 lp.stage = BS_DONE;
             }
@@ -317,10 +321,14 @@ __global__ __launch_bounds__(kBlock) void k_b_ctrl(BatchLP *__restrict__ lps, co
         to_phase2 = true;   // the forced exchange pivot has run (ST_FORCED_DONE): the artificial is nonbasic now
     } else if (stage == BS_P2 && st->done) {
         if (tid == 0) {
-            lp.piv2 += st->pivots; lp.bland += st->bland_steps;
             const int status = st->status;
-            lp.status = status == ST_OPTIMAL ? 0 : (status == ST_UNBOUNDED ? 4 : (status == ST_BLAND_FAILED ? 1 : 12));
-            lp.stage = BS_DONE;
+            if (status != ST_OPTIMAL && status != ST_UNBOUNDED && status != ST_BLAND_FAILED) {
+                lp.stage = BS_HOST;   // (see the Phase-I case: a transient device condition, the worker path solves it)
+            } else {
+                lp.piv2 += st->pivots; lp.bland += st->bland_steps;
+                lp.status = status == ST_OPTIMAL ? 0 : (status == ST_UNBOUNDED ? 4 : 1);
+                lp.stage = BS_DONE;
+            }
         }
     }
     if (to_phase2) {

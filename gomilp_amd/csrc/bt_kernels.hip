@@ -164,6 +164,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
             p = (int)w.i;
             const double mv = orddecode(w.k);
             if (mv == inf) { status = ST_UNBOUNDED; break; }  // simplex.go:328-330
+            if (a.guard > 0 && mv <= a.guard && !(k == 0 && a.exact_once)) { status = ST_NEED_EXACT; break; }   // degenerate (or nearly): decided on a fresh x_B
             if (mv <= 0) {
                 // ---- replaceBland (simplex.go:347-383): candidates in position order with r_i <= -1e-14 after the
                 // 1e-13 rounding of :252-256; the mat.Cond guard of :377 is replaced by |d| >= 1e-13
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
                 rq = r_s[q];
             }
         } else {
-            q = a.forced_q; p = a.forced_p; rq = 0;
+            q = a.forced_q; p = a.forced_p;
+            rq = a.forced_nocommit ? 0.0 : r_s[q];   // a set-up pivot leaves the reduced costs alone (they are rebuilt); a pivot the host decided on fresh solves (exact_step) is a pivot like any other
             column(q, k, dcol);
         }
         // ---- row p of the current tableau for this thread's columns; its owner publishes the pivot element d_p and
@@ -354,6 +356,7 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
     __shared__ unsigned int redIA[16], redIB[16];
     __shared__ double payA[16][KR + 1];  // per wave: r_q, v'_k[q]
     __shared__ double payB[16][KR + 2];  // per wave: d_p, x_B[p], u_k[p]
+    __shared__ double red2[16];          // guard mode: per-wave runner-up of the ratio test
     DevState *st = a.st;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
@@ -548,20 +551,49 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
 #pragma unroll
                 for (int s = 0; s < CJ; s++) rv[s] = r_s[tid + s * NT];
                 fq = reduce_cols(rv, rq, vq);
+                if (a.guard > 0 && !(k == 0 && a.exact_once)) {
+                    // Guard mode (BTArgs::guard).  The reference takes this decision on reduced costs recomputed from a fresh LU
+                    // (simplex.go:236-248): a minimum within the guard of the stop threshold, or two columns within the guard of each
+                    // other (integer data: exact ties), is decided by that solve's rounding noise — the host repeats it (ST_NEED_EXACT)
+                    double x2 = inf;
+#pragma unroll
+                    for (int s = 0; s < CJ; s++) x2 = vmin_f64(x2, (unsigned int)(tid + s * NT) == fq.i ? inf : rv[s]);
+                    x2 = wave_min_f64(x2);
+                    __syncthreads();   // (everyone has read payA / redMA of the reduction above before red2 reuses the barrier slot)
+                    if (lane == 0) red2[wv] = x2;
+                    __syncthreads();
+                    const double y2 = lane < NW ? red2[lane] : inf;
+                    const double r2 = readlane_f64(row_min_f64(y2), 15);
+                    const double rq0 = rq;   // (uniform)
+                    if (fabs(rq0 + a.tol) <= a.guard || r2 - rq0 <= a.guard * fmax(1.0, fabs(rq0))) { status = ST_NEED_EXACT; break; }
+                }
             }
             q = (int)fq.i;
             if (fq.i >= (unsigned int)a.nn) { q = 0; rq = __builtin_nan(""); }  // every r_j is NaN: MinIdx returns 0
             if (rq >= -a.tol) { status = ST_OPTIMAL; break; }  // simplex.go:248
             column(q, vq, dcol);
             BtWin w;
+            double mv2 = inf;   // guard mode: the runner-up ratio
             {
                 double mvv[RI];
                 ratios(dcol, mvv);
                 w = reduce_rows(mvv, dcol, dpv, xbp, up);
+                if (a.guard > 0) {   // (uniform) second-smallest ratio: a tie, exact or nearly, is broken by the fresh x_B's rounding noise too
+                    double x2 = inf;
+#pragma unroll
+                    for (int s = 0; s < RI; s++) x2 = vmin_f64(x2, (unsigned int)(tid + s * NT) == w.i ? inf : mvv[s]);
+                    x2 = wave_min_f64(x2);
+                    if (lane == 0) red2[wv] = x2;
+                    __syncthreads();
+                    const double y2 = lane < NW ? red2[lane] : inf;
+                    mv2 = readlane_f64(row_min_f64(y2), 15);
+                }
             }
             p = (int)w.i;
             const double mv = w.m;
             if (mv == inf || w.i >= (unsigned int)a.m) { status = ST_UNBOUNDED; break; }  // simplex.go:328-330
+            // degenerate (or nearly), or two rows within 1e-9 of each other: decided on a fresh gonum-order x_B (DevTypes: BTArgs::guard)
+            if (a.guard > 0 && !(k == 0 && a.exact_once) && (mv <= a.guard || mv2 - mv <= a.guard * fmax(1.0, fabs(mv)))) { status = ST_NEED_EXACT; break; }
             if (mv <= 0) {
                 // ---- replaceBland (simplex.go:347-383): candidates in position order with r_i <= -1e-14 after the
                 // 1e-13 rounding of :252-256; the mat.Cond guard of :377 is replaced by |d| >= 1e-13
@@ -608,7 +640,8 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
             }
         } else {
             // set-up pivot chosen by the host: first pivot of a block, so the block terms are all zero
-            q = a.forced_q; p = a.forced_p; rq = 0;
+            q = a.forced_q; p = a.forced_p;
+            rq = a.forced_nocommit ? 0.0 : r_s[q];   // a set-up pivot leaves the reduced costs alone (they are rebuilt); a pivot the host decided on fresh solves (exact_step) is a pivot like any other
             column(q, vq, dcol);   // vq -> the zeros written before the loop
             double gl[RI];
 #pragma unroll

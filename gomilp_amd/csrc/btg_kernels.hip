@@ -40,13 +40,14 @@ namespace {
 constexpr int kXSlots = 8;             // slots per record (one 128-byte line): min, first index, 3 scalars of the winner
 constexpr int kXHeader = 16;           // doubles in front of the records: [0] = exchanges completed so far
 constexpr int kXSpinLimit = 2000000;   // polls (~0.5 us each) before a launch gives up
-// Persistent loop kernel (k_bt_loop): header [1 + 2 par] / [2 + 2 par] = arrivals expected before the first block of the launch
-// with parity par on the two counters below (written by workgroup 0 of the previous launch: a launch never rewrites what its
-// own late starters still have to read); the counters sit on lines of their own
+// Persistent loop kernel (k_bt_loop): header [1 + 5 par + j] = arrivals expected before the first block of the launch with parity
+// par on counter j below (written by workgroup 0 of the previous launch: a launch never rewrites what its own late starters
+// still have to read); the counters sit on lines of their own.  Update arrivals are counted per block index mod 4: with ONE
+// total a fast update workgroup's arrival for block t + 1 could stand in for a slow one's missing arrival for block t
 // behind the records: blocks finished by the pivot workgroups (G arrivals per block), blocks applied by the update
 // workgroups (one arrival per update workgroup and block)
 constexpr int kXSync = kXHeader + 2 * 8 * kXSlots * 2;   // doubles in front of the counters
-constexpr int kXSyncDoubles = 32;
+constexpr int kXSyncDoubles = 16 * 5;   // the block counter and four update counters (blocks = j mod 4), a line each
 constexpr int kLoopSpinLimit = 600000;   // polls (~1.5 us each) of a block / update counter before a workgroup gives up
 
 typedef double xpair __attribute__((ext_vector_type(2)));   // {sequence number, value}
@@ -96,7 +97,7 @@ struct BtWinG { double m; unsigned int i; };                   // a wave's own w
 template <int G, int NT, int RI, int KR, bool STAMP, bool LOOP = false>
 __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, const int nupd = 0) {
     constexpr int NW = NT / 64;
-    static_assert(!LOOP || (KR == 16 && !STAMP), "loop mode: 8 lagging + 8 current terms");
+    static_assert(!LOOP || KR == 16, "loop mode: 8 lagging + 8 current terms");
     static_assert(G == 2 || G == 4 || G == 8, "G");
     if (a.fault && g == 1) return;   // test hook: a workgroup that never takes part -> the others must give up (ST_XCHG_TIMEOUT)
     __shared__ double redM[16];
@@ -156,8 +157,19 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
     // previous one (not yet in the tableau this block reads)
     int cur0 = 0, lag0 = 8, nl = 0;
     const int sel0 = LOOP ? (a.par ? st->tsel2[1] : st->tsel2[0]) : 0;
-    const unsigned int blk_base = LOOP ? (unsigned int)(unsigned long long)a.xbuf[1 + 2 * a.par] : 0u, upd_base = LOOP ? (unsigned int)(unsigned long long)a.xbuf[2 + 2 * a.par] : 0u;
+    const double *hdr_in = a.xbuf + 1 + 5 * (LOOP ? a.par : 0);
+    double *hdr_out = a.xbuf + 1 + 5 * (LOOP ? (a.par ^ 1) : 0);
+    const unsigned int blk_base = LOOP ? (unsigned int)(unsigned long long)hdr_in[0] : 0u;
+    unsigned int upd_base[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) upd_base[j] = LOOP ? (unsigned int)(unsigned long long)hdr_in[1 + j] : 0u;
     unsigned int *blk_cnt = reinterpret_cast<unsigned int *>(a.xbuf + kXSync), *upd_cnt = reinterpret_cast<unsigned int *>(a.xbuf + kXSync + 16);
+    // counters in step for the next launch after nb blocks: G arrivals per block, nupd per block on the counter of its index mod 4
+    auto hand_on = [&](int nb) {
+        hdr_out[0] = (double)(unsigned int)(blk_base + (unsigned int)G * (unsigned int)nb);
+#pragma unroll
+        for (int j = 0; j < 4; j++) hdr_out[1 + j] = (double)(unsigned int)(upd_base[j] + (unsigned int)nupd * (unsigned int)(nb > j ? (nb - 1 - j) / 4 + 1 : 0));
+    };
     if (done) {
         if constexpr (LOOP) {
             // a launch enqueued behind the end of the loop: the update workgroups wait for block 0 — release them (no pivots to
@@ -171,8 +183,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
                 if (g == 0) {
                     st->tsel2[a.par ^ 1] = sel0;
                     st->loop_blocks = 0;
-                    a.xbuf[1 + 2 * (a.par ^ 1)] = (double)(unsigned int)(blk_base + (unsigned int)G);
-                    a.xbuf[2 + 2 * (a.par ^ 1)] = (double)(unsigned int)(upd_base + (unsigned int)nupd);
+                    hand_on(1);
                 }
             }
         } else if (g == 0 && tid == 0) st->kdone = 0;
@@ -241,7 +252,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
                 v.y = lane == 0 ? fm : lane == 1 ? (double)fi : lane == 5 ? (double)myxcc : v0;
                 xstore(recs + ((size_t)(par * G + g) * kXSlots + lane), v, fast);
             }
-            if constexpr (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (STAMP && !LOOP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         stamp(which * 5 + 2);
         // lane l reads slot l >> 3 of record l & 7: the G minima sit in lanes 0..G-1, their indices in lanes 8.., the scalars behind
@@ -262,16 +273,18 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
         xm = vmin_f64(xm, dpp_f64<0xB1>(xm));    // quad_perm [1,0,3,2]
         xm = vmin_f64(xm, dpp_f64<0x4E>(xm));    // quad_perm [2,3,0,1]
         xm = vmin_f64(xm, dpp_f64<0x141>(xm));   // row_half_mirror
-        const double bm = readlane_f64(xm, 0);
-        unsigned int mk = (unsigned int)(__ballot(lane < G && val == bm) & 0xFFull);
-        double bi = 4294967295.0;
-        int gw = 0;
-        while (mk) {
-            const int g2 = __builtin_ctz(mk);
-            mk &= mk - 1;
-            const double ig = readlane_f64(val, 8 + g2);
-            if (ig < bi) { bi = ig; gw = g2; }
-        }
+        // (lanes 0..7 all hold the minimum now.)  Smallest index among the records that attain it, without a trip through
+        // scalar registers per candidate: the index of record l (lane 8 + l) is shifted into lane l, lanes that do not attain
+        // the minimum offer +big, three more DPP steps, one ballot finds the owner
+        const double idxl = dpp_f64<0x108>(val);   // row_shl:8
+        const bool mine = lane < G && val == xm;
+        double km = mine ? idxl : 4294967295.0;
+        km = vmin_f64(km, dpp_f64<0xB1>(km));
+        km = vmin_f64(km, dpp_f64<0x4E>(km));
+        km = vmin_f64(km, dpp_f64<0x141>(km));
+        const unsigned int mk = (unsigned int)(__ballot(mine && idxl == km) & 0xFFull);
+        const int gw = mk ? __builtin_ctz(mk) : 0;
+        const double bm = readlane_f64(xm, 0), bi = readlane_f64(km, 0);
         XWin r;
         r.m = bm;
         r.i = (unsigned int)bi;
@@ -326,6 +339,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             const int l = lane & 15;
             const int trow = l < k ? cur0 + k - 1 - l : lag0 + nl - 1 - (l - k);
             const double tv = l < k + nl ? ld_term(a.V + (size_t)trow * a.ldt + q) : 0.0;
+            if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(11); }   // column + term loads: issue -> data
 #pragma unroll
             for (int jj = 0; jj < KR; jj++) vq[jj] = readlane_f64(tv, jj);
         } else {
@@ -334,9 +348,17 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
         }
 #pragma unroll
         for (int s = 0; s < RI; s++) {
-            double d = d0[s];
+            double d;
+            if constexpr (LOOP) {   // four partial sums, the tableau entry added last: the multiply-adds run under its load latency
+                double acc[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int j = 0; j < KR; j++) d = __builtin_fma(ureg[s][j], vq[j], d);
+                for (int j = 0; j < KR; j++) acc[j & 3] = __builtin_fma(ureg[s][j], vq[j], acc[j & 3]);
+                d = d0[s] + ((acc[0] + acc[1]) + (acc[2] + acc[3]));
+            } else {
+                d = d0[s];
+#pragma unroll
+                for (int j = 0; j < KR; j++) d = __builtin_fma(ureg[s][j], vq[j], d);
+            }
             dcol[s] = gidx(s) < a.m ? d : 0.0;
         }
     };
@@ -358,7 +380,9 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
         // block blk reads the tableau after blk - 1 blocks: the update of block blk - 2 must be through (nupd arrivals per block)
         if (blk >= 2) {   // (one verdict per workgroup: a wave that gave up alone would leave the others at a barrier)
             if (wv == 0) {
-                const bool ok = spin_counter(upd_cnt, upd_base + (unsigned int)nupd * (unsigned int)(blk - 1), 0);
+                const int cj = (blk - 2) & 3;
+                const unsigned int ub = cj == 0 ? upd_base[0] : cj == 1 ? upd_base[1] : cj == 2 ? upd_base[2] : upd_base[3];
+                const bool ok = spin_counter(upd_cnt + 16 * cj * 2, ub + (unsigned int)nupd * (unsigned int)((blk - 2) / 4 + 1), 0);
                 if (lane == 0) s_ok = ok ? 1 : 0;
             }
             __syncthreads();
@@ -399,6 +423,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             p = (int)w.i; dpv = w.p0; xbp = w.p1; lea = (int)w.p2;
             const double mv = w.m;
             if (mv == inf || w.i >= (unsigned int)a.m) { status = ST_UNBOUNDED; break; }   // simplex.go:328-330
+            if (a.guard > 0 && mv <= a.guard && !(k == 0 && blk == 0 && a.exact_once)) { status = ST_NEED_EXACT; break; }   // degenerate (or nearly): decided on a fresh x_B
             if (mv <= 0) {
                 // replaceBland (simplex.go:347-383), as in k_bt_inner2: candidates in position order
                 bland = true;
@@ -451,13 +476,14 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             }
         } else {
             // set-up pivot chosen by the host (first pivot of a block: all block terms are zero)
-            q = a.forced_q; p = a.forced_p; rq = 0;
+            q = a.forced_q; p = a.forced_p; rq = 0;   // (a set-up pivot leaves the reduced costs alone: they are rebuilt)
             double fl[RI];
 #pragma unroll
             for (int s = 0; s < RI; s++) fl[s] = (gidx(s) == q) ? 0.0 : inf;
             const XWin fc = reduce_cols(fl);
             if (dead) break;
             ent = (int)fc.p1;
+            if (!a.forced_nocommit) rq = fc.p0;   // a pivot the host decided on fresh solves (exact_step): a pivot like any other
             column(q, k, dcol);
             double gl2[RI];
 #pragma unroll
@@ -484,6 +510,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             const int l = lane & 15;
             const int trow = l < k ? cur0 + k - 1 - l : lag0 + nl - 1 - (l - k);
             const double tv = l < k + nl ? ld_term(a.U + (size_t)trow * a.ldu + p) : 0.0;
+            if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(12); }   // row + term loads: issue -> data
 #pragma unroll
             for (int jj = 0; jj < KR; jj++) up[jj] = readlane_f64(tv, jj);
         } else {
@@ -507,9 +534,17 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
         for (int s = 0; s < RI; s++) {
             const int j = gidx(s);
             if (j < a.ldt) {
-                double v = vrow[s];
+                double v;
+                if constexpr (LOOP) {
+                    double acc[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int jj = 0; jj < KR; jj++) v = __builtin_fma(up[jj], vreg[s][jj], v);
+                    for (int jj = 0; jj < KR; jj++) acc[jj & 3] = __builtin_fma(up[jj], vreg[s][jj], acc[jj & 3]);
+                    v = vrow[s] + ((acc[0] + acc[1]) + (acc[2] + acc[3]));
+                } else {
+                    v = vrow[s];
+#pragma unroll
+                    for (int jj = 0; jj < KR; jj++) v = __builtin_fma(up[jj], vreg[s][jj], v);
+                }
                 rv[s] = (j == q) ? -mult : __builtin_fma(-mult, v, rv[s]);
                 const double vprime = (j == q) ? dpv + 1.0 : v;
                 st_term(Vk + j, vprime);
@@ -519,7 +554,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
                 if (j == q && commit_lists) nbasv[s] = lea;
             }
         }
-        if constexpr (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (STAMP && !LOOP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(10);
         if (forced && a.forced_nocommit == 3) status = ST_FORCED_DONE;
         if (g == 0 && tid == 0 && !(forced && a.forced_nocommit)) {   // simplex.go:280
@@ -577,8 +612,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
                 const int napplied = kd > 0 ? nbe : nbe - 1;
                 st->tsel2[a.par ^ 1] = sel0 ^ (napplied & 1);
                 st->loop_blocks = nbe;
-                a.xbuf[1 + 2 * (a.par ^ 1)] = (double)(unsigned int)(blk_base + (unsigned int)G * (unsigned int)nbe);
-                a.xbuf[2 + 2 * (a.par ^ 1)] = (double)(unsigned int)(upd_base + (unsigned int)nupd * (unsigned int)nbe);
+                hand_on(nbe);
             } else {
                 st->kdone = kd;
             }
@@ -601,20 +635,26 @@ __global__ __launch_bounds__(NT) void k_bt_innerG(BTArgs a) {
 // Everything that crosses workgroups inside the launch — the terms, the pivot count, both tableau buffers — moves with agent-scope
 // accesses; a workgroup always owns the same units of the tableau, so it only ever re-reads what it wrote itself.
 typedef double btg_d4 __attribute__((ext_vector_type(4)));
+typedef double btg_d2 __attribute__((ext_vector_type(2)));
+typedef unsigned int btg_u4 __attribute__((ext_vector_type(4)));
+// 16-byte accesses: the column index n of an MFMA block may stand for any 16 tableau columns as long as the B operand uses the
+// same map, so two blocks X / Y cover 32 columns INTERLEAVED (X: c0 + 2n, Y: c0 + 2n + 1): a lane's X and Y entries of a row are
+// neighbours inside one 4x4 tile, one 16-byte agent-scope load / store instead of two of 8 bytes (8-byte agent-scope accesses run
+// at 0.54-0.70 of the 16-byte rate).  One unit of a wave = 16 rows x 64 columns: eight 16-byte tableau loads per lane in flight.
 template <int NT>
 __device__ __forceinline__ void bt_loop_update_role(const BTArgs &a, const int u, const int nupd, const int G) {
-    constexpr int NWV = NT / 64, CW = 2;   // column blocks per wave and unit
+    constexpr int NWV = NT / 64;
     DevState *st = a.st;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // (no look at `done` here: a launch behind the end of the loop is released by the pivot workgroups' arrival for block 0,
     // and a loop that ends in block 0 of THIS launch still has that block's terms to apply)
     __shared__ int s_go;
-    const int sel0 = st->tsel2[a.par];
-    const unsigned int blk_base = (unsigned int)(unsigned long long)a.xbuf[1 + 2 * a.par];
+    const int sel0 = a.par ? st->tsel2[1] : st->tsel2[0];
+    const unsigned int blk_base = (unsigned int)(unsigned long long)a.xbuf[1 + 5 * a.par];
     unsigned int *blk_cnt = reinterpret_cast<unsigned int *>(a.xbuf + kXSync), *upd_cnt = reinterpret_cast<unsigned int *>(a.xbuf + kXSync + 16);
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int ncb = a.ldt >> 4;
-    const int groups = (ncb + NWV * CW - 1) / (NWV * CW), strips = (a.m + 15) >> 4, nunits = groups * strips;
+    const int ncp = a.ldt >> 6;                      // units of 64 columns per row strip (ldt is a multiple of 512)
+    const int groups = (ncp + NWV - 1) / NWV, strips = (a.m + 15) >> 4, nunits = groups * strips;
     const int ntr = (a.m + 3) >> 2;                  // tile rows that exist
     const size_t trow = (size_t)(a.ldt >> 2) * 16;   // doubles per tile row
     for (int blk = 0; blk < a.nblocks; blk++) {
@@ -627,48 +667,71 @@ __device__ __forceinline__ void bt_loop_update_role(const BTArgs &a, const int u
             const double *src = ((sel0 ^ blk) & 1) ? a.Tbuf[1] : a.Tbuf[0];
             double *dst = ((sel0 ^ blk) & 1) ? a.Tbuf[0] : a.Tbuf[1];
             const int k0 = (blk & 1) * 8;
+            const double *Ub = a.U + (size_t)k0 * a.ldu, *Vb = a.V + (size_t)k0 * a.ldt;
+            const int tbytes = (int)((size_t)ntr * trow * 8);
+            const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(src), 0, tbytes, 0x00020000);
+            const auto rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, tbytes, 0x00020000);
+            const auto rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Vb), 0, (int)((size_t)8 * a.ldt * 8), 0x00020000);
             for (int unit = u; unit < nunits; unit += nupd) {
-                const int strip = unit / groups, cb0 = ((unit % groups) * NWV + wv) * CW;
-                if (cb0 >= ncb) continue;
-                const int row = strip * 16 + l15;
+                const int strip = unit / groups, cp = (unit % groups) * NWV + wv;
+                if (cp >= ncp) continue;
+                const int c0 = cp * 64;
+                const int row = strip * 16 + l15, rowc = row < a.m ? row : a.m - 1;
+                // element (row mrow + 4 r of the strip, columns c0 + 32 x + 2 n, + 1): tile row strip * 4 + r, row l4 inside the tile
+                const size_t boff = (size_t)(strip * 4) * trow + (size_t)((c0 + 2 * l15) >> 2) * 16 + l4 * 4 + ((2 * l15) & 3);
+                // 16-byte agent-scope (sc1, aux 16) buffer loads / stores: instructions the compiler knows, so it counts them and
+                // places the wait states around the matrix instructions itself (an inline-asm global_store_dwordx4 here lost
+                // data: the next instruction may overwrite a wide store's data registers before the store has read them)
+                btg_d2 c[8], bv[4];
                 double av[2];
 #pragma unroll
-                for (int s2 = 0; s2 < 2; s2++) {
-                    const int k = 4 * s2 + l4;
-                    av[s2] = (k < kd && row < a.m) ? ld_agent(a.U + (size_t)(k0 + k) * a.ldu + row) : 0.0;
-                }
-                const size_t boff = (size_t)(strip * 4) * trow + (size_t)(l15 >> 2) * 16 + l4 * 4 + (l15 & 3);
-                btg_d4 c[CW];
-                double bv[CW][2];
+                for (int x = 0; x < 2; x++) {
 #pragma unroll
-                for (int x = 0; x < CW; x++) {
-                    const bool in = cb0 + x < ncb;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) c[x][r] = (in && strip * 4 + r < ntr) ? ld_agent(src + boff + (size_t)r * trow + (size_t)(cb0 + x) * 64) : 0.0;
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; s2++) {
-                        const int k = 4 * s2 + l4;
-                        bv[x][s2] = (in && k < kd) ? ld_agent(a.V + (size_t)(k0 + k) * a.ldt + (cb0 + x) * 16 + l15) : 0.0;
+                    for (int r = 0; r < 4; r++) {
+                        const size_t off = boff + (size_t)(strip * 4 + r < ntr ? r : 0) * trow + (size_t)x * 128;   // (32 columns = 8 tiles on)
+                        c[x * 4 + r] = __builtin_bit_cast(btg_d2, __builtin_amdgcn_raw_buffer_load_b128(rs_src, (int)(off * 8), 0, 16));
                     }
                 }
 #pragma unroll
-                for (int x = 0; x < CW; x++) {
+                for (int t = 0; t < 4; t++) {
+                    const size_t off = (size_t)((t & 1) * 4 + l4) * a.ldt + c0 + (t >> 1) * 32 + 2 * l15;
+                    bv[t] = __builtin_bit_cast(btg_d2, __builtin_amdgcn_raw_buffer_load_b128(rs_v, (int)(off * 8), 0, 16));
+                }
+                av[0] = ld_agent(Ub + (size_t)l4 * a.ldu + rowc);
+                av[1] = ld_agent(Ub + (size_t)(4 + l4) * a.ldu + rowc);
+                // rows of U / V beyond the pivots of this block are stale, rows beyond m do not exist
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; s2++) c[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[x][s2], c[x], 0, 0, 0);
+                for (int s2 = 0; s2 < 2; s2++) {
+                    const bool kon = 4 * s2 + l4 < kd;
+                    if (!kon || row >= a.m) av[s2] = 0.0;
+                    if (!kon) { bv[s2] = btg_d2{0.0, 0.0}; bv[2 + s2] = btg_d2{0.0, 0.0}; }
+                }
+                btg_d4 cx[2], cy[2];
+#pragma unroll
+                for (int x = 0; x < 2; x++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { cx[x][r] = c[x * 4 + r][0]; cy[x][r] = c[x * 4 + r][1]; }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; s2++) {
+                        cx[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[x * 2 + s2][0], cx[x], 0, 0, 0);
+                        cy[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[x * 2 + s2][1], cy[x], 0, 0, 0);
+                    }
                 }
 #pragma unroll
-                for (int x = 0; x < CW; x++) {
-                    if (cb0 + x < ncb) {
+                for (int x = 0; x < 2; x++) {
 #pragma unroll
-                        for (int r = 0; r < 4; r++)
-                            if (strip * 4 + r < ntr) st_agent(dst + boff + (size_t)r * trow + (size_t)(cb0 + x) * 64, c[x][r]);
+                    for (int r = 0; r < 4; r++) {
+                        if (strip * 4 + r < ntr) {
+                            const btg_d2 o = {cx[x][r], cy[x][r]};
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(btg_u4, o), rs_dst, (int)((boff + (size_t)r * trow + (size_t)x * 128) * 8), 0, 16);
+                        }
                     }
                 }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's tableau stores have landed
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(upd_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(upd_cnt + 16 * (blk & 3) * 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (unsigned ints: 32 per line)
         if (dn) return;
     }
 }
@@ -676,10 +739,10 @@ __device__ __forceinline__ void bt_loop_update_role(const BTArgs &a, const int u
 // Blocks 0, 8, ..., 8 (G - 1) — one XCD under the round-robin placement of blocks — are the pivot workgroups, every other block
 // of the grid an update workgroup.  All workgroups of the launch must be resident (they wait for each other): the grid is one
 // workgroup per CU (launch_bt_loop), and every wait is bounded.
-template <int G, int NT, int RI>
+template <int G, int NT, int RI, bool STAMP = false>
 __global__ __launch_bounds__(NT) void k_bt_loop(BTArgs a) {
     const int b = (int)blockIdx.x, nupd = (int)gridDim.x - G;
-    if ((b & 7) == 0 && (b >> 3) < G) { bt_innerG_body<G, NT, RI, 16, false, true>(a, b >> 3, nupd); return; }
+    if ((b & 7) == 0 && (b >> 3) < G) { bt_innerG_body<G, NT, RI, 16, STAMP, true>(a, b >> 3, nupd); return; }
     const int before = min(G, (b + 7) >> 3);   // pivot blocks in front of block b
     bt_loop_update_role<NT>(a, b - before, nupd, G);
 }
@@ -700,6 +763,10 @@ __global__ __launch_bounds__(NT) void k_bt_innerG_batch(const BatchLP *__restric
     bt_innerG_body<G, NT, RI, KR, false>(a, (int)(j % G));
 }
 
+// Tried and dropped (round 3, loop mode): one record per WAVE (no LDS stage, no barrier: 32 records at 2048 rows, 64 at 4096, three
+// resp. six 16-byte loads per lane and poll).  Same pivots, but 35.1 instead of 32.3 us per 8 pivots at 2048 rows and 114 instead
+// of 52.6 at 4096: what the workgroup stage costs (stamps: ~1000 cycles in wave 0) the wider poll costs again (1600 instead of
+// 760 cycles from post to "all seen").
 // Tried and dropped (round 2): every participant ONE wave on its own CU (no barrier, no LDS hop; terms in LDS by position,
 // prefetched under the load latency).  Bit-identical results, but slower at 2048 rows: 8 waves x 4 rows 107.7 us per 16
 // pivots, 16 waves x 2 rows 97.0 us, against 80.2 us for 4 workgroups of 8 waves: one wave issues its ~1500 instructions
@@ -746,11 +813,15 @@ void launch_bt_inner_groups(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEv
     else { if (ri == 1) btg_launch<8, 512, 1>(a, s, e0, e1); else btg_launch<8, 512, 2>(a, s, e0, e1); }
 }
 // persistent loop kernel: one workgroup per CU (the pivot workgroups among them); only the one-row-per-thread instances
-bool bt_loop_supported(const BtGroupCfg &c) { return c.groups > 0 && c.ri == 1; }
+bool bt_loop_supported(const BtGroupCfg &c) { return c.groups >= 2 && c.ri == 1; }
 void launch_bt_loop(const BTArgs &a, int ncu, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const int G = a.groups;
     const unsigned int grid = (unsigned int)std::max(ncu, 8 * G);
-    if (a.group_nt == 256) { hipExtLaunchKernelGGL((k_bt_loop<8, 256, 1>), dim3(grid), dim3(256), 0, s, e0, e1, 0, a); return; }
+    if (a.group_nt == 256) {
+        if (a.stamps) hipExtLaunchKernelGGL((k_bt_loop<8, 256, 1, true>), dim3(grid), dim3(256), 0, s, e0, e1, 0, a);   // diagnostic build
+        else hipExtLaunchKernelGGL((k_bt_loop<8, 256, 1>), dim3(grid), dim3(256), 0, s, e0, e1, 0, a);
+        return;
+    }
     if (G == 2) hipExtLaunchKernelGGL((k_bt_loop<2, 512, 1>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);
     else if (G == 4) hipExtLaunchKernelGGL((k_bt_loop<4, 512, 1>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);
     else hipExtLaunchKernelGGL((k_bt_loop<8, 512, 1>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);

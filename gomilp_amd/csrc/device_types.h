@@ -15,6 +15,8 @@ enum : int32_t {
     ST_BLAND_FAILED = 6,  // replaceBland exhausted its candidates (lp.ErrBland, simplex.go:382)
     ST_FORCED_DONE = 7,   // a set-up pivot ordered with forced_nocommit = 3 has run: later launches of the superstep are no-ops
     ST_XCHG_TIMEOUT = 9,    // multi-workgroup block kernel (btg_kernels.hip): an exchange saw no progress (a workgroup never ran)
+    ST_NEED_EXACT = 10,     // the winning ratio is within BTArgs::guard of zero: the host refreshes x_B with a gonum-order solve of the
+                            // current basis before the decision is taken (simplex.go:268-277 sees a fresh x_B every pivot)
     ST_DUAL_INFEASIBLE = 8  // dual simplex (warm start): a row with x_B < 0 has no negative entry: the relaxation is infeasible
 };
 
@@ -143,6 +145,12 @@ struct BTArgs {
     double *Tbuf[2];
     int32_t loop, nblocks;
     int32_t par, pad_p;   // launch parity (DevState::tsel2, and the counter bases in the exchange buffer's header)
+    // Degenerate vertices: the reference recomputes x_B from a fresh LU every pivot (simplex.go:289), so basic variables at level
+    // zero carry that solve's rounding noise, and `move[replace] <= 0` (:269) as well as the argmin among several zero-level rows
+    // are decided by it.  guard > 0: a block stops (ST_NEED_EXACT) in front of a pivot whose winning ratio is <= guard; the host
+    // uploads the gonum-order x_B of the current basis and restarts with exact_once = 1 (the first pivot then decides as is).
+    double guard;
+    int32_t exact_once, pad_g;
 };
 
 // shape of the multi-workgroup block kernel for a tableau (btg_kernels.hip): groups == 0 -> single-workgroup kernels

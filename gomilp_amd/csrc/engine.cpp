@@ -36,13 +36,10 @@ Engine::~Engine() {
     if (stream_) hipStreamDestroy(stream_);
 }
 
-namespace { std::atomic<int> g_loop_inflight[64]; }
-bool Engine::loop_slot_acquire_static(int dev) {
-    std::atomic<int> &c = g_loop_inflight[dev & 63];
-    int expected = 0;
-    return c.compare_exchange_strong(expected, 1);
+std::mutex &Engine::loop_mutex(int dev) {
+    static std::mutex mu[64];
+    return mu[dev & 63];
 }
-void Engine::loop_slot_release_static(int dev) { g_loop_inflight[dev & 63].store(0); }
 
 int Engine::set(const std::string &key, int64_t v) {
     std::lock_guard<std::mutex> g(mu_);
@@ -63,6 +60,8 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "bt_groups") { if (v != -1 && v != 0 && v != 2 && v != 4 && v != 8) return GOMILP_ERR_BAD_SHAPE; bt_groups_ = v; }
     else if (key == "bt_stamps") bt_stamps_ = v ? 1 : 0;
     else if (key == "bt_lag") bt_lag_ = v ? 1 : 0;
+    else if (key == "exact_degenerate") { if (v < 0 || v > 2) return GOMILP_ERR_BAD_SHAPE; exact_degenerate_ = v; }
+    else if (key == "loop_grid") { if (v < 0 || v > 4096) return GOMILP_ERR_BAD_SHAPE; loop_grid_ = v; }
     else if (key == "loop_chunk") { if (v < 32) return GOMILP_ERR_BAD_SHAPE; loop_chunk_ = v; }
     else if (key == "cond_guard") cond_guard_ = v ? 1 : 0;
     else if (key == "block_k") { if (v < 0 || v > bt_max_k()) return GOMILP_ERR_BAD_SHAPE; block_k_ = v; }
@@ -328,6 +327,7 @@ int64_t Engine::upload_child_impl(const Problem &R, int64_t root, int K, const i
     // the host copy of [[A0, 0], [G#, I]] is only needed when a solve starts from a non-slack basis: built on demand
     P->hA.clear();
     P->root = root;
+    P->root_ptr = &R;   // (a root resident in another engine of the pool: `root` is -1, the owner keeps it alive)
     P->kvar.assign(var, var + K);
     P->ksign.assign(sign, sign + K);
     P->seconds_upload = now_s() - t0;
@@ -391,9 +391,11 @@ int Engine::refresh_xb_y(const Problem &P, const double *cost) {
 // host copy of A for the general-basis path; children derive it from their root (subproblem.go:81-139)
 bool Engine::ensure_host_A(const Problem &P) {
     if (!P.hA.empty()) return true;
-    if (!P.is_child || P.root < 0 || (size_t)P.root >= problems_.size() || !problems_[P.root]) return false;
-    const Problem &R = *problems_[P.root];
-    if (!ensure_host_A(R)) return false;
+    if (!P.is_child || !P.root_ptr) return false;
+    const Problem &R = *P.root_ptr;
+    // the root of a pool child may live in another worker's engine (gomilp_pool_add_root keeps extra roots in worker 0): its host
+    // copy was made at upload (roots are never built lazily), read in place
+    if (P.root >= 0 ? !ensure_host_A(R) : R.hA.empty()) return false;
     const int m = P.m, n = P.n, m0 = R.m, n0 = R.n, K = (int)P.kvar.size();
     if ((size_t)m * n > ((size_t)1 << 25)) return false;
     P.hA.assign((size_t)m * n, 0.0);
@@ -684,14 +686,19 @@ int Engine::run_loop_fused(const Problem &P, int phase, double tol, int nn, cons
 // of Dgetrs (lapack/gonum/dgetrs.go:37-45 -> blas/gonum/level3double.go:75-118) on the host, because
 // the upper solve is one sequential dependency chain of m^2/2 rounded operations.
 // ------------------------------------------------------------------------------------------------
-int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *singular, const int32_t *basic_host) {
+// transpose: the system is ab^T y = rhs (the reference's BTRAN, simplex.go:236: LU of a materialised copy of ab.T()).  The
+// column-major image of ab^T is the row-major image of ab, so the two gathers just change places; no column of ab^T is known
+// to be a unit vector.  rhs_host (m entries, by basis position; default b): the right-hand side.
+int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *singular, const int32_t *basic_host, bool transpose,
+                        const double *rhs_host) {
     Work &w = *w_;
     const double tf0 = now_s();
     const int m = P.m, ldw = P.ld;
     int nonunit = 0;
     const bool compressed = lu_blocked_ >= 2 && lu_compressed_supported(m);
+    const double *rhs = rhs_host ? rhs_host : P.hb.data();
     // the compressed schedule keeps L/U column-major (lu_compressed.hip), the other two row-major
-    if (compressed) launch_luc_gather(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
+    if (compressed != transpose) launch_luc_gather(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
     else launch_gather_w(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
     // unit columns of ab (from the column statistics of the upload): the blocked LU skips their elimination steps
     if (!basic_host) {   // the caller has no host copy of the basis positions yet
@@ -703,7 +710,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
         std::vector<int32_t> ur(m);
         for (int pos = 0; pos < m; pos++) {
             const int j = basic_host[pos];
-            ur[pos] = (j < P.n && P.nnz[j] == 1 && P.allone[j]) ? P.lastrow[j] : -1;
+            ur[pos] = (!transpose && j < P.n && P.nnz[j] == 1 && P.allone[j]) ? P.lastrow[j] : -1;
             if (ur[pos] < 0) nonunit++;
         }
         int rcu = stage_upload(w.unitrow, ur.data(), (size_t)m * sizeof(int32_t));
@@ -761,6 +768,12 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     // large bases: only the nd x nd part that couples the dense positions goes to the host (lu_compressed.hip,
     // k_luc_pack_dense / k_luc_solve_rows); small ones take one host pass over all rows (one round trip fewer)
     const bool split = compressed && m >= 1024 && nd > 0;
+    const double *rhs_dev = P.db;
+    if (split && rhs_host) {   // the row kernel reads the right-hand side on the device
+        int rcr = stage_upload(w.move, rhs_host, (size_t)m * sizeof(double));
+        if (rcr != GOMILP_OK) return rcr;
+        rhs_dev = w.move;
+    }
     if (split) launch_luc_pack_dense(a, w.dlist, nd, w.rho, Wd, w.ludiag, stream_);
     else if (compressed) launch_luc_pack(a, w.dlist, nd, Wd, w.ludiag, stream_);
     else launch_lu_pack(a, w.dlist, nd, Wd, w.ludiag, stream_);
@@ -788,7 +801,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
         std::vector<double> xdl(nd), xdu(nd);
         for (int s2 = 0; s2 < nd; s2++) {   // Dtrsm(Left, Lower, NoTrans, Unit)
             const double *row = w.h_W + (size_t)s2 * nd;
-            double bi = P.hb[phys[dl[s2]]];
+            double bi = rhs[phys[dl[s2]]];
             for (int t = 0; t < s2; t++) bi = term(bi, row[t], xdl[t]);
             xdl[s2] = bi;
         }
@@ -805,7 +818,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
         int rcs = stage_upload(dxl, xdl.data(), (size_t)nd * sizeof(double));
         if (rcs == GOMILP_OK) rcs = stage_upload(dxu, xdu.data(), (size_t)nd * sizeof(double));
         if (rcs != GOMILP_OK) return rcs;
-        launch_luc_solve_rows(a, w.dlist, nd, P.db, dxl, dxu, dx, stream_);
+        launch_luc_solve_rows(a, w.dlist, nd, rhs_dev, dxl, dxu, dx, stream_);
         launches_++;
         HIP_TRY(hipMemcpyAsync(w.h_vec, dx, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(sync_stream());
@@ -816,7 +829,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
         return GOMILP_OK;
     }
     // Dlaswp: b in logical row order
-    for (int i = 0; i < m; i++) x[i] = P.hb[phys[i]];
+    for (int i = 0; i < m; i++) x[i] = rhs[phys[i]];
     // The two Dtrsm of Dgetrs, per row in gonum's order: ascending k, zero multipliers skipped, b_i = (-a_ik)*b_k + b_i
     // as a rounded multiply and a rounded add (level3double.go:75-118).  Only the nd columns whose elimination step did
     // arithmetic carry off-diagonal entries, so a row depends on the solution at those "dense" positions only: they are
@@ -922,6 +935,23 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
 int Engine::solve(int64_t id, double tol, const int64_t *initial_basic, double *opt_f, double *opt_x, int32_t *has_x,
                   int64_t *basis_out, gomilp_lp_stats *stats) {
     std::lock_guard<std::mutex> g(mu_);
+    xchg_timeout_ = false;
+    int rc = solve_locked(id, tol, initial_basic, opt_f, opt_x, has_x, basis_out, stats);
+    if (rc == GOMILP_ERR_DEVICE && xchg_timeout_ && bt_groups_ >= 0) {
+        // The workgroups of the multi-workgroup block kernel wait for each other; when one of them was not resident within the
+        // bounded wait (a crowded device) the launch gives up.  That says nothing about the problem: once more on the
+        // single-workgroup kernels, which depend on nobody.
+        const int64_t keep = bt_groups_;
+        bt_groups_ = -1;
+        rc = solve_locked(id, tol, initial_basic, opt_f, opt_x, has_x, basis_out, stats);
+        bt_groups_ = keep;
+        if (stats) stats->device_retries = 1;
+    }
+    return rc;
+}
+
+int Engine::solve_locked(int64_t id, double tol, const int64_t *initial_basic, double *opt_f, double *opt_x, int32_t *has_x,
+                         int64_t *basis_out, gomilp_lp_stats *stats) {
     const double t0 = now_s();
     gomilp_lp_stats local;
     gomilp_lp_stats *st = stats ? stats : &local;

@@ -37,6 +37,7 @@ struct Problem {
     double *dsign = nullptr;
     int cap_k = 0;
     int64_t root = -1;                          // child: the problem it was assembled from, its branching rows
+    const Problem *root_ptr = nullptr;          //   (the same as a pointer: also set when the root lives in another engine)
     std::vector<int32_t> kvar;
     std::vector<double> ksign;
 };
@@ -46,10 +47,7 @@ class Engine {
     explicit Engine(int device);
     ~Engine();
     int device() const { return device_; }
-    // The persistent loop kernel needs all its workgroups resident (they wait for each other): one per device at a time, a
-    // second concurrent solve of a large LP takes the launch-per-block path
-    static bool loop_slot_acquire_static(int dev);
-    static void loop_slot_release_static(int dev);
+    static std::mutex &loop_mutex(int dev);   // one persistent loop kernel per device at a time (engine_tableau.cpp run_loop_bt)
     int set(const std::string &key, int64_t v);
 
     int64_t upload(const double *c, const double *A, int64_t lda, const double *b, int64_t m, int64_t n);
@@ -61,6 +59,10 @@ class Engine {
     int64_t upload_child_of(Engine &owner, int64_t root, int K, const int32_t *var, const double *sign, const double *rhs);
     int solve(int64_t id, double tol, const int64_t *initial_basic, double *opt_f, double *opt_x, int32_t *has_x,
               int64_t *basis_out, gomilp_lp_stats *stats);
+   private:
+    int solve_locked(int64_t id, double tol, const int64_t *initial_basic, double *opt_f, double *opt_x, int32_t *has_x,
+                     int64_t *basis_out, gomilp_lp_stats *stats);
+   public:
     int64_t last_trace(gomilp_pivot *out, int64_t cap);
 
     // ---- hooks of the device-batched frontier (engine_batch.cpp) ----
@@ -120,7 +122,10 @@ class Engine {
     int refresh_xb_y(const Problem &P, const double *cost);
     int epilogue(const Problem &P, std::vector<int32_t> &basic, std::vector<double> &xb, int loop_rc, double *opt_f, double *opt_x,
                  int32_t *has_x, int64_t *basis_out, gomilp_lp_stats *st);
-    int final_solve(const Problem &P, int ncols_rows, std::vector<double> &xb_exact, bool *singular, const int32_t *basic_host = nullptr);
+    int final_solve(const Problem &P, int ncols_rows, std::vector<double> &xb_exact, bool *singular, const int32_t *basic_host = nullptr,
+                    bool transpose = false, const double *rhs_host = nullptr);
+    // one iteration of the reference on fresh solves (engine_tableau.cpp): the decision a degenerate or tied pivot needs
+    int exact_step(const Problem &P, int phase, double tol, int nn, int *q_out, int *p_out, gomilp_lp_stats *st);
     bool ensure_host_A(const Problem &P);
     // findLinearlyIndependent with the scan on the device (general_kernels.hip) and the last, square step on the host
     int find_independent_device(const Problem &P, std::vector<int32_t> &basic, std::vector<double> *binv_out);
@@ -147,7 +152,10 @@ class Engine {
             bt_nt_ = 0, bt_old_ = 0, bt_stamps_ = 0, bt_upd_valu_ = 0, bt_fault_ = 0, general_device_ = 1, bt_groups_ = 0,   // bt_groups_: -1 never, 0 by shape, 2 / 4 / 8 forced
             bt_lag_ = 1,       // persistent loop kernel where the multi-workgroup block kernel runs (0: block kernel + update launches)
             loop_chunk_ = 512, // pivots per launch of the persistent loop kernel
+            loop_grid_ = 0,    // its workgroups (0: one per CU)
+            exact_degenerate_ = 1,   // 0 never, 1 bases of up to 256 rows, 2 always: pivots whose winning ratio is (nearly) zero are decided on a fresh gonum-order x_B
             cond_guard_ = 1;   // replay the condition guards of the reference on the host for bases of up to 64 rows
+    bool xchg_timeout_ = false;   // the last pivot loop ended in ST_XCHG_TIMEOUT (Engine::solve repeats the solve once)
     bool shadow_trace_ = false;   // this solve records its pivots for the replay even when the caller did not ask for a trace   // developer knobs of the block kernels (per context: tests force the 1024-thread instance)
     // per-solve state
     int cur_ = 0;   // which Binv buffer is current
@@ -204,6 +212,7 @@ void launch_tab_r(const double *T, int ldt, int m, int nn, const double *cost, c
                   double *scratch, double *r, bool tiled, hipStream_t s);
 void launch_tab_row_colmax(const double *T, int ldt, int m, int nn, int row, double *out, bool tiled, hipStream_t s);
 void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb, double *dvec, double *move, bool tiled, hipStream_t s);
+void launch_exact_r(const double *At, int ld, int m, int nn, const int32_t *nonbasic, const double *y, const double *cost, double *r, int ldt, hipStream_t s);
 // general_kernels.hip
 void launch_gs_init(double *QT, int ldq, int m, GsState *st, hipStream_t s);
 void launch_gs_init_perm(double *QT, double *Rinv, int ldq, int m, const int32_t *perm, const double *sgn, const double *beta, int s0, GsState *st, hipStream_t s);

@@ -228,6 +228,8 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         lp.basic = b.d_basic + (size_t)i * b.cap_ldu; lp.nonbasic = b.d_nonbasic + (size_t)i * b.cap_ldt; lp.srcpos = b.d_srcpos + (size_t)i * b.cap_ldt;
         lp.st = b.d_st + i;
         lp.tol_user = tol; lp.kblock = kb; lp.stage = BS_HOST;
+        // degenerate pivots are decided on a fresh gonum-order x_B: such a relaxation is handed to the worker path (ST_NEED_EXACT -> BS_HOST)
+        lp.bt.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && lp.m <= 256)) ? 1e-9 : 0.0;
         if (kb == 16) { lp.bt.groups = grp.groups; lp.bt.group_ri = grp.ri; lp.bt.group_nt = grp.nt; lp.bt.xbuf = b.d_xbuf + (size_t)i * bt_xbuf_doubles(); }
         if (warm) {
             lp.warm = 1; lp.T0 = warm->dT; lp.r0 = warm->dr; lp.xb0 = warm->dxb; lp.basic0 = warm->dbasic; lp.nonbasic0 = warm->dnonbasic;

@@ -204,7 +204,7 @@ void Engine::bt_plan(const Problem &P, int *K, bool *tiled, bool *lag) const {
         *tiled = true;
         // persistent loop kernel (default, btg_kernels.hip k_bt_loop): blocks of 8 pivots, 8 lagging + 8 current terms, the rank-8
         // update of block t applied by the other workgroups of the same launch beside block t+1
-        if (lag && bt_lag_ && block_k_ == 0 && max_pivots_ == 0 && !bt_stamps_ && bt_loop_supported(gc) && loop_slot_acquire_static(device_)) { *lag = true; *K = 8; }
+        if (lag && bt_lag_ && block_k_ == 0 && max_pivots_ == 0 && (!bt_stamps_ || gc.nt == 256) && bt_loop_supported(gc)) { *lag = true; *K = 8; }
         return;
     }
     // block size: 8 when the block's rank-1 terms fit in registers (bt_kernels.hip), else 16
@@ -226,6 +226,8 @@ BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int
     a.stamps = bt_stamps_ ? w.stamps : nullptr;
     a.upd_valu = bt_upd_valu_ ? 1 : 0;
     a.fault = bt_fault_ ? 1 : 0;
+    // degenerate vertices decided on a fresh gonum-order x_B: by default for bases of up to 256 rows
+    a.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && P.m <= 256)) ? 1e-9 : 0.0;
     if (a.tiled && !bt_old_) {
         const BtGroupCfg gc = bt_group_cfg(P.m, ldt_, (int)bt_groups_);
         a.groups = gc.groups; a.group_ri = gc.ri; a.group_nt = gc.nt; a.xbuf = w.xbuf;
@@ -248,6 +250,74 @@ int Engine::bt_forced_pivot(const Problem &P, int phase, double tol, int nn, int
     return GOMILP_OK;
 }
 
+// One iteration of the reference on FRESH solves (simplex.go:233-277), for a pivot the block kernel would not decide on its
+// updated quantities (ST_NEED_EXACT: reduced cost at the stop threshold, tied reduced costs, winning ratio (nearly) zero, tied
+// ratios — the places where the rounding noise of the reference's three LU solves per pivot takes the decision).  Same
+// arithmetic: y from a gonum-order LU of ab^T with right-hand side c_B, r = c_N - an^T y in Dgemv / SubTo order on the device,
+// d and x_B from gonum-order LUs of ab.  Afterwards the fresh r and x_B are resident; returns
+//   0 pivot (q, p) decided — the caller enqueues it as a forced pivot; 1 optimal; 2 unbounded; 3 move[replace] <= 0: the Bland
+//   rule, which the block kernel runs on the fresh r / x_B (exact_once); < 0: -status of a failure.
+int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_out, int *p_out, gomilp_lp_stats *st) {
+    Work &w = *w_;
+    const int m = P.m, n = P.n;
+    std::vector<int32_t> basic(m), nonbasic(nn);
+    {
+        const size_t gap = (size_t)(w.nonbasic - w.basic);   // the two lists share one device block
+        HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (gap + (size_t)nn) * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(sync_stream());
+        for (int i = 0; i < m; i++) basic[i] = w.h_idx[i];
+        for (int j = 0; j < nn; j++) nonbasic[j] = w.h_idx[gap + j];
+    }
+    auto cost = [&](int var) -> double { return phase == 1 ? (var == n ? 1.0 : 0.0) : (var < n ? P.hc[var] : 0.0); };
+    std::vector<double> cb(m), y, xb, dsol, col(m);
+    for (int i = 0; i < m; i++) cb[i] = cost(basic[i]);
+    bool sing = false;
+    int rc;
+    if ((rc = final_solve(P, n, y, &sing, basic.data(), true, cb.data())) != GOMILP_OK) return -rc;
+    if (sing) return -GOMILP_ERR_LINSOLVE;
+    {
+        std::vector<double> ypad(P.ld, 0.0);
+        std::copy(y.begin(), y.begin() + m, ypad.begin());
+        if ((rc = stage_upload(w.dvec, ypad.data(), (size_t)P.ld * sizeof(double))) != GOMILP_OK) return -rc;
+    }
+    launch_exact_r(P.dAt, P.ld, m, nn, w.nonbasic, w.dvec, phase == 1 ? P.dc1 : P.dc, w.R[rcur_], ldt_, stream_);
+    launches_++;
+    std::vector<double> r(nn);
+    HIP_TRY(hipMemcpyAsync(w.h_vec, w.R[rcur_], (size_t)nn * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(sync_stream());
+    for (int j = 0; j < nn; j++) r[j] = w.h_vec[j];
+    // x_B of this iteration (simplex.go:289 of the previous one): resident from here on
+    if ((rc = final_solve(P, n, xb, &sing, basic.data())) != GOMILP_OK) return -rc;
+    if (sing) return -GOMILP_ERR_LINSOLVE;
+    {
+        std::vector<double> xpad(P.ld, 0.0);
+        std::copy(xb.begin(), xb.begin() + m, xpad.begin());
+        if ((rc = stage_upload(w.xb, xpad.data(), (size_t)P.ld * sizeof(double))) != GOMILP_OK) return -rc;
+    }
+    if (st) st->cond_fallbacks++;
+    const int64_t q = min_idx(r.data(), nn);   // simplex.go:247
+    if (r[q] >= -tol) return 1;                // :248
+    // computeMove (:306-342): d = -solve(ab, A[:, entering])
+    HIP_TRY(hipMemcpyAsync(w.h_vec, P.dAt + (size_t)nonbasic[q] * P.ld, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(sync_stream());
+    for (int i = 0; i < m; i++) col[i] = w.h_vec[i];
+    if ((rc = final_solve(P, n, dsol, &sing, basic.data(), false, col.data())) != GOMILP_OK) return -rc;
+    if (sing) return -GOMILP_ERR_LINSOLVE;
+    std::vector<double> move(m);
+    bool anyneg = false;
+    for (int i = 0; i < m; i++) {
+        double d = -dsol[i];
+        if (fabs(d) < 1e-13) d = 0;            // dRoundTol, :321-325
+        if (d < 0) anyneg = true;
+        move[i] = d >= 0 ? std::numeric_limits<double>::infinity() : xb[i] / fabs(d);   // :334-340
+    }
+    if (!anyneg) return 2;                      // :328-330
+    const int64_t p = min_idx(move.data(), m);  // :268
+    if (move[p] <= 0) return 3;                 // :269 -> replaceBland
+    *q_out = (int)q; *p_out = (int)p;
+    return 0;
+}
+
 // Pivot loop: blocks of block_k_ pivots (one single-workgroup launch) followed by one rank-K update launch.
 int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_lp_stats *st) {
     Work &w = *w_;
@@ -255,7 +325,11 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
     hs.done = 0; hs.status = ST_RUNNING; hs.pivots = 0; hs.kdone = 0; hs.bland_steps = 0; hs.lu_singular = 0;
     int K; bool tiled_plan, lag;
     bt_plan(P, &K, &tiled_plan, &lag);
-    struct SlotGuard { bool held; ~SlotGuard() { if (held) Engine::loop_slot_release_static(dev); } int dev; } slot_guard{lag, device_};
+    // The persistent loop kernel needs all its workgroups resident (they wait for each other) and takes one slot on every CU:
+    // one at a time per device.  Concurrent solves of large LPs queue up here for the duration of their pivot loops (set-up and
+    // final solve still overlap); many large LPs at once belong in the device-batched schedule (gomilp_frontier_solve_roots).
+    std::unique_lock<std::mutex> loop_lock;
+    if (lag) loop_lock = std::unique_lock<std::mutex>(loop_mutex(device_));
     bt_layout(P, tiled_plan);
     // persistent loop kernel: DevState::tsel2 hands the buffer that holds the tableau from launch to launch
     hs.tsel2[0] = hs.tsel2[1] = tcur_; hs.kdone2[0] = hs.kdone2[1] = 0; hs.loop_blocks = 0;
@@ -287,6 +361,10 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
         }
     }
     struct ChunkInfo { int64_t before_pred; size_t samp0, nsamp; int64_t nblocks; int par; };
+    int last_slot_enqueued = 0;
+    bool exact_pending = false;   // the next launch starts with a pivot that decides on the r / x_B just refreshed (ST_NEED_EXACT)
+    int forced_q_pending = -1, forced_p_pending = -1;   // ... or with the pivot the host decided on the fresh solves (exact_step)
+    int64_t seg0 = 0;             // pivots when the running segment started
     ChunkInfo info[2];
     size_t samp_total = 0;
     auto enqueue_chunk = [&](int slot, int64_t before_pred, int64_t nblocks) -> int {
@@ -295,17 +373,25 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
         info[slot].nsamp = 0;
         info[slot].nblocks = nblocks;
         info[slot].par = (int)(launch_no & 1);
+        last_slot_enqueued = slot;
         if (lag) {   // the whole chunk is one launch
             BTArgs ai = make_bt_args(P, phase, tol, nn, K);
             ai.loop = 1; ai.nblocks = (int)nblocks; ai.par = (int)(launch_no & 1);
             ai.Tbuf[0] = w.T[0]; ai.Tbuf[1] = w.T[1];
+            ai.exact_once = exact_pending ? 1 : 0; exact_pending = false;
+            ai.forced_q = forced_q_pending; ai.forced_p = forced_p_pending; forced_q_pending = forced_p_pending = -1;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (sampling) {
                 while (w.sample_ev.size() < (samp_total + 1) * 6) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); w.sample_ev.push_back(ev); }
                 e0 = w.sample_ev[samp_total * 6]; e1 = w.sample_ev[samp_total * 6 + 1];
                 samp_total++; info[slot].nsamp++;
             }
-            launch_bt_loop(ai, ncu_, stream_, e0, e1);
+            // workgroups: the 8 G pivot blocks + update workgroups for 256 KB of tableau each, at most one per CU (measured at
+            // 2048 x 2048: 128 workgroups 12.0 ms per solve, 256: 12.4, 512: 13.6; at 4096 x 4096: 256 64.3 ms, 128 68.4 — and a
+            // grid beyond one 512-thread workgroup per CU is not resident as a whole: the launch gives up after its bounded waits)
+            int grid = (int)std::min<int64_t>(ncu_, std::max<int64_t>(64, (int64_t)P.m * ldt_ * 8 / (256 << 10)));
+            if (loop_grid_ > 0) grid = (int)loop_grid_;
+            launch_bt_loop(ai, grid, stream_, e0, e1);
             launch_no++; block_no += nblocks; launches_++;
             HIP_TRY(hipMemcpyAsync(w.pipe_state[slot], w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
             HIP_TRY(hipEventRecord(w.pipe_ev[slot], stream_));
@@ -317,6 +403,8 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
             BTArgs a = make_bt_args(P, phase, tol, nn, kmax);
             a.kmax = K;  // the update kernel is instantiated for the configured block size
             BTArgs ai = a; ai.kmax = kmax;
+            ai.exact_once = exact_pending ? 1 : 0; exact_pending = false;
+            ai.forced_q = forced_q_pending; ai.forced_p = forced_p_pending; forced_q_pending = forced_p_pending = -1;
             const bool sample = sampling && (block_no % std::max<int64_t>(1, sample_events_ / K) == 0);
             hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
             if (sample) {
@@ -334,17 +422,19 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
     };
     int cur = 0, last_par = 0;
     int64_t pred = 0;   // pivots if every enqueued block ran in full
+  restart_segment:
     // small relaxations (B&B children) usually finish Phase I within a handful of pivots: their first chunk is one block
     const int64_t first_blocks = (P.m <= 1024 && !lag) ? 1 : blocks_per_chunk;
-    { int rc0 = enqueue_chunk(0, 0, first_blocks); if (rc0 != GOMILP_OK) return rc0; }
-    pred = first_blocks * K;
-    int64_t seen = 0;   // pivots at the end of the previous inspected chunk
+    cur = 0;
+    { int rc0 = enqueue_chunk(0, seg0, first_blocks); if (rc0 != GOMILP_OK) return rc0; }
+    pred = seg0 + first_blocks * K;
+    int64_t seen = seg0;   // pivots at the end of the previous inspected chunk
     for (;;) {
         // keep one chunk in flight behind the one whose state is awaited (not past a pivot budget)
         // (not behind the very first chunk: short loops — B&B children — usually end inside it, and the speculative
         // chunk would be pure no-op launches)
         const bool more = !(max_pivots_ > 0 && pred >= max_pivots_);
-        const bool speculate = more && seen > 0;
+        const bool speculate = more && seen > seg0;
         if (speculate) { int rc1 = enqueue_chunk(cur ^ 1, pred, blocks_per_chunk); if (rc1 != GOMILP_OK) return rc1; pred += blocks_per_chunk * K; }
         HIP_TRY(hipEventSynchronize(w.pipe_ev[cur]));
         HIP_TRY(hipGetLastError());
@@ -380,8 +470,38 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
         if (hs.status == ST_OPTIMAL) break;
         if (hs.status == ST_UNBOUNDED) { ret = GOMILP_ERR_UNBOUNDED; break; }
         if (hs.status == ST_BLAND_FAILED) { ret = GOMILP_ERR_BLAND; break; }
-        if (hs.status == ST_XCHG_TIMEOUT && w.xbuf)   // records of the abandoned exchange must not meet a later launch
+        if (hs.status == ST_NEED_EXACT) {
+            // The next pivot is degenerate or nearly so.  The reference decides it on the x_B of THIS iteration's fresh LU solve
+            // (simplex.go:289 -> :268-277): the rounding noise of that solve picks the leaving row among the zero-level ones and
+            // says whether the Bland rule takes over.  Same arithmetic here: gonum-order LU of the current basis, its x_B
+            // uploaded, the block kernel decides the first pivot of the next launch on it.
+            if (lag) {
+                tcur_ = hs.tsel2[(last_par ^ 1) & 1];
+                if (launch_no > 0) hipEventSynchronize(w.pipe_ev[(int)(last_slot_enqueued)]);
+            } else HIP_TRY(hipEventSynchronize(w.pipe_ev[last_slot_enqueued]));   // launches enqueued ahead of the news (no-ops)
+            hs.done = 0; hs.status = ST_RUNNING;
+            const DevState keep = hs;   // (final_solve keeps its singular flag in the same block and reads it back)
+            int fq = -1, fp = -1;
+            const int verdict = exact_step(P, phase, tol, nn, &fq, &fp, st);
+            hs = keep;
+            hs.done = 0; hs.status = ST_RUNNING; hs.lu_singular = 0;
+            hs.tsel2[0] = hs.tsel2[1] = tcur_; hs.kdone2[0] = hs.kdone2[1] = 0; hs.loop_blocks = 0;
+            if (verdict < 0) { ret = -verdict; break; }
+            if (verdict == 1) { hs.done = 1; hs.status = ST_OPTIMAL; break; }
+            if (verdict == 2) { ret = GOMILP_ERR_UNBOUNDED; break; }
+            sync_state_to_device();
+            forced_q_pending = fq; forced_p_pending = fp;   // (-1, -1: the Bland rule, run by the block kernel on the fresh r / x_B)
+            exact_pending = true;
+            seg0 = hs.pivots;
+            goto restart_segment;
+        }
+        if (hs.status == ST_XCHG_TIMEOUT && w.xbuf) {   // records of the abandoned exchange must not meet a later launch
+            hipStreamSynchronize(stream_);   // (every workgroup of the abandoned launches has left before the records are cleared)
             hipMemsetAsync(w.xbuf, 0, bt_xbuf_doubles() * sizeof(double), stream_);
+            w.loop_launches = 0;
+            xchg_timeout_ = true;
+        }
+        if (getenv("GOMILP_DEBUG_LOOP")) fprintf(stderr, "run_loop_bt: device status %d after %lld pivots (lag %d, loop_blocks %d)\n", hs.status, (long long)hs.pivots, (int)lag, hs.loop_blocks);
         ret = GOMILP_ERR_DEVICE;
         break;
     }
@@ -389,6 +509,9 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
         // the launch whose state was inspected last left the tableau in the buffer it wrote into tsel2 (launches enqueued
         // behind it are no-ops that pass the choice on)
         tcur_ = hs.tsel2[(last_par ^ 1) & 1];
+        // a launch enqueued ahead of the news (a no-op, but one that wants all its workgroups resident) has to be through
+        // before the next loop kernel of this device may start
+        if (launch_no > 0) hipEventSynchronize(w.pipe_ev[(int)(last_slot_enqueued)]);
     }
     // host clock from the first launch to the arrival of the final state: no extra event / sync per loop (the loop is
     // GPU-bound: the host only waits for chunk states)

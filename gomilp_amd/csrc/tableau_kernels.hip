@@ -387,6 +387,27 @@ void launch_tab_row_colmax(const double *T, int ldt, int m, int nn, int row, dou
     hipLaunchKernelGGL(k_tab_row_colmax, dim3((nn + 255) / 256), dim3(256), 0, s, T, ldt, m, nn, row, out, tiled ? 1 : 0);
 }
 
+// Reduced costs the way the reference forms them every pivot (simplex.go:242-243): data = an^T y by gonum's Dgemv(Trans)
+// (blas/gonum/level2double.go:99-106: for i < m, if y_i != 0: data += y_i * an[i, :], a rounded multiply and a rounded add per
+// element, ascending i), then r = (-1 * data) + cn (floats.SubTo).  One thread per nonbasic position; padding columns get 0.
+__global__ __launch_bounds__(256) void k_exact_r(const double *__restrict__ At, int ld, int m, int nn, const int32_t *__restrict__ nonbasic,
+                                                 const double *__restrict__ y, const double *__restrict__ cost, double *__restrict__ r, int ldt) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ldt) return;
+    if (j >= nn) { r[j] = 0.0; return; }
+    const int var = nonbasic[j];
+    const double *col = At + (size_t)var * ld;
+    double data = 0.0;
+    for (int i = 0; i < m; i++) {
+        const double yi = y[i];
+        if (yi != 0) data = __dadd_rn(__dmul_rn(yi, col[i]), data);
+    }
+    r[j] = __dadd_rn(__dmul_rn(-1.0, data), cost[var]);
+}
+void launch_exact_r(const double *At, int ld, int m, int nn, const int32_t *nonbasic, const double *y, const double *cost, double *r, int ldt, hipStream_t s) {
+    hipLaunchKernelGGL(k_exact_r, dim3((unsigned int)((ldt + 255) / 256)), dim3(256), 0, s, At, ld, m, nn, nonbasic, y, cost, r, ldt);
+}
+
 void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb, double *dvec, double *move, bool tiled, hipStream_t s) {
     hipLaunchKernelGGL(k_tab_column, dim3((m + 255) / 256), dim3(256), 0, s, T, ldt, m, jp, xb, dvec, move, tiled ? 1 : 0);
 }

@@ -65,6 +65,8 @@ typedef struct gomilp_lp_stats {
     int64_t lu_rounds;           /* panel rounds of the compressed LU schedule (0 for the other schedules) */
     int64_t art_exchanges;       /* 1 when a zero-level artificial was exchanged out of the basis after Phase I (simplex.go:581-606) */
     int64_t cond_fallbacks;      /* exact condition-number evaluations made because a cheap guard was near a threshold */
+    int64_t device_retries;      /* 1 when a transient device condition (a workgroup of the multi-workgroup block kernel was not
+                                    resident in time) made the engine repeat the solve on the single-workgroup kernels */
 } gomilp_lp_stats;
 
 /* One record per pivot, execution order (Phase I first).  Same fields as the oracle's trace. */
