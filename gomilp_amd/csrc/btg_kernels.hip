@@ -232,19 +232,42 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
         if (wv == 0) {
             // the workgroup's winner over its NW waves (uniform LDS reads, every lane computes the same): first index among the
             // waves that attain the minimum; lanes 0..7 post {sequence number, value}
-            double fm = redM[0];
-            unsigned int fi = redI[0];
-            double v0 = pay[0][lane < 5 && lane >= 2 ? lane - 2 : 3];
+            double fm, v0;
+            unsigned int fi;
+            if constexpr (LOOP && (NW == 4 || NW == 8)) {
+                // lane w holds wave w's (minimum, first index): two DPP minima inside the first quad / half row instead of a chain
+                // of dependent LDS reads and selects (the serial form cost wave 0 ~1000 cycles per exchange, the others ~240)
+                const double mw = lane < NW ? redM[lane & (NW - 1)] : inf;
+                const double iw = lane < NW ? (double)redI[lane & (NW - 1)] : 4294967295.0;
+                double xm = mw;
+                xm = vmin_f64(xm, dpp_f64<0xB1>(xm));
+                xm = vmin_f64(xm, dpp_f64<0x4E>(xm));
+                if constexpr (NW == 8) xm = vmin_f64(xm, dpp_f64<0x141>(xm));
+                const bool mine = lane < NW && mw == xm;
+                double km = mine ? iw : 4294967295.0;
+                km = vmin_f64(km, dpp_f64<0xB1>(km));
+                km = vmin_f64(km, dpp_f64<0x4E>(km));
+                if constexpr (NW == 8) km = vmin_f64(km, dpp_f64<0x141>(km));
+                const unsigned int mk = (unsigned int)(__ballot(mine && iw == km) & ((1ull << NW) - 1ull));
+                const int ww = mk ? __builtin_ctz(mk) : 0;   // (every minimum NaN: wave 0's entry, as the serial form)
+                fm = readlane_f64(mw, ww);
+                fi = (unsigned int)readlane_f64(iw, ww);
+                v0 = pay[ww][lane < 5 && lane >= 2 ? lane - 2 : 3];
+            } else {
+                fm = redM[0];
+                fi = redI[0];
+                v0 = pay[0][lane < 5 && lane >= 2 ? lane - 2 : 3];
 #pragma unroll
-            for (int w2 = 1; w2 < NW; w2++) {
-                const double mw = redM[w2];
-                const unsigned int iw = redI[w2];
-                const double pw = pay[w2][lane < 5 && lane >= 2 ? lane - 2 : 3];
-                // (value, index) lexicographic; a NaN minimum (index 0xFFFFFFFF) never replaces anything
-                const bool take = (mw < fm) || (mw == fm && iw < fi) || (fm != fm && mw == mw);
-                fm = take ? mw : fm;
-                fi = take ? iw : fi;
-                v0 = take ? pw : v0;
+                for (int w2 = 1; w2 < NW; w2++) {
+                    const double mw = redM[w2];
+                    const unsigned int iw = redI[w2];
+                    const double pw = pay[w2][lane < 5 && lane >= 2 ? lane - 2 : 3];
+                    // (value, index) lexicographic; a NaN minimum (index 0xFFFFFFFF) never replaces anything
+                    const bool take = (mw < fm) || (mw == fm && iw < fi) || (fm != fm && mw == mw);
+                    fm = take ? mw : fm;
+                    fi = take ? iw : fi;
+                    v0 = take ? pw : v0;
+                }
             }
             if (lane < kXSlots) {
                 xpair v;
