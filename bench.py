@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--chunk", type=int, default=64)
     ap.add_argument("--frontier-vars", type=int, default=8, help="C5: 2^k children from the k highest fractional integer vars (0 = skip at N = 1)")
     ap.add_argument("--workers", type=int, default=4, help="worker contexts per GPU (final solves / fall-backs of the batched frontier): 4 measured best — the pivot loops run in ONE batched schedule, and every further spinning host thread only delays it (16 workers: 1 wave in 6 takes 11 ms instead of 6)")
+    ap.add_argument("--frontier-wide-vars", type=int, default=11, help="second frontier line at N = 1: 2^k children (0 = skip)")
+    ap.add_argument("--milp-cpu-nodes", type=int, default=7, help="C3: nodes behind the root that the CPU oracle solves too (baseline + check; 0 = skip)")
     ap.add_argument("--frontier-cpu-children", type=int, default=8, help="children solved on the CPU oracle too (baseline + check)")
     ap.add_argument("--concurrent", type=int, default=4, help="extra figure: independent LPs of the headline shape solved together on one GPU (0 = skip)")
     ap.add_argument("--milp-nodes", type=int, default=127, help="C3: node budget of the host B&B over GPU relaxations (0 = skip)")
@@ -197,14 +199,15 @@ def main() -> int:
     # ------------------------------------------------------------------------------------------------------------------
     # the frontier wave (BASELINE config 5): headline for N > 1, `frontier` object of the N = 1 line
     # ------------------------------------------------------------------------------------------------------------------
-    def frontier_leg(steps, warmup):
+    def frontier_leg(steps, warmup, nvars=None, light=False):
+        nvars = args.frontier_vars if nvars is None else nvars
         m5, seed5 = synth.CONFIGS["C5"]
         c5, A5, b5 = synth.dense_lp_standard_form(m5, seed5)
         mask5 = synth.integrality_mask(m5, m5)
         ctx5 = lp.Context(device=local_rank)
         root5 = ctx5.upload(c5, A5, b5).solve(0.0)          # every rank solves the root (tree.go:72), outside the timing
         ctx5.close()
-        children = synth.frontier_children(root5.x, mask5, args.frontier_vars)
+        children = synth.frontier_children(root5.x, mask5, nvars)
         pool = lp.FrontierPool(device=local_rank, workers=args.workers)   # kernel sampling (HIP events per launch) only in the extra waves below
         pool.set_root(c5, A5, b5)                            # root resident on every GPU before the timed region
         # the incumbent exchange goes through the C-ABI (RCCL), also at N = 1 (a 1-rank communicator)
@@ -225,7 +228,7 @@ def main() -> int:
             return r.status, r.z, r.x, r.has_x
 
         dev = None if comm is None else torch.device("cuda", local_rank)
-        for _ in range(max(6, warmup)):   # first-touch allocations and code loading of every worker end inside the first waves
+        for _ in range(max(2 if light else 6, warmup)):   # first-touch allocations and code loading of every worker end inside the first waves
             wave = fr.solve_wave(solve_shard, children, mask5, rank, world, wave_dist, dev, comm=comm)
         acc = dict(inner=0.0, update=0.0, blocks=0, blocks_sampled=0, batch=0.0, pivots=0, phase1=0, bland=0, fallbacks=0, batched=0)
         per_wave = []
@@ -247,7 +250,7 @@ def main() -> int:
         # kernel durations: two more waves with a HIP event pair around every batched launch (outside the timed region: the
         # event records cost ~10 % of a wave)
         pool.set("sample_batch", 1)
-        for _ in range(2):
+        for _ in range(0 if light else 2):
             fr.solve_wave(solve_shard, children, mask5, rank, world, wave_dist, dev, comm=comm)
             st = holder["stats"]
             acc["inner"] += st["seconds_inner_kernels"]; acc["update"] += st["seconds_update_kernels"]; acc["blocks_sampled"] += st["blocks_sampled"]
@@ -256,7 +259,7 @@ def main() -> int:
                       float(sum(1 for s in wave["status"] if s == lp.OK))])
         # scaling bound: the heaviest child alone through the same batched path (a wave can never be faster than that)
         solo = None
-        if rank == 0:
+        if rank == 0 and not light:
             res_all = pool.solve(children)
             t_best, heavy = 0.0, 0
             for i in [i for i, st_ in enumerate(res_all.status) if st_ == lp.OK]:   # the feasible children are the long ones
@@ -267,14 +270,14 @@ def main() -> int:
                 t1 = time.perf_counter(); r1 = pool.solve([children[heavy]]); t_best = min(t_best, time.perf_counter() - t1)
             solo = {"child": heavy, "pivots": int(r1.stats["pivots_phase1"] + r1.stats["pivots_phase2"]), "bland_steps": int(r1.stats["bland_steps"]),
                     "seconds_alone": t_best}
-        m_c, n_c = m5 + args.frontier_vars, 2 * m5 + args.frontier_vars
+        m_c, n_c = m5 + nvars, 2 * m5 + nvars
         nn_c = n_c - m_c
         alg_bytes = 32.0 * (m_c + nn_c)     # per pivot: column + row of T read, u and v' written (8 B each)
         inner_us = 1e6 * acc["inner"] / max(acc["blocks_sampled"], 1)
         upd_us = 1e6 * acc["update"] / max(acc["blocks_sampled"], 1)
         out = {
             "workload": "C5: %d children of the %dx%d root (seed %d), %d bnb rows each, dealt round-robin over a fixed shuffle to %d rank(s)"
-                        % (len(children), m5, 2 * m5, seed5, args.frontier_vars, world),
+                        % (len(children), m5, 2 * m5, seed5, nvars, world),
             "relaxations_per_s": steps * len(children) / dt, "wave_seconds": dt / steps, "waves_timed": steps, "n_gpus": world,
             "wave_seconds_rank0": per_wave, "pivots_per_wave": int(tot[0] / steps), "phase1_runs_per_wave": int(tot[1] / steps),
             "bland_steps_per_wave": int(tot[2] / steps), "host_fallbacks_per_wave": tot[3] / steps, "device_batched_per_wave": tot[4] / steps,
@@ -296,7 +299,7 @@ def main() -> int:
                         "latency, not bandwidth; achieved = rank 0's pivots x algorithmic bytes per pivot / HIP-event time of its batched inner launches"}
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
         cpu = None
-        if not args.no_cpu_baseline and world == 1 and args.frontier_cpu_children > 0:
+        if not args.no_cpu_baseline and world == 1 and args.frontier_cpu_children > 0 and not light:
             from concurrent.futures import ThreadPoolExecutor
             from oracle import oracle as O   # the checker, timed as the CPU baseline (never the product path)
             O.set_threads(1)
@@ -581,6 +584,11 @@ def main() -> int:
         if fcpu is not None:
             fout["cpu_baseline"] = fcpu
         out["frontier"] = fout
+        if args.frontier_wide_vars > args.frontier_vars:
+            # a frontier wider than one GPU's 256 CUs (2^11 = 2048 children of the same root): where sharding over GPUs can pay
+            wout, wroof, _ = frontier_leg(3, 2, nvars=args.frontier_wide_vars, light=True)
+            out["frontier_wide"] = {k: wout[k] for k in ("workload", "relaxations_per_s", "wave_seconds", "waves_timed", "pivots_per_wave", "feasible_children",
+                                                       "host_fallbacks_per_wave", "device_batched_per_wave", "schedule")}
 
     # ---- BASELINE config 3: host branch-and-bound (tree.go semantics, gomilp_amd/bnb.py) driving GPU relaxations
     if args.milp_nodes > 0:
@@ -598,6 +606,21 @@ def main() -> int:
                           "relaxations": mres.relaxations, "waves": mres.waves, "pivots": mres.pivots, "seconds": tm,
                           "relaxations_per_s": mres.relaxations / tm, "result": mres.error or "optimal",
                           "incumbent_z": None if mres.x is None else mres.z}
+        if not args.no_cpu_baseline and args.milp_cpu_nodes > 0:
+            from oracle import oracle as O   # the checker, timed as the CPU baseline (never the product path)
+            O.set_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
+            tc0 = time.perf_counter()
+            ores = O.solve_milp(c3, None, None, G3, h3, int3, max_nodes=args.milp_cpu_nodes,
+                                simplex_fn=lambda cc, AA, bb: O.simplex(cc, AA, bb, 0.0, None, fast_initial_basis=True))
+            tc = time.perf_counter() - tc0
+            osolved = [nd for nd in ores.nodes if nd.status != -1]
+            gsolved = [nd for nd in mres.nodes if nd.status != -1][: len(osolved)]
+            same = all(g.status == o.status and g.decision == o.decision and (o.status != 0 or (g.z == o.z and np.array_equal(g.x[: len(o.x)], o.x)))
+                       for g, o in zip(gsolved, osolved))
+            out["milp_c3"]["cpu_baseline"] = {"value": len(osolved) / tc, "unit": "relaxations/s", "cores": max(1, min(args.cpu_threads, os.cpu_count() or 1)), "kind": "port",
+                                              "sample": "root + the first %d nodes of the same tree in the reference's FIFO order, one oracle solve after the other "
+                                                        "(LU panels threaded over the host cores), %.1f s wall" % (len(osolved) - 1, tc),
+                                              "gpu_nodes_identical_on_sample": bool(same)}
     emit(out)
     prob.free()
     ctx.close()

@@ -77,7 +77,7 @@ def max_fun_branch_point(c, integrality) -> int:
 
 
 def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int = 8, device: int = -1,
-               warm_start: bool = False, pool=None) -> Result:
+               pool=None) -> Result:
     """milpProblem.solve (ilp.go:75-116) with every relaxation on the GPU.  `max_nodes` stands in for the context
     deadline of the reference (its tree does not terminate on many inputs: SURVEY.md §3.4)."""
     c = np.asarray(c, dtype=np.float64)
@@ -96,9 +96,6 @@ def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int
     if own_pool:
         pool = lp.FrontierPool(device=device, workers=workers)   # (a caller that solves several MILPs keeps one pool)
     pool.set_root(c0, A0, b0)
-    pool.set("warm_start", 0)
-    if warm_start:
-        pool.set("warm_start", 1)   # opt-in: children start from the root's optimal basis (dual simplex), not the reference's path
     r = pool.solve_root(0.0)                             # subproblem.go:172
     root.status, root.z, root.x = r.status, r.z, r.x
     out.relaxations, out.pivots = 1, r.stats["pivots_phase1"] + r.stats["pivots_phase2"]

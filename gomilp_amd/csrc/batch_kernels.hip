@@ -46,38 +46,6 @@ __global__ __launch_bounds__(kBlock) void k_b_setup(BatchLP *__restrict__ lps) {
     __shared__ int s_bad;
     BatchLP &lp = lps[blockIdx.x];
     const int tid = threadIdx.x, m = lp.m, n = lp.n;
-    if (lp.warm) {
-        // ---- warm start: the root's optimal basis + this child's branch slacks (positions m0 .. m0+K-1); x_B of a new row is
-        // rhs - sign * x_var(root optimum): negative exactly where the branch cuts the root's optimum off
-        const int m0 = lp.m0, nn = n - m;
-        for (int i = tid; i < lp.ldu; i += kBlock) {
-            double x = 0.0;
-            if (i < m0) { x = lp.xb0[i]; lp.basic[i] = lp.basic0[i]; }
-            else if (i < m) {
-                const int kk = i - m0, pos = lp.posvar0[lp.var[kk]];
-                x = pos >= 0 ? lp.rhs[kk] - lp.sign[kk] * lp.xb0[pos] : lp.rhs[kk];
-                lp.basic[i] = lp.n0 + kk;
-            }
-            lp.xb[i] = x;
-        }
-        const int ldt = b_ldt(nn);
-        for (int jp = tid; jp < ldt; jp += kBlock) {
-            lp.R[jp] = jp < nn ? lp.r0[jp] : 0.0;
-            if (jp < nn) lp.nonbasic[jp] = lp.nonbasic0[jp];
-        }
-        if (tid == 0) {
-            BTArgs &a = lp.bt;
-            a.m = m; a.ldu = lp.ldu; a.T = lp.T[0]; a.U = lp.U; a.V = lp.V; a.r = lp.R; a.xb = lp.xb;
-            a.basic = lp.basic; a.nonbasic = lp.nonbasic; a.st = lp.st; a.trace = nullptr; a.trace_cap = 0;
-            a.nt_force = 0; a.tiled = 1; a.old_only = 0; a.stamps = nullptr;
-            a.nn = nn; a.ldt = ldt; a.phase = 1; a.tol = 1e-10; a.kmax = lp.kblock;   // dual feasibility restored to 1e-10, like Phase I
-            a.forced_q = a.forced_p = -1; a.forced_nocommit = 0;
-            lp.tcur = 0; lp.do_permute = 0; lp.do_r = 0; lp.wrapped = 0; lp.piv1 = lp.piv2 = lp.bland = 0; lp.status = 0; lp.phase1_used = 0;
-            b_reset_state(lp.st);
-            lp.stage = BS_DUAL;
-        }
-        return;
-    }
     if (tid == 0) s_bad = 0;
     __syncthreads();
     unsigned long long k = ~0ull;
@@ -139,14 +107,6 @@ __global__ __launch_bounds__(kBlock) void k_b_setup(BatchLP *__restrict__ lps) {
 // ---- T[pos, jp] = A'[rho(pos)][var(jp)] in 4x4 tiles, A' = [[A0, 0], [G#, I_K]] never materialised ---------------------
 __device__ __forceinline__ double b_entry(const BatchLP &lp, int pos, int jp, int nn) {
     if (pos >= lp.m || jp >= nn) return 0.0;
-    if (lp.warm) {
-        // rows of the root's final tableau; a branch row on a variable basic at root position i is -sign * (root row i), on a
-        // nonbasic one sign * e_position (x_var = x_B0[i] - T0[i,:] x_N substituted into sign * x_var + s = rhs)
-        if (pos < lp.m0) return lp.T0[tab_idx(pos, jp, lp.ldt0, lp.tiled0)];
-        const int kk = pos - lp.m0, pv = lp.posvar0[lp.var[kk]];
-        if (pv >= 0) return -lp.sign[kk] * lp.T0[tab_idx(pv, jp, lp.ldt0, lp.tiled0)];
-        return (-1 - pv) == jp ? lp.sign[kk] : 0.0;
-    }
     const int r = b_rho(lp, pos);
     const int nn2 = lp.n - lp.m;
     const int j = jp < nn2 ? jp : lp.n;   // slack start: the nonbasic list is 0 .. nn2-1 (+ the artificial)
@@ -296,25 +256,6 @@ __global__ __launch_bounds__(kBlock) void k_b_ctrl(BatchLP *__restrict__ lps, co
             } else {
                 if (tid == 0) { lp.piv1 += st->pivots; lp.bland += st->bland_steps; }
                 to_phase2 = true;
-            }
-        }
-    } else if (stage == BS_DUAL && !st->done && st->pivots > 20ll * m) {
-        if (tid == 0) lp.stage = BS_HOST;   // the dual loop is not converging (degenerate cycling): cold start on the single-relaxation engine
-    } else if (stage == BS_DUAL && st->done) {
-        if (tid == 0) {
-            lp.piv1 += st->pivots;   // dual pivots are reported with the Phase-I pivots
-            const int status = st->status;
-            if (status == ST_OPTIMAL) {
-                // primal feasible and dual feasible: hand over to the primal kernel, which confirms min r >= -tol (or goes on)
-                BTArgs &a = lp.bt;
-                a.phase = 2; a.tol = lp.tol_user; a.kmax = lp.kblock;
-                b_reset_state(st);
-                lp.stage = BS_P2;
-            } else if (status == ST_DUAL_INFEASIBLE) {
-                lp.status = 2;   // lp.ErrInfeasible
-                lp.stage = BS_DONE;
-            } else {
-                lp.stage = BS_HOST;
             }
         }
     } else if (stage == BS_EXCH && st->done) {

@@ -781,7 +781,7 @@ __global__ __launch_bounds__(NT) void k_bt_innerG_batch(const BatchLP *__restric
     if (lpos >= *count) return;
     const BatchLP &lp = lps[ids[lpos]];
     const int stage = lp.stage;
-    if (stage == BS_DONE || stage == BS_HOST || stage == BS_DUAL) return;
+    if (stage == BS_DONE || stage == BS_HOST) return;
     const BTArgs a = lp.bt;
     bt_innerG_body<G, NT, RI, KR, false>(a, (int)(j % G));
 }

@@ -36,8 +36,6 @@ struct gomilp_pool {
     std::vector<int64_t> root;  // root problem id inside each engine
     int64_t m0 = 0, n0 = 0;
     int batched = 1;            // knob: 0 = every relaxation through a worker's single-relaxation engine (round-1 path)
-    int warm_start = 0;         // knob: 1 = children start from the solved root's optimal basis (gomilp_pool_solve_root), dual simplex
-    Engine::RootOpt opt;        // final state of the root after gomilp_pool_solve_root
     std::unique_ptr<BatchEngine> batch;
     std::unique_ptr<BatchEngine> batch2;   // second schedule for waves of large relaxations (created on first use)
     int split_large = 1;        // knob: waves of >= 4 large relaxations run as two interleaved schedules
@@ -82,7 +80,6 @@ struct gomilp_pool {
         cv_idle.wait(lk, [&] { return queue.empty() && busy == 0; });
     }
     ~gomilp_pool() {
-        Engine::free_optimum(&opt);
         { std::lock_guard<std::mutex> lk(mu); stop = true; }
         cv.notify_all();
         for (auto &t : threads) t.join();
@@ -151,7 +148,6 @@ int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value) {
     std::lock_guard<std::mutex> g(pool->call_mu);
     if (std::string(key) == "batched") { pool->batched = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "split_large") { pool->split_large = value ? 1 : 0; return GOMILP_OK; }
-    if (std::string(key) == "warm_start") { pool->warm_start = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "sample_batch") { pool->batch->set_sampling(value != 0); return GOMILP_OK; }
     if (std::string(key) == "exact_degenerate") pool->batch->set_exact_degenerate((int)value);   // (and the workers' engines below)
     int rc = GOMILP_OK;
@@ -165,7 +161,6 @@ int gomilp_pool_set_root(gomilp_pool *pool, const double *c0, const double *A0, 
     std::lock_guard<std::mutex> g(pool->call_mu);
     for (auto id : pool->extra_root) pool->eng[0]->free_problem(id);
     pool->extra_root.clear(); pool->extra_view.clear();
-    Engine::free_optimum(&pool->opt);
     for (size_t w = 0; w < pool->eng.size(); w++) {
         if (pool->root[w] >= 0) pool->eng[w]->free_problem(pool->root[w]);
         int64_t id = pool->eng[w]->upload(c0, A0, lda, b0, m0, n0);
@@ -281,8 +276,7 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
     bool any_p1 = false;
     for (int r = 0; r < nroots && !any_p1; r++) for (double v : views[r]->hb) if (v < -1e-13) { any_p1 = true; break; }
     for (int64_t k = koff[0]; k < koff[count] && !any_p1; k++) if (rhs[k] < -1e-13) any_p1 = true;
-    const Engine::RootOpt *warm = (pool->warm_start && pool->opt.valid && nroots == 1) ? &pool->opt : nullptr;
-    for (int r = 0; r < nroots && use_batch; r++) use_batch = pool->batch->eligible(*views[r], K_max, any_p1 && !warm, warm != nullptr);
+    for (int r = 0; r < nroots && use_batch; r++) use_batch = pool->batch->eligible(*views[r], K_max, any_p1);
     if (use_batch) {
         std::mutex agg_mu;
         auto on_done_at = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) {
@@ -308,7 +302,7 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
         // streams, put one half's updates under the other half's block kernels.
         int m_big = 0, nn_big = 0;
         for (int r = 0; r < nroots; r++) { m_big = std::max(m_big, views[r]->m + K_max); nn_big = std::max(nn_big, views[r]->n - views[r]->m + (any_p1 ? 1 : 0)); }
-        const bool two = pool->split_large && !warm && count >= 4 && gomilp::bt_batch_k(m_big, gomilp::batch_ldt(nn_big)) == 16;
+        const bool two = pool->split_large && count >= 4 && gomilp::bt_batch_k(m_big, gomilp::batch_ldt(nn_big)) == 16;
         int rc;
         if (two) {
             if (!pool->batch2) pool->batch2.reset(new BatchEngine(pool->device));
@@ -318,15 +312,15 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
             auto on_done2 = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) { on_done_at(i + half, o, basic, xb); };
             std::thread t2([&] {
                 hipSetDevice(pool->device);
-                rc2 = pool->batch2->run_roots(views.data(), nroots, root_of ? root_of + half : nullptr, count - half, koff + half, var, sign, rhs, tol, on_done2, &bs2, nullptr);
+                rc2 = pool->batch2->run_roots(views.data(), nroots, root_of ? root_of + half : nullptr, count - half, koff + half, var, sign, rhs, tol, on_done2, &bs2);
             });
-            rc = pool->batch->run_roots(views.data(), nroots, root_of, half, koff, var, sign, rhs, tol, on_done, &bs, nullptr);
+            rc = pool->batch->run_roots(views.data(), nroots, root_of, half, koff, var, sign, rhs, tol, on_done, &bs);
             t2.join();
             if (rc == GOMILP_OK) rc = rc2;
             bs.launches += bs2.launches; bs.supersteps += bs2.supersteps; bs.blocks += bs2.blocks; bs.blocks_sampled += bs2.blocks_sampled;
             bs.seconds_inner += bs2.seconds_inner; bs.seconds_update += bs2.seconds_update; bs.seconds_total = std::max(bs.seconds_total, bs2.seconds_total);
         } else {
-            rc = pool->batch->run_roots(views.data(), nroots, root_of, count, koff, var, sign, rhs, tol, on_done, &bs, warm);
+            rc = pool->batch->run_roots(views.data(), nroots, root_of, count, koff, var, sign, rhs, tol, on_done, &bs);
         }
         pool->drain();
         if (rc != GOMILP_OK) return rc;
@@ -358,15 +352,11 @@ int gomilp_frontier_solve(gomilp_pool *pool, int64_t count, const int64_t *koff,
     return gomilp_frontier_solve_roots(pool, count, nullptr, koff, var, sign, rhs, tol, z_out, x_out, pool->n0, status_out, has_x_out, stats);
 }
 
-// The root relaxation (subproblem.go:172) on the pool's first worker; its final tableau, reduced costs, x_B and lists are
-// kept as the warm-start point of the children (used when the knob "warm_start" is 1).
+// The root relaxation (subproblem.go:172) on the pool's first worker.
 int gomilp_pool_solve_root(gomilp_pool *pool, double tol, double *opt_f, double *opt_x, int32_t *has_x, gomilp_lp_stats *stats) {
     if (!pool || pool->root[0] < 0) return GOMILP_ERR_BAD_SHAPE;
     std::lock_guard<std::mutex> g(pool->call_mu);
-    Engine::free_optimum(&pool->opt);
-    const int rc = pool->eng[0]->solve(pool->root[0], tol, nullptr, opt_f, opt_x, has_x, nullptr, stats);
-    if (rc == GOMILP_OK) pool->eng[0]->export_optimum(pool->root[0], &pool->opt);   // (not valid on another pipeline: the children start cold)
-    return rc;
+    return pool->eng[0]->solve(pool->root[0], tol, nullptr, opt_f, opt_x, has_x, nullptr, stats);
 }
 
 int gomilp_pool_add_root(gomilp_pool *pool, const double *c, const double *A, int64_t lda, const double *b, int64_t m, int64_t n) {

@@ -15,9 +15,8 @@ enum : int32_t {
     ST_BLAND_FAILED = 6,  // replaceBland exhausted its candidates (lp.ErrBland, simplex.go:382)
     ST_FORCED_DONE = 7,   // a set-up pivot ordered with forced_nocommit = 3 has run: later launches of the superstep are no-ops
     ST_XCHG_TIMEOUT = 9,    // multi-workgroup block kernel (btg_kernels.hip): an exchange saw no progress (a workgroup never ran)
-    ST_NEED_EXACT = 10,     // the winning ratio is within BTArgs::guard of zero: the host refreshes x_B with a gonum-order solve of the
+    ST_NEED_EXACT = 10      // the winning ratio is within BTArgs::guard of zero: the host refreshes x_B with a gonum-order solve of the
                             // current basis before the decision is taken (simplex.go:268-277 sees a fresh x_B every pivot)
-    ST_DUAL_INFEASIBLE = 8  // dual simplex (warm start): a row with x_B < 0 has no negative entry: the relaxation is infeasible
 };
 
 constexpr int kMaxPartials = 1024;  // per-workgroup partial arg-reductions (grid <= 1024 workgroups)
@@ -165,7 +164,6 @@ enum : int32_t {
     BS_P2_START = 1,  // slack basis feasible: Phase II starts after the reduced costs are built
     BS_P1 = 2,        // Phase-I loop running
     BS_P2 = 3,        // Phase-II loop running
-    BS_DUAL = 7,      // warm start: dual simplex from the root's optimal basis + the child's branch slacks
     BS_EXCH = 6,      // the zero-level artificial is being exchanged out of the basis (one forced pivot, simplex.go:581-606)
     BS_DONE = 4,      // terminal: `status` holds the outcome (GOMILP_OK = basis + x_B ready for the final gonum-order solve)
     BS_HOST = 5       // terminal: a path the device schedule does not cover (artificial exchange, guard band, ...): the
@@ -187,12 +185,6 @@ struct BatchLP {
     double *R, *xb, *U, *V, *scratch, *art;
     int32_t *basic, *nonbasic, *srcpos;
     DevState *st;
-    // warm start (opt-in): the solved root's final state, read in place
-    const double *T0;        // m0 x ldt0 final tableau of the root (layout tiled0), column j = nonbasic position j
-    const double *r0, *xb0;  // its reduced costs by position (>= -tol), its x_B by position
-    const int32_t *basic0, *nonbasic0;   // its positional index lists
-    const int32_t *posvar0;  // n0 : variable id -> basis position (>= 0) or -1 - nonbasic position
-    int32_t ldt0, tiled0, warm, pad1;
     double tol_user;         // Phase-II tolerance of the call (GoMILP: 0)
     int32_t stage;           // BS_*
     int32_t tcur;            // index of the current T buffer

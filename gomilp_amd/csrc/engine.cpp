@@ -971,7 +971,6 @@ int Engine::solve_locked(int64_t id, double tol, const int64_t *initial_basic, d
         return code;
     };
     launches_ = 0;
-    last_solved_ = -1;
     fs_device_ = fs_host_ = 0;
     last_trace_.clear();
     last_trace_total_ = 0;
@@ -1260,7 +1259,6 @@ int Engine::solve_locked(int64_t id, double tol, const int64_t *initial_basic, d
     if (loop_unbounded) { *opt_f = -inf; return finish(loop_rc); }
     rc = epilogue(P, basic, xb, loop_rc, opt_f, opt_x, has_x, basis_out, st);
     if (rc == GOMILP_ERR_DEVICE) return finish(rc);
-    if (rc == GOMILP_OK && use_tab && use_bt_) { last_solved_ = id; last_nn_ = n - m; }
     if (trace_on_) {
         HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(sync_stream());
@@ -1321,37 +1319,6 @@ bool Engine::root_view(int64_t id, RootView *out) {
         out->rho0[pos] = P.lastrow[j]; used[P.lastrow[j]] = 1;
     }
     return true;
-}
-
-void Engine::free_optimum(RootOpt *o) {
-    for (void *p : {(void *)o->dT, (void *)o->dr, (void *)o->dxb, (void *)o->dbasic, (void *)o->dnonbasic, (void *)o->dposvar}) if (p) hipFree(p);
-    *o = RootOpt();
-}
-
-int Engine::export_optimum(int64_t id, RootOpt *out) {
-    std::lock_guard<std::mutex> g(mu_);
-    if (!out || id != last_solved_ || id < 0 || (size_t)id >= problems_.size() || !problems_[id]) return GOMILP_ERR_BAD_SHAPE;
-    const Problem &P = *problems_[id];
-    Work &w = *w_;
-    const int m = P.m, n = P.n, nn = last_nn_;
-    free_optimum(out);
-    const size_t nT = (size_t)((m + 3) & ~3) * ldt_;
-    HIP_TRY(dmalloc(&out->dT, nT)); HIP_TRY(dmalloc(&out->dr, (size_t)ldt_)); HIP_TRY(dmalloc(&out->dxb, (size_t)P.ld));
-    HIP_TRY(dmalloc(&out->dbasic, (size_t)m)); HIP_TRY(dmalloc(&out->dnonbasic, (size_t)nn)); HIP_TRY(dmalloc(&out->dposvar, (size_t)n));
-    HIP_TRY(hipMemcpyAsync(out->dT, w.T[tcur_], nT * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-    HIP_TRY(hipMemcpyAsync(out->dr, w.R[rcur_], (size_t)ldt_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-    HIP_TRY(hipMemcpyAsync(out->dxb, w.xb, (size_t)P.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-    HIP_TRY(hipMemcpyAsync(out->dbasic, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToDevice, stream_));
-    HIP_TRY(hipMemcpyAsync(out->dnonbasic, w.nonbasic, (size_t)nn * sizeof(int32_t), hipMemcpyDeviceToDevice, stream_));
-    std::vector<int32_t> hb(m), hn(nn), pv(n, -1);
-    HIP_TRY(hipMemcpyAsync(hb.data(), w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipMemcpyAsync(hn.data(), w.nonbasic, (size_t)nn * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(sync_stream());
-    for (int i = 0; i < m; i++) { if (hb[i] < 0 || hb[i] >= n) return GOMILP_ERR_DEVICE; pv[hb[i]] = i; }
-    for (int jp = 0; jp < nn; jp++) { if (hn[jp] < 0 || hn[jp] >= n) return GOMILP_ERR_DEVICE; pv[hn[jp]] = -1 - jp; }
-    HIP_TRY(hipMemcpy(out->dposvar, pv.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
-    out->ldt = ldt_; out->tiled = t_tiled_ ? 1 : 0; out->m = m; out->n = n; out->valid = true;
-    return GOMILP_OK;
 }
 
 int Engine::finish_from_basis(int64_t id, const int32_t *basic_in, const double *xb_updated, int loop_rc, double *opt_f,

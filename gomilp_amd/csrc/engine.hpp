@@ -77,17 +77,6 @@ class Engine {
         std::vector<double> hb, hc;       // host copies of b and c (final solves on another engine's behalf)
     };
     bool root_view(int64_t id, RootView *out);
-    // final state of the LAST solve on this engine (must be `id`, solved to optimality on the blocked tableau pipeline):
-    // tableau, reduced costs, x_B and the positional lists are copied into buffers the caller owns (free_optimum) — the
-    // starting point of warm-started children (engine_batch.cpp)
-    struct RootOpt {
-        double *dT = nullptr, *dr = nullptr, *dxb = nullptr;
-        int32_t *dbasic = nullptr, *dnonbasic = nullptr, *dposvar = nullptr;
-        int ldt = 0, tiled = 0, m = 0, n = 0;
-        bool valid = false;
-    };
-    int export_optimum(int64_t id, RootOpt *out);
-    static void free_optimum(RootOpt *o);
     // epilogue of simplex() (simplex.go:296-301) for a relaxation whose pivot loop ran elsewhere: final basis positions
     // `basic` (m entries) and updated x_B in, gonum-order solve of that basis, z, x out; `loop_rc` as Engine::solve
     int finish_from_basis(int64_t id, const int32_t *basic, const double *xb_updated, int loop_rc, double *opt_f, double *opt_x,
@@ -165,8 +154,6 @@ class Engine {
     bool t_tiled_ = false;   // layout of T[tcur_]: 4x4 tiles (blocked pipeline, register-resident kernel) or row-major
     bool use_bt_ = false;  // blocked tableau (deferred rank-K updates) instead of one launch per pivot  // tableau pipeline: current T / r buffer, row length of T  // workgroups of the last ratio-test kernel (partials to reduce)
     int64_t launches_ = 0;
-    int64_t last_solved_ = -1;   // problem of the last solve that ended at an optimum on the blocked tableau pipeline (-1: none)
-    int last_nn_ = 0;
     double fs_device_ = 0, fs_host_ = 0;
     int64_t lu_dense_ = 0, lu_rounds_ = 0;
     std::vector<gomilp_pivot> last_trace_;
@@ -241,7 +228,6 @@ int bt_batch_k(int m_max, int ldt_max);
 void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void launch_bt_update_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 const char *bt_batch_kernel_name(int m_max, int ldt_max);
-void launch_bt_inner_dual_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s);
 // batch_kernels.hip
 int batch_ldt(int nn);
 void launch_b_setup(BatchLP *lps, int nlp, hipStream_t s);

@@ -89,13 +89,12 @@ BatchEngine::~BatchEngine() {
     if (copy_stream_) hipStreamDestroy(copy_stream_);
 }
 
-bool BatchEngine::eligible(const Engine::RootView &R, int K_max, bool phase1, bool warm) const {
+bool BatchEngine::eligible(const Engine::RootView &R, int K_max, bool phase1) const {
     if (R.verify_status != GOMILP_OK || !R.unit_basis) return false;
     const int m = R.m + K_max, n = R.n + K_max;
     if (m >= n || !((n - m) < 2 * m)) return false;              // the tableau formulation (engine.cpp: use_tab)
     if (n + 2 > 8000) return false;                              // k_b_ctrl keeps two int lists of n in (default-limit) LDS
     const int ldt1 = batch_ldt(n - m + (phase1 ? 1 : 0));
-    if (warm && bt_batch_k(m, ldt1) != 8) return false;          // the dual-simplex block kernel exists in the single-workgroup form only
     return bt_batch_supported(m, ldt1);
 }
 
@@ -155,9 +154,7 @@ int BatchEngine::ensure(int nlp, int m_max, int n_max, int ldt1, int64_t ktot) {
 }
 
 int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, const int32_t *root_of, int64_t count, const int64_t *koff,
-                           const int32_t *var, const double *sign, const double *rhs, double tol, const DoneFn &on_done, Stats *stats,
-                           const Engine::RootOpt *warm) {
-    if (warm && !(warm->valid && nroots == 1 && warm->m == roots[0]->m && warm->n == roots[0]->n)) warm = nullptr;
+                           const int32_t *var, const double *sign, const double *rhs, double tol, const DoneFn &on_done, Stats *stats) {
     const double t0 = bnow();
     Stats local;
     Stats &S = stats ? *stats : local;
@@ -173,10 +170,8 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         const int K = (int)(koff[i + 1] - koff[i]);
         m_max = std::max(m_max, Ri.m + K); n_max = std::max(n_max, Ri.n + K);
         bool p1 = false;   // does this relaxation start infeasible?  (initPosTol; the set-up kernel decides the same way)
-        if (!warm) {       // (a warm start has no Phase I)
-            for (double v : Ri.hb) if (v < -1e-13) { p1 = true; break; }
-            for (int64_t k = koff[i]; k < koff[i + 1] && !p1; k++) if (rhs[k] < -1e-13) p1 = true;
-        }
+        for (double v : Ri.hb) if (v < -1e-13) { p1 = true; break; }
+        for (int64_t k = koff[i]; k < koff[i + 1] && !p1; k++) if (rhs[k] < -1e-13) p1 = true;
         ldt1 = std::max(ldt1, batch_ldt(Ri.n - Ri.m + (p1 ? 1 : 0)));   // Phase-I tableau: one column more (the artificial)
     }
     const int64_t ktot = koff[nlp] - koff[0];
@@ -231,10 +226,6 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         // degenerate pivots are decided on a fresh gonum-order x_B: such a relaxation is handed to the worker path (ST_NEED_EXACT -> BS_HOST)
         lp.bt.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && lp.m <= 256)) ? 1e-9 : 0.0;
         if (kb == 16) { lp.bt.groups = grp.groups; lp.bt.group_ri = grp.ri; lp.bt.group_nt = grp.nt; lp.bt.xbuf = b.d_xbuf + (size_t)i * bt_xbuf_doubles(); }
-        if (warm) {
-            lp.warm = 1; lp.T0 = warm->dT; lp.r0 = warm->dr; lp.xb0 = warm->dxb; lp.basic0 = warm->dbasic; lp.nonbasic0 = warm->dnonbasic;
-            lp.posvar0 = warm->dposvar; lp.ldt0 = warm->ldt; lp.tiled0 = warm->tiled;
-        }
     }
     B_TRY(hipMemsetAsync(b.d_active, 0, kMaxSteps * sizeof(int), stream_));
     B_TRY(hipMemsetAsync(b.d_out, 0, (size_t)nlp * sizeof(BatchOut), stream_));   // stage 0 = not terminal
@@ -265,11 +256,10 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
                 while (b.samp_ev.size() < (size_t)(nsamp + 1) * 4) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) break; b.samp_ev.push_back(ev); }
                 if (b.samp_ev.size() >= (size_t)(nsamp + 1) * 4) { for (int q = 0; q < 4; q++) e[q] = b.samp_ev[(size_t)nsamp * 4 + q]; nsamp++; }
             }
-            if (warm) launch_bt_inner_dual_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_);
             launch_bt_inner_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_, e[0], e[1]);
             launch_bt_update_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_, e[2], e[3]);
         }
-        S.launches += (warm ? 3 : 2) * nb; S.blocks += nb;
+        S.launches += 2 * nb; S.blocks += nb;
     };
     // the control step of superstep `step` visits the relaxations of the previous active list and leaves the next one
     auto control = [&](bool permute) {

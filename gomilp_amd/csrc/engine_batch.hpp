@@ -35,7 +35,7 @@ class BatchEngine {
     ~BatchEngine();
     // can children of this root with up to K_max branch rows take the batched path?
     // (phase1: some relaxation of the wave starts infeasible — the Phase-I tableau is one column wider)
-    bool eligible(const Engine::RootView &R, int K_max, bool phase1, bool warm = false) const;
+    bool eligible(const Engine::RootView &R, int K_max, bool phase1) const;
     int run(const Engine::RootView &R, int64_t count, const int64_t *koff, const int32_t *var, const double *sign,
             const double *rhs, double tol, const DoneFn &on_done, Stats *stats) {
         const Engine::RootView *one = &R;
@@ -43,11 +43,8 @@ class BatchEngine {
     }
     // relaxation i is a child (K_i >= 0 rows) of roots[root_of[i]] (root_of == nullptr: all of roots[0]); the wave is
     // ONE batch: independent LPs of similar shape are children with K = 0 of different roots
-    // warm (nullable, root 0 only): every relaxation starts from the solved root's optimal basis + its own branch slacks and
-    // runs the dual simplex first (opt-in: the pivot path is not the reference's)
     int run_roots(const Engine::RootView *const *roots, int nroots, const int32_t *root_of, int64_t count, const int64_t *koff,
-                  const int32_t *var, const double *sign, const double *rhs, double tol, const DoneFn &on_done, Stats *stats,
-                  const Engine::RootOpt *warm = nullptr);
+                  const int32_t *var, const double *sign, const double *rhs, double tol, const DoneFn &on_done, Stats *stats);
 
    private:
     struct Buf;

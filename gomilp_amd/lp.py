@@ -303,8 +303,7 @@ class FrontierPool:
         self._widths = [n0]
 
     def solve_root(self, tol: float = 0.0) -> LPResult:
-        """The root relaxation on the pool's first worker; keeps its optimal tableau as the warm-start point
-        (used by solve() when the pool knob warm_start is 1)."""
+        """The root relaxation (subproblem.go:172) on the pool's first worker."""
         x = np.zeros(self.n0)
         z = C.c_double(math.nan)
         has_x = C.c_int32(0)

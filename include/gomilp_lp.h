@@ -89,7 +89,8 @@ typedef struct gomilp_pivot {
  * basis_out (nullable, length m) receives the final basicIdxs in positional order.
  * initial_basic (nullable, exactly m entries; GoMILP passes nil): a supplied feasible basis skips Phase I
  * (simplex.go:147-160); an index out of range, a singular or an infeasible set return GOMILP_ERR_PANIC (the
- * reference panics); supported for m <= 512 (GOMILP_ERR_UNSUPPORTED above), like any non-slack starting basis.
+ * reference panics); like any non-slack starting basis it needs the host copy of A, kept for m * n <= 2^25
+ * (GOMILP_ERR_UNSUPPORTED above): the column search runs on the device from 224 rows on.
  * ---------------------------------------------------------------------------------------- */
 int gomilp_lp_simplex(const double *c, const double *A, int64_t lda, const double *b, int64_t m, int64_t n,
                       double tol, const int64_t *initial_basic, double *opt_f, double *opt_x, int32_t *has_x,
@@ -200,11 +201,10 @@ int gomilp_incumbent_allreduce(gomilp_comm *comm, double local_z, int64_t local_
 /* the host logic of the exchange (no GPU): lexicographic minimum of a table of `world` (z, index) pairs, +Inf = none */
 void gomilp_incumbent_pick(const double *table, int world, double *global_z, int64_t *global_index);
 
-/* Warm start (opt-in; the reference's hook is initialBasic, simplex.go:147-161, its README lists "initiate the
- * simplex at solution of parent?" as a TODO): gomilp_pool_solve_root solves the root relaxation (subproblem.go:172) and keeps its
- * optimal tableau resident; with gomilp_pool_set(pool, "warm_start", 1) every child of that root then starts from the root's
- * optimal basis + its own branch slacks and restores feasibility with the dual simplex (a few pivots instead of a Phase I).
- * This mode does not follow the reference's pivot path: z and every branching decision agree, x / z bits need not. */
+/* The root relaxation (subproblem.go:172) on the pool's first worker.  (A warm start of the children from the root's optimal
+ * tableau — SURVEY.md §8f-1; the reference's hook would be initialBasic, simplex.go:147-161 — was built in round 2 and withdrawn
+ * in round 3: on the benchmark frontier the reference's cold Phase I proves a cut-off child infeasible in ~7 pivots where the
+ * dual simplex from the root's optimum needed hundreds) */
 int gomilp_pool_solve_root(gomilp_pool *pool, double tol, double *opt_f, double *opt_x, int32_t *has_x, gomilp_lp_stats *stats);
 
 /* Several roots in one pool: relaxation i of a wave is a child (K_i >= 0 rows) of root root_of[i]; index 0 is the root of
