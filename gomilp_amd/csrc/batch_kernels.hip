@@ -53,7 +53,20 @@ __global__ __launch_bounds__(kBlock) void k_b_setup(BatchLP *__restrict__ lps) {
     int bad = 0;
     for (int pos = tid; pos < lp.ldu; pos += kBlock) {
         double x = 0.0;
-        if (pos < m) {
+        if (pos < m && lp.gen) {
+            // basis of the child = its K branch slacks (the descending scan of findLinearlyIndependent meets them first:
+            // positions 0 .. K-1, slack of branch row K-1-pos) + the root's initial basis; B'^-1 b' by block elimination
+            if (pos < lp.K) {
+                const int kk = lp.K - 1 - pos, pv = lp.gposvar0[lp.var[kk]];
+                x = lp.rhs[kk] - lp.sign[kk] * (pv >= 0 ? lp.gxb0[pv] : 0.0);
+                lp.basic[pos] = lp.n0 + kk;
+            } else {
+                x = lp.gxb0[pos - lp.K];
+                lp.basic[pos] = lp.gbasic0[pos - lp.K];
+            }
+            amin_take(k, idx, ordkey(x), (unsigned int)pos);
+            if (x < -1e-13) bad = 1;
+        } else if (pos < m) {
             x = b_rhs(lp, b_rho(lp, pos));   // ab = permutation: x_B = ab^-1 b exactly (initializeFromBasic, simplex.go:447-471)
             lp.basic[pos] = n - 1 - pos;      // descending scan of findLinearlyIndependent (simplex.go:618-635)
             amin_take(k, idx, ordkey(x), (unsigned int)pos);
@@ -66,9 +79,19 @@ __global__ __launch_bounds__(kBlock) void k_b_setup(BatchLP *__restrict__ lps) {
     const int infeasible = s_bad;
     const int minidx = idx == 0xFFFFFFFFu ? 0 : (int)idx;
     const int nn2 = n - m;
-    for (int jp = tid; jp < nn2; jp += kBlock) lp.nonbasic[jp] = jp;   // ascending ids not in the basis (simplex.go:174-184)
+    for (int jp = tid; jp < nn2; jp += kBlock) lp.nonbasic[jp] = lp.gen ? lp.gnonbasic0[jp] : jp;   // ascending ids not in the basis (simplex.go:174-184)
     int art_zero = 0;
-    if (infeasible) {
+    if (infeasible && lp.gen) {
+        // the artificial column in tableau space, by basis POSITION: B^-1 (b - sum_{i != minidx} a_basic_i) = x_B - 1 + e_minidx
+        int nz = 0;
+        for (int pos = tid; pos < lp.ldu; pos += kBlock) {
+            double v = 0.0;
+            if (pos < m) v = (pos == minidx) ? lp.xb[pos] : lp.xb[pos] - 1.0;
+            lp.art[pos] = v;
+            if (v != 0) nz = 1;
+        }
+        art_zero = !__syncthreads_or(nz);
+    } else if (infeasible) {
         // a_{n+1} = b - sum_{i != minidx} a_{basic_i}: unit columns, one exact "- 1" per row (floats.Sub, simplex.go:536-542)
         const int rmin = b_rho(lp, minidx);
         int nz = 0;
@@ -107,6 +130,15 @@ __global__ __launch_bounds__(kBlock) void k_b_setup(BatchLP *__restrict__ lps) {
 // ---- T[pos, jp] = A'[rho(pos)][var(jp)] in 4x4 tiles, A' = [[A0, 0], [G#, I_K]] never materialised ---------------------
 __device__ __forceinline__ double b_entry(const BatchLP &lp, int pos, int jp, int nn) {
     if (pos >= lp.m || jp >= nn) return 0.0;
+    if (lp.gen) {
+        const int nn0 = lp.n0 - lp.m0;
+        if (jp >= nn0) return lp.art[pos];   // the artificial (tableau space, by position: k_b_setup)
+        if (pos >= lp.K) return lp.gT0[(size_t)(pos - lp.K) * lp.gldt + jp];
+        // branch row kk: sign * x_var + s = rhs with x_var = x_B0[pv] - T0[pv, :] x_N (var basic at pv) or the nonbasic variable itself
+        const int kk = lp.K - 1 - pos, pv = lp.gposvar0[lp.var[kk]];
+        if (pv >= 0) return -lp.sign[kk] * lp.gT0[(size_t)pv * lp.gldt + jp];
+        return (-1 - pv) == jp ? lp.sign[kk] : 0.0;
+    }
     const int r = b_rho(lp, pos);
     const int nn2 = lp.n - lp.m;
     const int j = jp < nn2 ? jp : lp.n;   // slack start: the nonbasic list is 0 .. nn2-1 (+ the artificial)

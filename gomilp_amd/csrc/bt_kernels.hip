@@ -565,7 +565,10 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
                     const double y2 = lane < NW ? red2[lane] : inf;
                     const double r2 = readlane_f64(row_min_f64(y2), 15);
                     const double rq0 = rq;   // (uniform)
-                    if (fabs(rq0 + a.tol) <= a.guard || r2 - rq0 <= a.guard * fmax(1.0, fabs(rq0))) { status = ST_NEED_EXACT; break; }
+                    // at the stop threshold itself only the drift of the updated reduced costs matters (1e-12; a Phase-I optimum has
+                    // many reduced costs at zero, 1e-10 above its threshold: nothing to re-decide there); a tie matters only when
+                    // the loop goes on
+                    if (fabs(rq0 + a.tol) <= 1e-12 || (!(rq0 >= -a.tol) && r2 - rq0 <= a.guard * fmax(1.0, fabs(rq0)))) { status = ST_NEED_EXACT; break; }
                 }
             }
             q = (int)fq.i;
@@ -593,7 +596,9 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
             const double mv = w.m;
             if (mv == inf || w.i >= (unsigned int)a.m) { status = ST_UNBOUNDED; break; }  // simplex.go:328-330
             // degenerate (or nearly), or two rows within 1e-9 of each other: decided on a fresh gonum-order x_B (DevTypes: BTArgs::guard)
-            if (a.guard > 0 && !(k == 0 && a.exact_once) && (mv <= a.guard || mv2 - mv <= a.guard * fmax(1.0, fabs(mv)))) { status = ST_NEED_EXACT; break; }
+            // (a winning pivot element below the guard too: the updated tableau drifts by ~1e-12 on nearly dependent rows, where the fresh
+            // column has an exact zero that the reference's 1e-13 rounding removes from the test — pivoting there gave singular bases)
+            if (a.guard > 0 && !(k == 0 && a.exact_once) && (mv <= a.guard || mv2 - mv <= a.guard * fmax(1.0, fabs(mv)) || fabs(dpv) <= a.guard)) { status = ST_NEED_EXACT; break; }
             if (mv <= 0) {
                 // ---- replaceBland (simplex.go:347-383): candidates in position order with r_i <= -1e-14 after the
                 // 1e-13 rounding of :252-256; the mat.Cond guard of :377 is replaced by |d| >= 1e-13

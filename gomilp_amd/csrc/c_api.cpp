@@ -169,6 +169,7 @@ int gomilp_pool_set_root(gomilp_pool *pool, const double *c0, const double *A0, 
     }
     pool->m0 = m0; pool->n0 = n0;
     if (!pool->eng[0]->root_view(pool->root[0], &pool->view)) return GOMILP_ERR_DEVICE;
+    if (!pool->view.unit_basis && pool->view.verify_status == GOMILP_OK) pool->eng[0]->root_general(pool->root[0], &pool->view);   // equality rows: one column search per root
     // first-touch allocations of every worker (work buffers, child slot, final-solve workspace) happen here, not inside the
     // first waves: each worker finishes one dummy child (8 slack rows x_0 <= 1e30) from its slack basis
     if (pool->view.unit_basis && pool->view.verify_status == GOMILP_OK) {
@@ -274,7 +275,10 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
     BatchEngine::Stats bs;
     bool use_batch = pool->batched && count > 0;
     bool any_p1 = false;
-    for (int r = 0; r < nroots && !any_p1; r++) for (double v : views[r]->hb) if (v < -1e-13) { any_p1 = true; break; }
+    for (int r = 0; r < nroots && !any_p1; r++) {
+        if (views[r]->gen && !views[r]->unit_basis) any_p1 = true;
+        for (double v : views[r]->hb) if (v < -1e-13) { any_p1 = true; break; }
+    }
     for (int64_t k = koff[0]; k < koff[count] && !any_p1; k++) if (rhs[k] < -1e-13) any_p1 = true;
     for (int r = 0; r < nroots && use_batch; r++) use_batch = pool->batch->eligible(*views[r], K_max, any_p1);
     if (use_batch) {
@@ -367,6 +371,7 @@ int gomilp_pool_add_root(gomilp_pool *pool, const double *c, const double *A, in
     if (id < 0) return (int)id;
     std::unique_ptr<Engine::RootView> v(new Engine::RootView);
     if (!pool->eng[0]->root_view(id, v.get())) return -GOMILP_ERR_DEVICE;
+    if (!v->unit_basis && v->verify_status == GOMILP_OK) pool->eng[0]->root_general(id, v.get());
     pool->extra_root.push_back(id);
     pool->extra_view.push_back(std::move(v));
     return (int)pool->extra_root.size();

@@ -185,6 +185,13 @@ struct BatchLP {
     double *R, *xb, *U, *V, *scratch, *art;
     int32_t *basic, *nonbasic, *srcpos;
     DevState *st;
+    // root WITHOUT a slack basis (equality rows): the root's initial basis from the column search (simplex.go:611-637) and its
+    // tableau, computed once per root (Engine::root_general); a child's basis is that one + its K branch slacks
+    const double *gT0;       // m0 x gldt row-major: B0^-1 A_N0, column jp = root nonbasic position jp (ascending variable id)
+    const double *gxb0;      // m0: x_B of the root's initial basis (gonum-order solve)
+    const int32_t *gbasic0, *gnonbasic0;   // its positional lists
+    const int32_t *gposvar0; // n0: variable id -> basis position (>= 0) or -1 - nonbasic position
+    int32_t gldt, gen;       // gen = 1: this relaxation starts from that basis
     double tol_user;         // Phase-II tolerance of the call (GoMILP: 0)
     int32_t stage;           // BS_*
     int32_t tcur;            // index of the current T buffer

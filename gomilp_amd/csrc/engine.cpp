@@ -699,7 +699,10 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     const double *rhs = rhs_host ? rhs_host : P.hb.data();
     // the compressed schedule keeps L/U column-major (lu_compressed.hip), the other two row-major
     if (compressed != transpose) launch_luc_gather(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
-    else launch_gather_w(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
+    else {
+        if (transpose) HIP_TRY(hipMemsetAsync(w.W, 0, (size_t)m * ldw * sizeof(double), stream_));   // (k_gather_w leaves the padding of a line alone)
+        launch_gather_w(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
+    }
     // unit columns of ab (from the column statistics of the upload): the blocked LU skips their elimination steps
     if (!basic_host) {   // the caller has no host copy of the basis positions yet
         HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
@@ -793,6 +796,12 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     double logdet = 0;
     for (int i = 0; i < m; i++) logdet += log(fabs(diag[phys[i]]));
     *singular = w.st_host->lu_singular != 0 || exp(logdet) == 0;
+    if (*singular && getenv("GOMILP_DEBUG_LOOP")) {
+        int nz = 0; double dmin = 1e300;
+        for (int i = 0; i < m; i++) { if (diag[phys[i]] == 0) nz++; dmin = std::min(dmin, fabs(diag[phys[i]])); }
+        fprintf(stderr, "final_solve: singular (transpose %d, m %d, nd %d, rounds %lld, lu_singular flag %d, logdet %g, zero diagonals %d, min |u_ii| %g, compressed %d)\n",
+                (int)transpose, m, nd, (long long)lu_rounds_, (int)w.st_host->lu_singular, logdet, nz, dmin, (int)compressed);
+    }
     x.assign(m, 0.0);
     if (*singular) return GOMILP_OK;
     auto term = [](double bi, double va, double xk) { return va != 0 ? (-va) * xk + bi : bi; };
@@ -1029,6 +1038,7 @@ int Engine::solve_locked(int64_t id, double tol, const int64_t *initial_basic, d
             rho[pos] = P.lastrow[j]; used[rho[pos]] = 1; basic[pos] = j;
         }
     }
+    gen_start_ = !unit_basis;
     const int nn_max = n + 1 - m;
     // a non-slack starting basis (equality rows, supplied basis) always takes the tableau pipelines: their set-up accepts
     // any B^-1; the n - m < 2m rule is only the bytes-per-pivot trade-off between the two formulations
@@ -1318,6 +1328,51 @@ bool Engine::root_view(int64_t id, RootView *out) {
         if (!(P.nnz[j] == 1 && P.allone[j]) || used[P.lastrow[j]]) { out->unit_basis = false; break; }
         out->rho0[pos] = P.lastrow[j]; used[P.lastrow[j]] = 1;
     }
+    return true;
+}
+
+Engine::RootView::General::~General() {
+    for (void *p : {(void *)dT0, (void *)dxb0, (void *)dbasic0, (void *)dnonbasic0, (void *)dposvar0}) if (p) hipFree(p);
+}
+
+bool Engine::root_general(int64_t id, RootView *out) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (id < 0 || (size_t)id >= problems_.size() || !problems_[id]) return false;
+    const Problem &P = *problems_[id];
+    const int m = P.m, n = P.n;
+    if (P.verify_status != GOMILP_OK || m >= n || !((n - m) < 2 * m) || !ensure_host_A(P)) return false;
+    if (ensure_work(m, n + 1) != GOMILP_OK) return false;
+    Work &w = *w_;
+    std::vector<int32_t> basic;
+    std::vector<double> binv;
+    const int rc = (m >= 224 && general_device_) ? find_independent_device(P, basic, &binv) : general_find_linearly_independent(P.hA, m, n, basic, &binv);
+    if (rc != GOMILP_OK || (int)basic.size() != m) return false;
+    if (binv.size() != (size_t)m * m && !general_basis_inverse(P.hA, m, n, basic, n, std::vector<double>(), binv)) return false;
+    std::vector<char> inb(n, 0);
+    for (int i = 0; i < m; i++) inb[basic[i]] = 1;
+    std::vector<int32_t> nonbasic, posvar(n);
+    for (int j = 0; j < n; j++) if (!inb[j]) nonbasic.push_back(j);
+    const int nn = (int)nonbasic.size();
+    for (int i = 0; i < m; i++) posvar[basic[i]] = i;
+    for (int jp = 0; jp < nn; jp++) posvar[nonbasic[jp]] = -1 - jp;
+    if (upload_index_lists(basic, nonbasic) != GOMILP_OK) return false;
+    // x_B of the basis with the reference's own arithmetic (as Engine::solve does for the feasibility test)
+    std::vector<double> xb;
+    bool sing = false;
+    if (final_solve(P, n, xb, &sing, basic.data()) != GOMILP_OK || sing) return false;
+    std::shared_ptr<RootView::General> G(new RootView::General);
+    G->m = m; G->nn = nn; G->ldt = tab_ld(nn);
+    auto ok = [](hipError_t e) { return e == hipSuccess; };
+    if (!ok(dmalloc(&G->dT0, (size_t)m * G->ldt)) || !ok(dmalloc(&G->dxb0, (size_t)m)) || !ok(dmalloc(&G->dbasic0, (size_t)m)) ||
+        !ok(dmalloc(&G->dnonbasic0, (size_t)std::max(nn, 1))) || !ok(dmalloc(&G->dposvar0, (size_t)n))) return false;
+    if (!ok(hipMemcpy2DAsync(w.binv[0], (size_t)P.ld * sizeof(double), binv.data(), (size_t)m * sizeof(double), (size_t)m * sizeof(double), m, hipMemcpyHostToDevice, stream_))) return false;
+    if (!ok(hipMemsetAsync(G->dT0, 0, (size_t)m * G->ldt * sizeof(double), stream_))) return false;
+    launch_tab_gemm(w.binv[0], P.ld, P.dAt, P.ld, m, nn, w.nonbasic, G->dT0, G->ldt, false, stream_);
+    if (!ok(hipMemcpyAsync(G->dxb0, xb.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, stream_)) ||
+        !ok(hipMemcpyAsync(G->dbasic0, basic.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_)) ||
+        !ok(hipMemcpyAsync(G->dnonbasic0, nonbasic.data(), (size_t)nn * sizeof(int32_t), hipMemcpyHostToDevice, stream_)) ||
+        !ok(hipMemcpyAsync(G->dposvar0, posvar.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, stream_)) || !ok(sync_stream())) return false;
+    out->gen = G;
     return true;
 }
 

@@ -75,8 +75,20 @@ class Engine {
         int verify_status = GOMILP_OK;
         uint64_t serial = 0;              // identifies the upload (device buffers are recycled)
         std::vector<double> hb, hc;       // host copies of b and c (final solves on another engine's behalf)
+        // no slack basis (equality rows): the result of the column search (simplex.go:611-637) and the tableau of that basis,
+        // computed ONCE per root (root_general) — a child's starting basis is this one + its K branch slacks, so the batched
+        // schedule takes such children too instead of repeating the search per node
+        struct General {
+            int m = 0, nn = 0, ldt = 0;
+            double *dT0 = nullptr, *dxb0 = nullptr;                              // m x ldt row-major B0^-1 A_N0; x_B of the basis
+            int32_t *dbasic0 = nullptr, *dnonbasic0 = nullptr, *dposvar0 = nullptr;
+            ~General();
+        };
+        std::shared_ptr<General> gen;     // null: slack basis, or no usable basis (the single-relaxation engine reports why)
     };
     bool root_view(int64_t id, RootView *out);
+    // fills out->gen for a root without a slack basis (false: not possible — too large for the host copy of A, singular, ...)
+    bool root_general(int64_t id, RootView *out);
     // epilogue of simplex() (simplex.go:296-301) for a relaxation whose pivot loop ran elsewhere: final basis positions
     // `basic` (m entries) and updated x_B in, gonum-order solve of that basis, z, x out; `loop_rc` as Engine::solve
     int finish_from_basis(int64_t id, const int32_t *basic, const double *xb_updated, int loop_rc, double *opt_f, double *opt_x,
@@ -142,8 +154,9 @@ class Engine {
             bt_lag_ = 1,       // persistent loop kernel where the multi-workgroup block kernel runs (0: block kernel + update launches)
             loop_chunk_ = 512, // pivots per launch of the persistent loop kernel
             loop_grid_ = 0,    // its workgroups (0: one per CU)
-            exact_degenerate_ = 1,   // 0 never, 1 bases of up to 256 rows, 2 always: pivots whose winning ratio is (nearly) zero are decided on a fresh gonum-order x_B
+            exact_degenerate_ = 1,   // 0 never, 1 bases of up to 256 rows and every non-slack start, 2 always: pivots whose winning ratio is (nearly) zero are decided on a fresh gonum-order x_B
             cond_guard_ = 1;   // replay the condition guards of the reference on the host for bases of up to 64 rows
+    bool gen_start_ = false;      // the current solve starts from a searched (non-slack) basis: the degenerate-pivot guard stays on
     bool xchg_timeout_ = false;   // the last pivot loop ended in ST_XCHG_TIMEOUT (Engine::solve repeats the solve once)
     bool shadow_trace_ = false;   // this solve records its pivots for the replay even when the caller did not ask for a trace   // developer knobs of the block kernels (per context: tests force the 1024-thread instance)
     // per-solve state
@@ -170,6 +183,7 @@ bool general_basis_inverse(const std::vector<double> &A, int m, int n, const std
 int general_condition_replay(const std::vector<double> &A, int m, int n, std::vector<int32_t> &basic, const std::vector<std::pair<int, int>> &pivots,
                              bool ended_in_compute_move, int *status_out, int64_t *evaluations);
 double general_cond_inf(const std::vector<double> &A, int n);
+double general_basis_cond1(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, const std::vector<double> &art);
 bool general_solve_basis(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, const std::vector<double> &b, std::vector<double> &x);
 
 int device_count();

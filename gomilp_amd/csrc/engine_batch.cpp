@@ -90,7 +90,7 @@ BatchEngine::~BatchEngine() {
 }
 
 bool BatchEngine::eligible(const Engine::RootView &R, int K_max, bool phase1) const {
-    if (R.verify_status != GOMILP_OK || !R.unit_basis) return false;
+    if (R.verify_status != GOMILP_OK || !(R.unit_basis || R.gen)) return false;
     const int m = R.m + K_max, n = R.n + K_max;
     if (m >= n || !((n - m) < 2 * m)) return false;              // the tableau formulation (engine.cpp: use_tab)
     if (n + 2 > 8000) return false;                              // k_b_ctrl keeps two int lists of n in (default-limit) LDS
@@ -170,6 +170,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         const int K = (int)(koff[i + 1] - koff[i]);
         m_max = std::max(m_max, Ri.m + K); n_max = std::max(n_max, Ri.n + K);
         bool p1 = false;   // does this relaxation start infeasible?  (initPosTol; the set-up kernel decides the same way)
+        if (Ri.gen && !Ri.unit_basis) p1 = true;   // (a searched basis: feasibility is only known on the device — keep room for the artificial)
         for (double v : Ri.hb) if (v < -1e-13) { p1 = true; break; }
         for (int64_t k = koff[i]; k < koff[i + 1] && !p1; k++) if (rhs[k] < -1e-13) p1 = true;
         ldt1 = std::max(ldt1, batch_ldt(Ri.n - Ri.m + (p1 ? 1 : 0)));   // Phase-I tableau: one column more (the artificial)
@@ -213,6 +214,10 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         const int ri = root_of ? root_of[i] : 0;
         const Engine::RootView &R = *roots[ri];
         lp.At0 = R.dAt; lp.c0 = R.dc; lp.b0 = R.db; lp.rho0 = rho_of[ri];
+        if (!R.unit_basis && R.gen) {   // equality rows: start from the root's searched basis + the branch slacks
+            lp.gen = 1; lp.gT0 = R.gen->dT0; lp.gxb0 = R.gen->dxb0; lp.gbasic0 = R.gen->dbasic0; lp.gnonbasic0 = R.gen->dnonbasic0;
+            lp.gposvar0 = R.gen->dposvar0; lp.gldt = R.gen->ldt;
+        }
         lp.var = b.d_var + k0; lp.sign = b.d_sr + k0; lp.rhs = b.d_sr + b.cap_k + k0;
         lp.ld0 = R.ld; lp.m0 = R.m; lp.n0 = R.n; lp.K = K; lp.m = R.m + K; lp.n = R.n + K;
         lp.ldu = (lp.m + 1) & ~1; lp.cap_ldt = b.cap_ldt;
@@ -224,7 +229,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         lp.st = b.d_st + i;
         lp.tol_user = tol; lp.kblock = kb; lp.stage = BS_HOST;
         // degenerate pivots are decided on a fresh gonum-order x_B: such a relaxation is handed to the worker path (ST_NEED_EXACT -> BS_HOST)
-        lp.bt.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && lp.m <= 256)) ? 1e-9 : 0.0;
+        lp.bt.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && (lp.m <= 256 || lp.gen))) ? 1e-9 : 0.0;
         if (kb == 16) { lp.bt.groups = grp.groups; lp.bt.group_ri = grp.ri; lp.bt.group_nt = grp.nt; lp.bt.xbuf = b.d_xbuf + (size_t)i * bt_xbuf_doubles(); }
     }
     B_TRY(hipMemsetAsync(b.d_active, 0, kMaxSteps * sizeof(int), stream_));

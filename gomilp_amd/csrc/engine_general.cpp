@@ -303,6 +303,18 @@ bool general_basis_inverse(const std::vector<double> &A, int m, int n, const std
     return invert_threaded(B, m, binv);
 }
 
+// exact kappa_1 of a basis (columns `basic` of A, the artificial column `art` standing for index n): the trial bases of the Bland
+// rule (simplex.go:374-379: mat.Cond(abTmp, 1) < 1e16; the reference has Dgecon's estimate of the same number)
+double general_basis_cond1(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, const std::vector<double> &art) {
+    std::vector<double> B((size_t)m * m);
+    for (int i = 0; i < m; i++)
+        for (int p = 0; p < m; p++) {
+            const int j = basic[p];
+            B[(size_t)i * m + p] = (j < n) ? A[(size_t)i * n + j] : art[i];
+        }
+    return cond1_exact(B, m, m);
+}
+
 // ---- condition guards of gonum's LU.Solve (mat/lu.go:301,321) for SMALL bases, by replaying the pivot sequence on the host
 // The reference factorises the basis three times per pivot and leaves its loop with the current point when a solve reports
 // mat.Condition (cond > 1e16 or Det() == 0: simplex.go:236-239, :289-292) or lp.ErrLinSolve (computeMove, :316-318).  The

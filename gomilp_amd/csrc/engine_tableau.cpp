@@ -226,8 +226,10 @@ BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int
     a.stamps = bt_stamps_ ? w.stamps : nullptr;
     a.upd_valu = bt_upd_valu_ ? 1 : 0;
     a.fault = bt_fault_ ? 1 : 0;
-    // degenerate vertices decided on a fresh gonum-order x_B: by default for bases of up to 256 rows
-    a.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && P.m <= 256)) ? 1e-9 : 0.0;
+    // degenerate vertices decided on a fresh gonum-order x_B: by default for bases of up to 256 rows, and for
+    // every start that is not a slack basis (equality rows: a tree's repeated branch rows make nearly dependent tableau rows
+    // there, and a pivot on their 1e-12 drift walks into a singular basis)
+    a.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && (P.m <= 256 || gen_start_))) ? 1e-9 : 0.0;
     if (a.tiled && !bt_old_) {
         const BtGroupCfg gc = bt_group_cfg(P.m, ldt_, (int)bt_groups_);
         a.groups = gc.groups; a.group_ri = gc.ri; a.group_nt = gc.nt; a.xbuf = w.xbuf;
@@ -274,7 +276,7 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
     bool sing = false;
     int rc;
     if ((rc = final_solve(P, n, y, &sing, basic.data(), true, cb.data())) != GOMILP_OK) return -rc;
-    if (sing) return -GOMILP_ERR_LINSOLVE;
+    if (sing) { if (getenv("GOMILP_DEBUG_LOOP")) fprintf(stderr, "exact_step: ab^T singular (phase %d, m %d)\n", phase, m); return -GOMILP_ERR_LINSOLVE; }
     {
         std::vector<double> ypad(P.ld, 0.0);
         std::copy(y.begin(), y.begin() + m, ypad.begin());
@@ -288,7 +290,7 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
     for (int j = 0; j < nn; j++) r[j] = w.h_vec[j];
     // x_B of this iteration (simplex.go:289 of the previous one): resident from here on
     if ((rc = final_solve(P, n, xb, &sing, basic.data())) != GOMILP_OK) return -rc;
-    if (sing) return -GOMILP_ERR_LINSOLVE;
+    if (sing) { if (getenv("GOMILP_DEBUG_LOOP")) fprintf(stderr, "exact_step: ab singular for x_B (phase %d, m %d)\n", phase, m); return -GOMILP_ERR_LINSOLVE; }
     {
         std::vector<double> xpad(P.ld, 0.0);
         std::copy(xb.begin(), xb.begin() + m, xpad.begin());
@@ -313,9 +315,45 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
     }
     if (!anyneg) return 2;                      // :328-330
     const int64_t p = min_idx(move.data(), m);  // :268
-    if (move[p] <= 0) return 3;                 // :269 -> replaceBland
-    *q_out = (int)q; *p_out = (int)p;
-    return 0;
+    if (!(move[p] <= 0)) { *q_out = (int)q; *p_out = (int)p; return 0; }
+    // ---- :269 -> replaceBland (:347-383) on the same fresh quantities: candidates in position order with r <= -1e-14 after the
+    // rounding of :252-256, each with its own computeMove; a zero-level row is only taken when the basis it gives is not
+    // singular (mat.Cond(abTmp, 1) < 1e16 — here the exact kappa_1 on the host copy of A: the device Bland rule has no such test
+    // and has walked into singular bases on equality-constrained LPs)
+    if (!ensure_host_A(P)) return 3;
+    if (st) st->bland_steps++;
+    std::vector<double> art(m, 0.0);
+    if (phase == 1) {
+        HIP_TRY(hipMemcpyAsync(w.h_vec, P.dAt + (size_t)n * P.ld, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(sync_stream());
+        for (int i = 0; i < m; i++) art[i] = w.h_vec[i];
+    }
+    for (int j = 0; j < nn; j++) if (fabs(r[j]) < 1e-13) r[j] = 0;   // rRoundTol
+    for (int i = 0; i < nn; i++) {
+        if (r[i] > -1e-14) continue;            // blandNegTol, :352
+        const int var = nonbasic[i];
+        for (int t = 0; t < m; t++) col[t] = var < n ? P.hA[(size_t)t * n + var] : art[t];
+        if ((rc = final_solve(P, n, dsol, &sing, basic.data(), false, col.data())) != GOMILP_OK) return -rc;
+        if (sing) return -GOMILP_ERR_LINSOLVE;
+        bool neg = false;
+        for (int t = 0; t < m; t++) {
+            double d = -dsol[t];
+            if (fabs(d) < 1e-13) d = 0;
+            if (d < 0) neg = true;
+            move[t] = d >= 0 ? std::numeric_limits<double>::infinity() : xb[t] / fabs(d);
+        }
+        if (!neg) return 2;                     // computeMove inside Bland: ErrUnbounded, :356-360
+        const int64_t rp0 = min_idx(move.data(), m);
+        if (fabs(move[rp0]) > 1e-12) { *q_out = i; *p_out = (int)rp0; return 0; }   // blandZeroTol, :362
+        for (int rp = 0; rp < m; rp++) {
+            if (move[rp] > 1e-12) continue;
+            std::vector<int32_t> trial = basic;
+            trial[rp] = var;
+            const double kappa = general_basis_cond1(P.hA, m, n, trial, art);
+            if (kappa < 1e16) { *q_out = i; *p_out = rp; return 0; }           // :377
+        }
+    }
+    return -GOMILP_ERR_BLAND;                   // :382
 }
 
 // Pivot loop: blocks of block_k_ pivots (one single-workgroup launch) followed by one rank-K update launch.

@@ -176,6 +176,34 @@ def gen_c1():
         dump_tree(os.path.join(OUT, "milp_C1%s.npz" % ("_single" if single else "")), res, 15, dict(budget=63))
 
 
+def eq_problem(seed: int = 77, me: int = 200, nv: int = 320):
+    """A MILP with 200 equality and 200 inequality rows (api.go:124 EqualTo; ilp.go:43-57 gives [[A, 0], [G, I]]: no slack basis, the
+    column search of simplex.go:611-637 decides the start of every node): Gaussian data, feasible by construction."""
+    rng = np.random.default_rng(seed)
+    x0 = np.abs(rng.standard_normal(nv))
+    A, G = rng.standard_normal((me, nv)), rng.standard_normal((me, nv))
+    b, h = A @ x0, G @ x0 + np.abs(rng.standard_normal(me))
+    c = np.abs(rng.standard_normal(nv))
+    integ = [j % 5 == 0 for j in range(nv)]
+    return c, A, b, G, h, integ
+
+
+def gen_eq(budget: int = 30):
+    c, A, b, G, h, integ = eq_problem()
+    O.set_threads(THREADS)
+    done = [0]
+    t0 = time.time()
+
+    def sf(cc, AA, bb):
+        r = O.simplex(cc, AA, bb, 0.0, None)      # the reference's own O(m^4) column search per node
+        done[0] += 1
+        log("EQ node", done[0], "%.0f s" % (time.time() - t0))
+        return r
+
+    res = O.solve_milp(c, A, b, G, h, integ, max_nodes=budget, simplex_fn=sf)
+    dump_tree(os.path.join(OUT, "milp_EQ.npz"), res, len(c) + G.shape[0], dict(budget=budget))
+
+
 def main(argv):
     os.makedirs(OUT, exist_ok=True)
     O.build()
@@ -193,6 +221,8 @@ def main(argv):
             gen_c3()
         elif t == "c1":
             gen_c1()
+        elif t == "eq":
+            gen_eq()
         else:
             raise SystemExit("unknown target " + t)
     return 0
