@@ -389,7 +389,7 @@ def main() -> int:
     bytes_pivot_survey = 8.0 * (m * nn + 3.0 * m * m)      # SURVEY.md §8d per-unit figure (explicit-inverse model)
     if pipeline == "blocked":
         nblocks = max(ksec[1], 1.0)
-        K = ksec[3] / nblocks if ksec[1] > 0 else 8.0
+        K = ksec[3] / nblocks if ksec[1] > 0 else 8.0   # pivots per block
         t_inner, t_upd = ksec[0] / nblocks, ksec[2] / nblocks
         need = max(m, nn)
         inner_name = ("k_bt_inner2<512,2,2,8,0>" if need <= 1024 else "k_bt_innerG<8,256,1,16>" if need <= 2048 else
@@ -404,19 +404,24 @@ def main() -> int:
         if t_upd <= 0 and need > 1024:
             # persistent loop kernel: ONE kernel carries the whole pivot loop — the pivot workgroups' chain and, beside it, the
             # update workgroups' streaming pass over the tableau (read + written once per block of K = 8 pivots)
-            loop_name = "k_bt_loop<8,%d,1>" % (256 if need <= 2048 else 512)
+            loop_name = "k_bt_loop<8,256,1,8>" if need <= 2048 else "k_bt_loop<16,256,1,16>"
             traffic, tsrc = newest_pmc("k_bt_loop")
             bytes_block = bytes_inner + bytes_update
+            bpl = 512.0 / K   # sampled launches are full ones: loop_chunk (512 pivots) / K blocks
             roofline = {
-                "bound": "latency", "kernel": loop_name, "time_share": loop_s / dt,
+                "bound": "hbm", "kernel": loop_name, "time_share": loop_s / dt,
                 "achieved": bytes_block / t_inner / 1e9 if t_inner > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "traffic": traffic, "traffic_source": tsrc, "traffic_unit": "bytes per block of %d pivots" % int(K),
+                "traffic": traffic, "traffic_source": tsrc,
+                "bytes_per_launch": bpl * bytes_block, "avg_launch_us": 1e6 * t_inner * bpl, "blocks_per_launch": int(bpl),
+                "sampled_launches": int(ksec[1] / bpl),
                 "bytes_per_block": bytes_block, "block_us": 1e6 * t_inner, "us_per_pivot": 1e6 * t_inner / K, "pivots_per_block": K,
-                "blocks_per_launch": "up to 64 (knob loop_chunk = 512 pivots)",
+                "limited_by": "the pivot workgroups' dependent-latency chain (two exchanges + two tableau reads per pivot), not by bandwidth: "
+                              "the update workgroups finish a block's %.0f MB in less than the chain needs for its 8 pivots" % (bytes_update / 1e6),
                 "note": "persistent kernel, one workgroup per CU or fewer: 8 pivot workgroups on one XCD run the blocks (two exchanges through that XCD's L2 and two "
                         "dependent tableau reads per pivot: the latency chain that sets the pace), the other workgroups apply the rank-8 update of block t "
                         "(tableau read + written once, matrix cores) beside block t+1.  achieved = algorithmic bytes per block (16 m (n-m) update + the pivot "
-                        "workgroups' columns, rows and terms) / HIP-event time of the launch per block",
+                        "workgroups' columns, rows and terms) x 64 blocks of a full launch / HIP-event time of that launch (only full launches are sampled; "
+                        "rocprofv3's average also counts the short last launch of each phase)",
                 "loop": {"bytes_per_block": bytes_block, "block_us": 1e6 * block_s, "kernel_us_per_block": 1e6 * t_inner,
                          "achieved_GBs": bytes_block / block_s / 1e9, "frac": bytes_block / block_s / 1e9 / HBM_PEAK_GBS, "us_per_pivot_end_to_end": 1e6 * block_s / K,
                          "model": "per block of K pivots: 16*m*(n-m) (rank-K update: T read + written once) + K*16*(m+n-m) + 24*(m+n-m) (pivot workgroups); wall time of the whole loop / blocks"},
@@ -542,10 +547,11 @@ def main() -> int:
                      "inner_us_per_launch": 1e6 * k4[0] / nb4, "update_us_per_launch": 1e6 * k4[2] / nb4, "pivots_per_launch": k4[3] / nb4,
                      "update_GBs": 16.0 * m4 * m4 / (k4[2] / nb4) / 1e9 if k4[2] > 0 else 0.0,
                      "update_frac_of_hbm_peak": 16.0 * m4 * m4 / (k4[2] / nb4) / 1e9 / HBM_PEAK_GBS if k4[2] > 0 else 0.0,
-                     "inner_kernel": "k_bt_loop<8,512,1>",
-                     "note": "persistent loop kernel (blocks of 8 pivots on 8 pivot workgroups of one XCD, the rank-8 update of block t on the other workgroups beside block "
-                             "t+1; inner_us_per_launch = time per block): the two 134 MB tableau buffers do not fit the Infinity Cache, the update streams at the HBM "
-                             "rate (block_GBs) and sets the block time at this size, not the pivot chain"}
+                     "inner_kernel": "k_bt_loop<16,256,1,16>", "us_per_block": 1e6 * k4[0] / nb4,
+                     "note": "persistent loop kernel: blocks of 16 pivots on 16 pivot workgroups of 256 threads on one XCD (16 current + 16 lagging terms per row / column in "
+                             "registers), the rank-16 update of block t (matrix cores) on the other workgroups beside block t+1; inner_us_per_launch = time per block.  "
+                             "The two 134 MB tableau buffers do not fit the Infinity Cache: the update streams at the HBM rate (~51 us per block) and would set the block "
+                             "time with blocks of 8; with 16 the pivot chain does (block_GBs = update + chain bytes per block / block time)"}
         p4.free()
         cx4.close()
         del c4, A4, b4

@@ -46,7 +46,7 @@ constexpr int kXSpinLimit = 2000000;   // polls (~0.5 us each) before a launch g
 // total a fast update workgroup's arrival for block t + 1 could stand in for a slow one's missing arrival for block t
 // behind the records: blocks finished by the pivot workgroups (G arrivals per block), blocks applied by the update
 // workgroups (one arrival per update workgroup and block)
-constexpr int kXSync = kXHeader + 2 * 8 * kXSlots * 2;   // doubles in front of the counters
+constexpr int kXSync = kXHeader + 2 * 16 * kXSlots * 2;   // doubles in front of the counters (records of up to 16 workgroups, two parities)
 constexpr int kXSyncDoubles = 16 * 5;   // the block counter and four update counters (blocks = j mod 4), a line each
 constexpr int kLoopSpinLimit = 600000;   // polls (~1.5 us each) of a block / update counter before a workgroup gives up
 
@@ -69,6 +69,12 @@ template <> struct XLoad<1> {
     static __device__ __forceinline__ void run(const xpair *p, xpair (&v)[1], bool fast) {
         if (fast) asm volatile("global_load_dwordx4 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(p) : "memory");
         else asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(p) : "memory");
+    }
+};
+template <> struct XLoad<2> {   // two slots per lane (16 workgroups), one wait
+    static __device__ __forceinline__ void run(const xpair *p0, const xpair *p1, xpair (&v)[2], bool fast) {
+        if (fast) asm volatile("global_load_dwordx4 %0, %2, off nt\n\tglobal_load_dwordx4 %1, %3, off nt\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]), "=&v"(v[1]) : "v"(p0), "v"(p1) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]), "=&v"(v[1]) : "v"(p0), "v"(p1) : "memory");
     }
 };
 __device__ __forceinline__ double ld_agent(const double *p) {
@@ -97,8 +103,9 @@ struct BtWinG { double m; unsigned int i; };                   // a wave's own w
 template <int G, int NT, int RI, int KR, bool STAMP, bool LOOP = false>
 __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, const int nupd = 0) {
     constexpr int NW = NT / 64;
-    static_assert(!LOOP || KR == 16, "loop mode: 8 lagging + 8 current terms");
-    static_assert(G == 2 || G == 4 || G == 8, "G");
+    static_assert(!LOOP || KR == 16 || KR == 32, "loop mode: KR / 2 lagging + KR / 2 current terms");
+    constexpr int KB = LOOP ? KR / 2 : KR;   // pivots per block
+    static_assert(G == 2 || G == 4 || G == 8 || G == 16, "G");
     if (a.fault && g == 1) return;   // test hook: a workgroup that never takes part -> the others must give up (ST_XCHG_TIMEOUT)
     __shared__ double redM[16];
     __shared__ unsigned int redI[16];
@@ -153,9 +160,9 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
         rv[s] = i < a.nn ? a.r[i] : inf;   // padding never wins an argmin
         nbasv[s] = i < a.nn ? a.nonbasic[i] : 0;
     }
-    // loop mode: rows [cur0, cur0 + 8) of U / V take the terms of the running block, rows [lag0, lag0 + nl) hold those of the
+    // loop mode: rows [cur0, cur0 + KB) of U / V take the terms of the running block, rows [lag0, lag0 + nl) hold those of the
     // previous one (not yet in the tableau this block reads)
-    int cur0 = 0, lag0 = 8, nl = 0;
+    int cur0 = 0, lag0 = KB, nl = 0;
     const int sel0 = LOOP ? (a.par ? st->tsel2[1] : st->tsel2[0]) : 0;
     const double *hdr_in = a.xbuf + 1 + 5 * (LOOP ? a.par : 0);
     double *hdr_out = a.xbuf + 1 + 5 * (LOOP ? (a.par ^ 1) : 0);
@@ -278,6 +285,48 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             if constexpr (STAMP && !LOOP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         stamp(which * 5 + 2);
+        if constexpr (G == 16) {
+            // 16 records: two 16-byte loads per lane, both slots of the same record l & 15 — lanes 0..15 get (minimum, first index)
+            // of record l directly, the other rows the winner's scalars (slots 2, 3, 4) and the XCC ids (slot 5)
+            const int rec = lane & 15, grp = lane >> 4;
+            const bool actB = grp < 2;
+            const xpair *base = recs + (size_t)par * G * kXSlots + rec * kXSlots;
+            const xpair *srcA = base + (grp == 0 ? 0 : grp + 1), *srcB = base + (grp == 0 ? 1 : grp == 1 ? 5 : 0);
+            xpair got[2];
+            int spins = 0;
+            for (;;) {
+                XLoad<2>::run(srcA, srcB, got, fast);
+                if (__all(got[0].x == seqd && (!actB || got[1].x == seqd))) break;
+                if (++spins > kXSpinLimit) { dead = true; break; }
+            }
+            stamp(which * 5 + 3);
+            const double val = got[0].y, val2 = got[1].y;
+            double xm = (lane < 16) ? val : inf;
+            xm = vmin_f64(xm, dpp_f64<0xB1>(xm));
+            xm = vmin_f64(xm, dpp_f64<0x4E>(xm));
+            xm = vmin_f64(xm, dpp_f64<0x141>(xm));   // row_half_mirror
+            xm = vmin_f64(xm, dpp_f64<0x140>(xm));   // row_mirror: lanes 0..15 all hold the minimum
+            const bool mine = lane < 16 && val == xm;
+            double km = mine ? val2 : 4294967295.0;
+            km = vmin_f64(km, dpp_f64<0xB1>(km));
+            km = vmin_f64(km, dpp_f64<0x4E>(km));
+            km = vmin_f64(km, dpp_f64<0x141>(km));
+            km = vmin_f64(km, dpp_f64<0x140>(km));
+            const unsigned int mk = (unsigned int)(__ballot(mine && val2 == km) & 0xFFFFull);
+            const int gw = mk ? __builtin_ctz(mk) : 0;
+            XWin r;
+            r.m = readlane_f64(xm, 0);
+            r.i = (unsigned int)readlane_f64(km, 0);
+            r.p0 = readlane_f64(val, 16 + gw);
+            r.p1 = readlane_f64(val, 32 + gw);
+            r.p2 = readlane_f64(val, 48 + gw);
+            if (first) {
+                fast = !dead && __all(grp != 1 || val2 == (double)myxcc);
+                first = false;
+            }
+            stamp(which * 5 + 4);
+            return r;
+        }
         // lane l reads slot l >> 3 of record l & 7: the G minima sit in lanes 0..G-1, their indices in lanes 8.., the scalars behind
         const bool act = (lane & 7) < G && (lane >> 3) < 6;
         const xpair *src = recs + (size_t)par * G * kXSlots + (act ? (lane & 7) * kXSlots + (lane >> 3) : 0);
@@ -359,7 +408,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
         if constexpr (LOOP) {
             // lane l fetches term l (newest first: this block's k terms, then the nl lagging ones): ONE load instruction
             // instead of 16 with scalar addresses each; the terms reach the multiply-adds as scalar operands
-            const int l = lane & 15;
+            const int l = lane & (KR - 1);
             const int trow = l < k ? cur0 + k - 1 - l : lag0 + nl - 1 - (l - k);
             const double tv = l < k + nl ? ld_term(a.V + (size_t)trow * a.ldt + q) : 0.0;
             if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(11); }   // column + term loads: issue -> data
@@ -412,12 +461,12 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             if (!s_ok) { dead = true; break; }
         }
         Tb = reinterpret_cast<const char *>(((sel0 ^ (blk > 0 ? blk - 1 : 0)) & 1) ? a.Tbuf[1] : a.Tbuf[0]);   // (no dynamic index into the argument block: scratch)
-        cur0 = (blk & 1) * 8; lag0 = cur0 ^ 8; nl = blk > 0 ? 8 : 0;
-        if (blk > 0) {   // entries 0..7 = the previous block (now lagging), 8..15 = the block before it: in the tableau by now
+        cur0 = (blk & 1) * KB; lag0 = cur0 ^ KB; nl = blk > 0 ? KB : 0;
+        if (blk > 0) {   // entries 0..KB-1 = the previous block (now lagging), KB.. = the block before it: in the tableau by now
 #pragma unroll
             for (int s = 0; s < RI; s++) {
 #pragma unroll
-                for (int j = 8; j < KR; j++) { ureg[s][j] = 0; vreg[s][j] = 0; }
+                for (int j = KB; j < KR; j++) { ureg[s][j] = 0; vreg[s][j] = 0; }
             }
         }
         kd = 0;
@@ -530,7 +579,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
         }
         double up[KR];   // u_j[p] of the block's k earlier pivots, newest first (loop mode: then the lagging ones)
         if constexpr (LOOP) {
-            const int l = lane & 15;
+            const int l = lane & (KR - 1);
             const int trow = l < k ? cur0 + k - 1 - l : lag0 + nl - 1 - (l - k);
             const double tv = l < k + nl ? ld_term(a.U + (size_t)trow * a.ldu + p) : 0.0;
             if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(12); }   // row + term loads: issue -> data
@@ -664,7 +713,7 @@ typedef unsigned int btg_u4 __attribute__((ext_vector_type(4)));
 // same map, so two blocks X / Y cover 32 columns INTERLEAVED (X: c0 + 2n, Y: c0 + 2n + 1): a lane's X and Y entries of a row are
 // neighbours inside one 4x4 tile, one 16-byte agent-scope load / store instead of two of 8 bytes (8-byte agent-scope accesses run
 // at 0.54-0.70 of the 16-byte rate).  One unit of a wave = 16 rows x 64 columns: eight 16-byte tableau loads per lane in flight.
-template <int NT>
+template <int NT, int KB>
 __device__ __forceinline__ void bt_loop_update_role(const BTArgs &a, const int u, const int nupd, const int G) {
     constexpr int NWV = NT / 64;
     DevState *st = a.st;
@@ -689,12 +738,12 @@ __device__ __forceinline__ void bt_loop_update_role(const BTArgs &a, const int u
         if (kd > 0) {
             const double *src = ((sel0 ^ blk) & 1) ? a.Tbuf[1] : a.Tbuf[0];
             double *dst = ((sel0 ^ blk) & 1) ? a.Tbuf[0] : a.Tbuf[1];
-            const int k0 = (blk & 1) * 8;
+            const int k0 = (blk & 1) * KB;
             const double *Ub = a.U + (size_t)k0 * a.ldu, *Vb = a.V + (size_t)k0 * a.ldt;
             const int tbytes = (int)((size_t)ntr * trow * 8);
             const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(src), 0, tbytes, 0x00020000);
             const auto rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, tbytes, 0x00020000);
-            const auto rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Vb), 0, (int)((size_t)8 * a.ldt * 8), 0x00020000);
+            const auto rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Vb), 0, (int)((size_t)KB * a.ldt * 8), 0x00020000);
             for (int unit = u; unit < nunits; unit += nupd) {
                 const int strip = unit / groups, cp = (unit % groups) * NWV + wv;
                 if (cp >= ncp) continue;
@@ -705,8 +754,9 @@ __device__ __forceinline__ void bt_loop_update_role(const BTArgs &a, const int u
                 // 16-byte agent-scope (sc1, aux 16) buffer loads / stores: instructions the compiler knows, so it counts them and
                 // places the wait states around the matrix instructions itself (an inline-asm global_store_dwordx4 here lost
                 // data: the next instruction may overwrite a wide store's data registers before the store has read them)
-                btg_d2 c[8], bv[4];
-                double av[2];
+                constexpr int NS = KB / 4;   // matrix instructions (4 terms each) per 16 x 16 block
+                btg_d2 c[8], bv[2 * NS];
+                double av[NS];
 #pragma unroll
                 for (int x = 0; x < 2; x++) {
 #pragma unroll
@@ -716,18 +766,18 @@ __device__ __forceinline__ void bt_loop_update_role(const BTArgs &a, const int u
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const size_t off = (size_t)((t & 1) * 4 + l4) * a.ldt + c0 + (t >> 1) * 32 + 2 * l15;
+                for (int t = 0; t < 2 * NS; t++) {   // bv[x * NS + s2]: terms 4 s2 + l4 for the column half x
+                    const size_t off = (size_t)((t % NS) * 4 + l4) * a.ldt + c0 + (t / NS) * 32 + 2 * l15;
                     bv[t] = __builtin_bit_cast(btg_d2, __builtin_amdgcn_raw_buffer_load_b128(rs_v, (int)(off * 8), 0, 16));
                 }
-                av[0] = ld_agent(Ub + (size_t)l4 * a.ldu + rowc);
-                av[1] = ld_agent(Ub + (size_t)(4 + l4) * a.ldu + rowc);
+#pragma unroll
+                for (int s2 = 0; s2 < NS; s2++) av[s2] = ld_agent(Ub + (size_t)(4 * s2 + l4) * a.ldu + rowc);
                 // rows of U / V beyond the pivots of this block are stale, rows beyond m do not exist
 #pragma unroll
-                for (int s2 = 0; s2 < 2; s2++) {
+                for (int s2 = 0; s2 < NS; s2++) {
                     const bool kon = 4 * s2 + l4 < kd;
                     if (!kon || row >= a.m) av[s2] = 0.0;
-                    if (!kon) { bv[s2] = btg_d2{0.0, 0.0}; bv[2 + s2] = btg_d2{0.0, 0.0}; }
+                    if (!kon) { bv[s2] = btg_d2{0.0, 0.0}; bv[NS + s2] = btg_d2{0.0, 0.0}; }
                 }
                 btg_d4 cx[2], cy[2];
 #pragma unroll
@@ -735,9 +785,9 @@ __device__ __forceinline__ void bt_loop_update_role(const BTArgs &a, const int u
 #pragma unroll
                     for (int r = 0; r < 4; r++) { cx[x][r] = c[x * 4 + r][0]; cy[x][r] = c[x * 4 + r][1]; }
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; s2++) {
-                        cx[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[x * 2 + s2][0], cx[x], 0, 0, 0);
-                        cy[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[x * 2 + s2][1], cy[x], 0, 0, 0);
+                    for (int s2 = 0; s2 < NS; s2++) {
+                        cx[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[x * NS + s2][0], cx[x], 0, 0, 0);
+                        cy[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[x * NS + s2][1], cy[x], 0, 0, 0);
                     }
                 }
 #pragma unroll
@@ -762,12 +812,12 @@ __device__ __forceinline__ void bt_loop_update_role(const BTArgs &a, const int u
 // Blocks 0, 8, ..., 8 (G - 1) — one XCD under the round-robin placement of blocks — are the pivot workgroups, every other block
 // of the grid an update workgroup.  All workgroups of the launch must be resident (they wait for each other): the grid is one
 // workgroup per CU (launch_bt_loop), and every wait is bounded.
-template <int G, int NT, int RI, bool STAMP = false>
+template <int G, int NT, int RI, bool STAMP = false, int KB = 8>
 __global__ __launch_bounds__(NT) void k_bt_loop(BTArgs a) {
     const int b = (int)blockIdx.x, nupd = (int)gridDim.x - G;
-    if ((b & 7) == 0 && (b >> 3) < G) { bt_innerG_body<G, NT, RI, 16, STAMP, true>(a, b >> 3, nupd); return; }
+    if ((b & 7) == 0 && (b >> 3) < G) { bt_innerG_body<G, NT, RI, 2 * KB, STAMP, true>(a, b >> 3, nupd); return; }
     const int before = min(G, (b + 7) >> 3);   // pivot blocks in front of block b
-    bt_loop_update_role<NT>(a, b - before, nupd, G);
+    bt_loop_update_role<NT, KB>(a, b - before, nupd, G);
 }
 
 // Batched form (device-batched waves of large relaxations, engine_batch.cpp): the relaxation at position p of the active list
@@ -840,13 +890,15 @@ bool bt_loop_supported(const BtGroupCfg &c) { return c.groups >= 2 && c.ri == 1;
 void launch_bt_loop(const BTArgs &a, int ncu, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const int G = a.groups;
     const unsigned int grid = (unsigned int)std::max(ncu, 8 * G);
-    if (a.group_nt == 256) {
+    if (a.group_nt == 256 && G == 8) {
         if (a.stamps) hipExtLaunchKernelGGL((k_bt_loop<8, 256, 1, true>), dim3(grid), dim3(256), 0, s, e0, e1, 0, a);   // diagnostic build
         else hipExtLaunchKernelGGL((k_bt_loop<8, 256, 1>), dim3(grid), dim3(256), 0, s, e0, e1, 0, a);
         return;
     }
+    if (G == 16) { hipExtLaunchKernelGGL((k_bt_loop<16, 256, 1, false, 16>), dim3(std::max(grid, 136u)), dim3(256), 0, s, e0, e1, 0, a); return; }   // 4096 rows: 16 x 256 threads, blocks of 16
     if (G == 2) hipExtLaunchKernelGGL((k_bt_loop<2, 512, 1>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);
     else if (G == 4) hipExtLaunchKernelGGL((k_bt_loop<4, 512, 1>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);
+    else if (a.kmax == 16) hipExtLaunchKernelGGL((k_bt_loop<8, 512, 1, false, 16>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);   // blocks of 16 pivots
     else hipExtLaunchKernelGGL((k_bt_loop<8, 512, 1>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);
 }
 // batched launch: the whole wave has the shape class of its largest relaxation (8 workgroups; 256 or 512 threads)

@@ -204,7 +204,12 @@ void Engine::bt_plan(const Problem &P, int *K, bool *tiled, bool *lag) const {
         *tiled = true;
         // persistent loop kernel (default, btg_kernels.hip k_bt_loop): blocks of 8 pivots, 8 lagging + 8 current terms, the rank-8
         // update of block t applied by the other workgroups of the same launch beside block t+1
-        if (lag && bt_lag_ && block_k_ == 0 && max_pivots_ == 0 && (!bt_stamps_ || gc.nt == 256) && bt_loop_supported(gc)) { *lag = true; *K = 8; }
+        // (512-thread shapes — beyond 2048 rows — run blocks of 16: there the rank-8 update of a 134 MB tableau takes longer than 8
+        // pivots, and 16 + 16 terms still fit the 256 registers of a 512-thread workgroup)
+        if (lag && bt_lag_ && block_k_ == 0 && max_pivots_ == 0 && (!bt_stamps_ || gc.nt == 256) && bt_loop_supported(gc)) {
+            *lag = true;
+            *K = (gc.nt == 512 && gc.groups == 8 && loop_k_ != 8) ? 16 : 8;
+        }
         return;
     }
     // block size: 8 when the block's rank-1 terms fit in registers (bt_kernels.hip), else 16
@@ -415,6 +420,9 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
         if (lag) {   // the whole chunk is one launch
             BTArgs ai = make_bt_args(P, phase, tol, nn, K);
             ai.loop = 1; ai.nblocks = (int)nblocks; ai.par = (int)(launch_no & 1);
+            // 2049..4096 rows: 16 pivot workgroups of 256 threads (one wave per SIMD: the per-pivot chain of the 2048-row shape)
+            // instead of 8 of 512 — inside the loop kernel only; set-up pivots and the batched schedule keep bt_group_cfg's shape
+            if (ai.groups == 8 && ai.group_nt == 512 && ai.group_ri == 1 && loop_g_ != 8 && K == 16) { ai.groups = 16; ai.group_nt = 256; }
             ai.Tbuf[0] = w.T[0]; ai.Tbuf[1] = w.T[1];
             ai.exact_once = exact_pending ? 1 : 0; exact_pending = false;
             ai.forced_q = forced_q_pending; ai.forced_p = forced_p_pending; forced_q_pending = forced_p_pending = -1;

@@ -63,6 +63,8 @@ def frontier_children(root_x, integrality, nvars: int = 8):
     import math
     picks = [j for j in range(len(integrality) - 1, -1, -1)
              if integrality[j] and root_x[j] != math.floor(root_x[j])][:nvars]
+    if len(picks) < nvars:   # a wider frontier than the root has fractional variables: integer-valued ones behind them (x_j <= v | x_j >= v + 1)
+        picks += [j for j in range(len(integrality) - 1, -1, -1) if integrality[j] and j not in picks][: nvars - len(picks)]
     children = []
     for pattern in range(1 << len(picks)):
         cons = []

@@ -204,6 +204,40 @@ def gen_eq(budget: int = 30):
     dump_tree(os.path.join(OUT, "milp_EQ.npz"), res, len(c) + G.shape[0], dict(budget=budget))
 
 
+EQLP_CASES = [(5, 420, 300), (6, 900, 500)]      # (seed, n, m): 600- and 1000-row standard forms without a slack basis
+
+
+def eqlp_problem(seed: int, n: int, m: int):
+    """m equality + m inequality rows over n variables (the data of test_general_initial_basis_beyond_512_rows)."""
+    rng = np.random.default_rng(seed)
+    x0 = np.abs(rng.standard_normal(n))
+    A = rng.standard_normal((m, n)); b = A @ x0
+    G = rng.standard_normal((m, n)); h = G @ x0 + np.abs(rng.standard_normal(m))
+    c = np.abs(rng.standard_normal(n))
+    return O.convert_to_equalities(c, A, b, G, h)
+
+
+def gen_eqlp():
+    """The reference's own O(m^4) column search (simplex.go:611-637) and pivot loop on the two large equality LPs: start basis,
+    pivot trace, final basis, x and z bits."""
+    O.set_threads(THREADS)
+    for seed, n, m in EQLP_CASES:
+        c0, A0, b0 = eqlp_problem(seed, n, m)
+        t0 = time.time()
+        start = O.find_linearly_independent(A0)
+        log("EQLP", 2 * m, "rows: column search", "%.0f s" % (time.time() - t0))
+        r = O.simplex(c0, A0, b0, 0.0, None, trace=True)
+        dt = time.time() - t0
+        tr = trace_array(r.pivots)
+        fn = os.path.join(OUT, "lp_EQ%d.npz" % (2 * m))
+        np.savez_compressed(
+            fn, seed=seed, n=n, m=m, status=r.status, start_basis=np.array(start, np.int32), trace=tr, trace_sha256=trace_sha(tr),
+            basis=np.zeros(0, np.int32) if r.basis is None else r.basis.astype(np.int32), x=np.zeros(0) if r.x is None else r.x,
+            z=r.z, pivots_phase1=r.pivots_phase1, pivots_phase2=r.pivots_phase2, bland_steps=r.bland_steps, oracle_seconds=dt,
+            oracle_threads=THREADS)
+        log("wrote", fn, "status", r.status, "pivots", len(tr), "%.0f s" % dt)
+
+
 def main(argv):
     os.makedirs(OUT, exist_ok=True)
     O.build()
@@ -223,6 +257,8 @@ def main(argv):
             gen_c1()
         elif t == "eq":
             gen_eq()
+        elif t == "eqlp":
+            gen_eqlp()
         else:
             raise SystemExit("unknown target " + t)
     return 0

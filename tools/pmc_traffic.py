@@ -24,9 +24,12 @@ with open("profiles/%s_pmc_counters.csv" % tag, "w") as out:
     out.write("kernel,launches,FETCH_SIZE_mean_KB_raw,WRITE_SIZE_mean_KB\n")
     for k, n, fk, wk in rows: out.write('"%s",%d,%.3f,%.3f\n' % (k, n, fk, wk))
 m, nn = 2048, 2048
-alg = {"k_bt_update_mfma16": 16.0 * m * nn, "k_bt_innerG<8, 256": 16 * 16.0 * (m + nn) + 24.0 * (m + nn)}
+alg = {"k_bt_loop": 64 * (16.0 * m * nn + 8 * 16.0 * (m + nn) + 24.0 * (m + nn)), "k_bt_update_mfma16": 16.0 * m * nn, "k_bt_innerG<8, 256": 16 * 16.0 * (m + nn) + 24.0 * (m + nn)}
 docs = []
-for key, note in (("k_bt_update_mfma16", "streaming rank-16 update on the matrix cores: 8-byte loads / stores, 512 contiguous bytes per instruction"),
+for key, note in (("k_bt_loop", "persistent loop kernel, mean over the FULL launches (64 blocks of 8 pivots: the rank-8 update reads and writes the 33.6 MB tableau once "
+                                "per block, 16-byte agent-scope accesses; the pivot workgroups add one column + one row per pivot and the exchange records).  The tableau "
+                                "pair (67 MB) lives in the 256 MB Infinity Cache between blocks, so FETCH_SIZE / WRITE_SIZE (traffic at the fabric) can sit below the algorithmic bytes"),
+                  ("k_bt_update_mfma16", "streaming rank-16 update on the matrix cores: 8-byte loads / stores, 512 contiguous bytes per instruction"),
                   ("k_bt_innerG<8, 256", "block kernel, 8 workgroups of one XCD: 8-byte reads of 128-byte tile lines (one column + one row of T per pivot) + the exchange records; FETCH_SIZE is "
                                        "UNCALIBRATED for this shape (MI355X_MICROARCH.md: only wide coalesced reads are known to report 1/2) — the x2 figure is an upper bound"),
                   ("k_bt_inner2_batch", "batched block kernel (C5 wave): mean over launches with 1..256 active relaxations"),
@@ -52,9 +55,10 @@ if mfma_csv:
         perk[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     docs.append({"kernel": "(all kernels of the run)", "mfma_counters_sum": dict(tot)})
     for k, cs in perk.items():
-        if "k_bt_update_mfma16" in k:
+        if "k_bt_update_mfma16" in k or "k_bt_loop" in k:
             big = {c: [x for x in v if x > 0.5 * max(v)] or v for c, v in cs.items()}
             docs.append({"kernel": k, "mfma_counters_mean_per_launch": {c: sum(v) / len(v) for c, v in big.items()},
-                         "note": "rank-16 update of T: (m/16) * ((n-m)/16) * 4 v_mfma_f64_16x16x4_f64 per launch"})
+                         "note": "rank-16 update of T: (m/16) * ((n-m)/16) * 4 v_mfma_f64_16x16x4_f64 per launch" if "mfma16" in k else
+                                 "rank-8 update per block: (m/16) * ((n-m)/16) * 2 v_mfma_f64_16x16x4_f64, 64 blocks per full launch"})
 json.dump(docs, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
 print(json.dumps(docs, indent=1))
