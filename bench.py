@@ -75,7 +75,7 @@ def newest_pmc(kernel_substr):
         except Exception:
             continue
         for ent in (doc if isinstance(doc, list) else [doc]):
-            if kernel_substr in ent.get("kernel", ""):
+            if kernel_substr in ent.get("kernel", "") and ent.get("traffic_bytes_per_launch") is not None:
                 best = (ent.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT))
     return best or (None, None)
 
@@ -404,7 +404,7 @@ def main() -> int:
         if t_upd <= 0 and need > 1024:
             # persistent loop kernel: ONE kernel carries the whole pivot loop — the pivot workgroups' chain and, beside it, the
             # update workgroups' streaming pass over the tableau (read + written once per block of K = 8 pivots)
-            loop_name = "k_bt_loop<8,256,1,8>" if need <= 2048 else "k_bt_loop<16,256,1,16>"
+            loop_name = "k_bt_loop<16,128,1,8>" if need <= 2048 else "k_bt_loop<16,256,1,16>"
             traffic, tsrc = newest_pmc("k_bt_loop")
             bytes_block = bytes_inner + bytes_update
             bpl = 512.0 / K   # sampled launches are full ones: loop_chunk (512 pivots) / K blocks
@@ -417,7 +417,7 @@ def main() -> int:
                 "bytes_per_block": bytes_block, "block_us": 1e6 * t_inner, "us_per_pivot": 1e6 * t_inner / K, "pivots_per_block": K,
                 "limited_by": "the pivot workgroups' dependent-latency chain (two exchanges + two tableau reads per pivot), not by bandwidth: "
                               "the update workgroups finish a block's %.0f MB in less than the chain needs for its 8 pivots" % (bytes_update / 1e6),
-                "note": "persistent kernel, one workgroup per CU or fewer: 8 pivot workgroups on one XCD run the blocks (two exchanges through that XCD's L2 and two "
+                "note": "persistent kernel, one workgroup per CU or fewer: 16 pivot workgroups on one XCD run the blocks (two exchanges through that XCD's L2 and two "
                         "dependent tableau reads per pivot: the latency chain that sets the pace), the other workgroups apply the rank-8 update of block t "
                         "(tableau read + written once, matrix cores) beside block t+1.  achieved = algorithmic bytes per block (16 m (n-m) update + the pivot "
                         "workgroups' columns, rows and terms) x 64 blocks of a full launch / HIP-event time of that launch (only full launches are sampled; "
