@@ -60,9 +60,11 @@ __device__ __forceinline__ unsigned int tile_off_g(unsigned int i, unsigned int 
 // exchange over 16 placements in tools/xsync_bench.hip, which showed up as 68 vs 78 us per launch from one process to the
 // next).  FAST, used once the workgroups have seen that they share one XCD: plain stores (write-through L1 -> that XCD's
 // L2, the coherence point of its CUs) and nt loads (never served by L1) — 1860-1920 cycles at every placement.
+// (the strings end in s_nop 1: the compiler pads nothing after an asm statement, and its next instruction may overwrite the data
+// registers of a 16-byte store before the store has read them)
 __device__ __forceinline__ void xstore(xpair *p, xpair v, bool fast) {
-    if (fast) asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    if (fast) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 template <int H> struct XLoad;
 template <> struct XLoad<1> {

@@ -208,6 +208,14 @@ int64_t Engine::upload(const double *c, const double *A, int64_t lda, const doub
     P->allone.assign(hs.begin() + 2 * n, hs.begin() + 3 * n);
     P->hb.assign(b, b + m);
     P->hc.assign(c, c + n);
+    {   // spread of the entries: badly scaled inputs take the careful path (Engine::make_bt_args)
+        double amax = 0, amin = std::numeric_limits<double>::infinity();
+        for (int i = 0; i < m; i++) {
+            const double *row = A + (size_t)i * lda;
+            for (int j = 0; j < n; j++) { const double v = fabs(row[j]); if (v > amax) amax = v; if (v != 0 && v < amin) amin = v; }
+        }
+        P->scale_span = (amax > 0 && amin <= amax) ? amax / amin : 1.0;
+    }
     if ((size_t)m * n <= ((size_t)1 << 25)) {  // up to 256 MB: keep A for the general initial-basis path (equality rows, supplied basis)
         P->hA.resize((size_t)m * n);
         for (int i = 0; i < m; i++) memcpy(&P->hA[(size_t)i * n], A + (size_t)i * lda, sizeof(double) * (size_t)n);
@@ -328,6 +336,7 @@ int64_t Engine::upload_child_impl(const Problem &R, int64_t root, int K, const i
     }
     // the host copy of [[A0, 0], [G#, I]] is only needed when a solve starts from a non-slack basis: built on demand
     P->hA.clear();
+    P->scale_span = R.scale_span;
     P->root = root;
     P->root_ptr = &R;   // (a root resident in another engine of the pool: `root` is -1, the owner keeps it alive)
     P->kvar.assign(var, var + K);
@@ -1041,6 +1050,7 @@ int Engine::solve_locked(int64_t id, double tol, const int64_t *initial_basic, d
         }
     }
     gen_start_ = !unit_basis;
+    badly_scaled_ = P.scale_span > 1e9;
     const int nn_max = n + 1 - m;
     // a non-slack starting basis (equality rows, supplied basis) always takes the tableau pipelines: their set-up accepts
     // any B^-1; the n - m < 2m rule is only the bytes-per-pivot trade-off between the two formulations
@@ -1321,7 +1331,7 @@ bool Engine::root_view(int64_t id, RootView *out) {
     if (id < 0 || (size_t)id >= problems_.size() || !problems_[id]) return false;
     const Problem &P = *problems_[id];
     out->m = P.m; out->n = P.n; out->ld = P.ld; out->dAt = P.dAt; out->dc = P.dc; out->db = P.db;
-    out->verify_status = P.verify_status; out->serial = P.serial; out->hb = P.hb; out->hc = P.hc;
+    out->verify_status = P.verify_status; out->serial = P.serial; out->hb = P.hb; out->hc = P.hc; out->scale_span = P.scale_span;
     out->rho0.assign(P.m, 0);
     out->unit_basis = P.m < P.n;
     std::vector<char> used(P.m, 0);

@@ -31,6 +31,7 @@ struct Problem {
     uint64_t serial = 0;      // unique per upload (device buffers are recycled: a pointer does not identify a problem)
     // children are recycled: their device buffers go back to a per-engine pool instead of hipFree (which synchronises
     // the whole device and would serialise the worker streams of a frontier pool)
+    double scale_span = 1.0;  // max |a_ij| / min nonzero |a_ij| of A: beyond 1e9 the solve keeps the degenerate-pivot guard on at every size
     bool is_child = false;
     size_t cap_at = 0, cap_c = 0, cap_b = 0;    // capacities in doubles
     int32_t *dvar = nullptr;                    // child: branched variables / signs on the device
@@ -70,6 +71,7 @@ class Engine {
     struct RootView {
         int m = 0, n = 0, ld = 0;
         const double *dAt = nullptr, *dc = nullptr, *db = nullptr;
+        double scale_span = 1.0;          // Problem::scale_span of the root
         bool unit_basis = false;          // the descending scan of simplex.go:618-635 meets m distinct unit columns
         std::vector<int32_t> rho0;        // their rows, by basis position
         int verify_status = GOMILP_OK;
@@ -127,6 +129,7 @@ class Engine {
                     bool transpose = false, const double *rhs_host = nullptr);
     // one iteration of the reference on fresh solves (engine_tableau.cpp): the decision a degenerate or tied pivot needs
     int exact_step(const Problem &P, int phase, double tol, int nn, int *q_out, int *p_out, gomilp_lp_stats *st);
+    int cond_check(const Problem &P, int nn, double *k1, double *kinf);
     bool ensure_host_A(const Problem &P);
     // findLinearlyIndependent with the scan on the device (general_kernels.hip) and the last, square step on the host
     int find_independent_device(const Problem &P, std::vector<int32_t> &basic, std::vector<double> *binv_out);
@@ -158,6 +161,7 @@ class Engine {
             loop_k_ = 0,       // its pivots per block (0: 8 up to 2048 rows, 16 beyond; 8 / 16 forced where instantiated)
             exact_degenerate_ = 1,   // 0 never, 1 bases of up to 256 rows and every non-slack start, 2 always: pivots whose winning ratio is (nearly) zero are decided on a fresh gonum-order x_B
             cond_guard_ = 1;   // replay the condition guards of the reference on the host for bases of up to 64 rows
+    bool badly_scaled_ = false;   // the current problem's entries span more than nine decades (Problem::scale_span): guard on, tableau checked
     bool gen_start_ = false;      // the current solve starts from a searched (non-slack) basis: the degenerate-pivot guard stays on
     bool xchg_timeout_ = false;   // the last pivot loop ended in ST_XCHG_TIMEOUT (Engine::solve repeats the solve once)
     bool shadow_trace_ = false;   // this solve records its pivots for the replay even when the caller did not ask for a trace   // developer knobs of the block kernels (per context: tests force the 1024-thread instance)
@@ -185,6 +189,8 @@ bool general_basis_inverse(const std::vector<double> &A, int m, int n, const std
 int general_condition_replay(const std::vector<double> &A, int m, int n, std::vector<int32_t> &basic, const std::vector<std::pair<int, int>> &pivots,
                              bool ended_in_compute_move, int *status_out, int64_t *evaluations);
 double general_cond_inf(const std::vector<double> &A, int n);
+bool general_invert(const std::vector<double> &B, int m, std::vector<double> &inv);
+double inverse_norm1_estimate(const std::vector<double> &M, int n, bool transposed);
 double general_basis_cond1(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, const std::vector<double> &art);
 bool general_solve_basis(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, const std::vector<double> &b, std::vector<double> &x);
 
@@ -215,6 +221,8 @@ void launch_tab_r(const double *T, int ldt, int m, int nn, const double *cost, c
                   double *scratch, double *r, bool tiled, hipStream_t s);
 void launch_tab_row_colmax(const double *T, int ldt, int m, int nn, int row, double *out, bool tiled, hipStream_t s);
 void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb, double *dvec, double *move, bool tiled, hipStream_t s);
+void launch_cond_check(const double *T, int ldt, int m, int nn, const int32_t *nonbasic, const int32_t *basic, const double *At, int ld, int slack0, int nvar,
+                       double *scratch, bool tiled, hipStream_t s);
 void launch_exact_r(const double *At, int ld, int m, int nn, const int32_t *nonbasic, const double *y, const double *cost, double *r, int ldt, hipStream_t s);
 // general_kernels.hip
 void launch_gs_init(double *QT, int ldq, int m, GsState *st, hipStream_t s);

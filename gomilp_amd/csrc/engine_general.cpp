@@ -303,6 +303,8 @@ bool general_basis_inverse(const std::vector<double> &A, int m, int n, const std
     return invert_threaded(B, m, binv);
 }
 
+bool general_invert(const std::vector<double> &B, int m, std::vector<double> &inv) { return invert_threaded(B, m, inv); }
+
 // exact kappa_1 of a basis (columns `basic` of A, the artificial column `art` standing for index n): the trial bases of the Bland
 // rule (simplex.go:374-379: mat.Cond(abTmp, 1) < 1e16; the reference has Dgecon's estimate of the same number)
 double general_basis_cond1(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, const std::vector<double> &art) {
@@ -360,6 +362,52 @@ int general_condition_replay(const std::vector<double> &A, int m, int n, std::ve
         conds(k1, kinf);
         if (kinf > lim || kinf != kinf) { *status_out = GOMILP_ERR_CONDITION; return (int)t + 1; } // x_B of the new basis, :289-292
     }
+}
+
+// Hager / Higham estimate of the 1-norm of M (transposed = false) or of M^T (true) for an explicitly given n x n matrix M — the
+// iteration LAPACK's dlacn2 drives (published algorithm: Higham, "FORTRAN codes for estimating the one-norm of a real or complex
+// matrix", ACM TOMS 14, 1988; gonum: lapack/gonum/dlacn2.go): start from the uniform vector, follow the sign vector's gradient
+// through at most five products with M and M^T, then compare with the alternating-sign probe.  Engine::cond_check hands it
+// B^-1, so the value is what gonum's Dgecon reports for the basis up to the rounding of the products.
+double inverse_norm1_estimate(const std::vector<double> &M, int n, bool transposed) {
+    if (n <= 0) return 0.0;
+    std::vector<double> x(n), y(n), z(n);
+    std::vector<int> sgn(n);
+    auto mul = [&](const std::vector<double> &in, std::vector<double> &out, bool tr) {   // out = M in (tr: M^T in), `transposed` swaps the two
+        const bool t = tr != transposed;
+        std::fill(out.begin(), out.end(), 0.0);
+        if (!t) { for (int i = 0; i < n; i++) { double s2 = 0; const double *row = &M[(size_t)i * n]; for (int j = 0; j < n; j++) s2 += row[j] * in[j]; out[i] = s2; } }
+        else { for (int i = 0; i < n; i++) { const double xi = in[i]; if (xi == 0) continue; const double *row = &M[(size_t)i * n]; for (int j = 0; j < n; j++) out[j] += row[j] * xi; } }
+    };
+    auto asum = [&](const std::vector<double> &v) { double s2 = 0; for (double e : v) s2 += fabs(e); return s2; };
+    auto amax = [&](const std::vector<double> &v) { int best = 0; for (int i = 1; i < n; i++) if (fabs(v[i]) > fabs(v[best])) best = i; return best; };
+    for (int i = 0; i < n; i++) x[i] = 1.0 / n;
+    mul(x, y, false);
+    if (n == 1) return fabs(y[0]);
+    double est = asum(y);
+    for (int i = 0; i < n; i++) { sgn[i] = std::signbit(y[i]) ? -1 : 1; x[i] = sgn[i]; }
+    mul(x, z, true);
+    int j = amax(z);
+    for (int iter = 2;; iter++) {
+        std::fill(x.begin(), x.end(), 0.0);
+        x[j] = 1.0;
+        mul(x, y, false);
+        const double estold = est;
+        est = asum(y);
+        bool same = true;
+        for (int i = 0; i < n; i++) if ((std::signbit(y[i]) ? -1 : 1) != sgn[i]) { same = false; break; }
+        if (same || est <= estold) break;
+        for (int i = 0; i < n; i++) { sgn[i] = std::signbit(y[i]) ? -1 : 1; x[i] = sgn[i]; }
+        mul(x, z, true);
+        const int jlast = j;
+        j = amax(z);
+        if (!(z[jlast] != fabs(z[j]) && iter < 5)) break;
+    }
+    double alt = 1.0;
+    for (int i = 0; i < n; i++) { x[i] = alt * (1.0 + (double)i / (double)(n - 1)); alt = -alt; }
+    mul(x, y, false);
+    const double probe = 2.0 * asum(y) / (double)(3 * n);
+    return probe > est ? probe : est;
 }
 
 // exact kappa_inf of a square matrix (m == n path: any Condition of the single solve becomes lp.ErrSingular, simplex.go:109-112)

@@ -234,7 +234,8 @@ BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int
     // degenerate vertices decided on a fresh gonum-order x_B: by default for bases of up to 256 rows, and for
     // every start that is not a slack basis (equality rows: a tree's repeated branch rows make nearly dependent tableau rows
     // there, and a pivot on their 1e-12 drift walks into a singular basis)
-    a.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && (P.m <= 256 || gen_start_))) ? 1e-9 : 0.0;
+    // (and for inputs whose entries span more than nine decades: their updated tableau loses digits, the exact steps check and rebuild it)
+    a.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && (P.m <= 256 || gen_start_ || badly_scaled_))) ? 1e-9 : 0.0;
     if (a.tiled && !bt_old_) {
         const BtGroupCfg gc = bt_group_cfg(P.m, ldt_, (int)bt_groups_);
         a.groups = gc.groups; a.group_ri = gc.ri; a.group_nt = gc.nt; a.xbuf = w.xbuf;
@@ -275,6 +276,16 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
         for (int i = 0; i < m; i++) basic[i] = w.h_idx[i];
         for (int j = 0; j < nn; j++) nonbasic[j] = w.h_idx[gap + j];
     }
+    // gonum's guards on the solves of this iteration (mat/lu.go:321: cond > 1e16 -> mat.Condition out of the duals' solve,
+    // simplex.go:236-239; lp.ErrLinSolve out of computeMove, :316-318): the tableau of a slack-basis start holds B^-1, so the exact
+    // kappa_1 / kappa_inf of the current basis cost three small launches (cond_check) — every exact step measures them
+    if (cond_guard_ && phase == 2 && !gen_start_ && m > 64) {
+        double k1 = 0, kinf = 0;
+        int rc0 = cond_check(P, nn, &k1, &kinf);
+        if (rc0 != GOMILP_OK) return -rc0;
+        if (k1 > 1e16 || k1 != k1) return -GOMILP_ERR_CONDITION;
+        if (kinf > 1e16 || kinf != kinf) return -GOMILP_ERR_LINSOLVE;
+    }
     auto cost = [&](int var) -> double { return phase == 1 ? (var == n ? 1.0 : 0.0) : (var < n ? P.hc[var] : 0.0); };
     std::vector<double> cb(m), y, xb, dsol, col(m);
     for (int i = 0; i < m; i++) cb[i] = cost(basic[i]);
@@ -310,6 +321,33 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
     for (int i = 0; i < m; i++) col[i] = w.h_vec[i];
     if ((rc = final_solve(P, n, dsol, &sing, basic.data(), false, col.data())) != GOMILP_OK) return -rc;
     if (sing) return -GOMILP_ERR_LINSOLVE;
+    // Accuracy of the resident tableau: its column q against the fresh one.  On badly scaled LPs (entries over 1e19) the updated
+    // tableau loses digits within a few hundred pivots, its ratio tests then leave the reference's path and may never end; beyond
+    // 1e-6 of the column's size the tableau is rebuilt from a fresh inverse of the basis (B^-1 on the host, T = B^-1 A_N as one
+    // device GEMM: the set-up of a general start), up to 1024 rows
+    if (m <= 1024) {
+        launch_tab_column(w.T[tcur_], ldt_, m, (int)q, w.xb, w.dvec, w.move, t_tiled_, stream_);
+        launches_++;
+        HIP_TRY(hipMemcpyAsync(w.h_vec, w.dvec, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(sync_stream());
+        double scale = 0, err = 0;
+        for (int i = 0; i < m; i++) { scale = std::max(scale, fabs(dsol[i])); err = std::max(err, fabs(w.h_vec[i] - dsol[i])); }
+        if (!(err <= 1e-6 * scale)) {
+            std::vector<double> cols((size_t)m * P.ld), B((size_t)m * m), inv;
+            for (int p = 0; p < m; p++)
+                HIP_TRY(hipMemcpyAsync(&cols[(size_t)p * P.ld], P.dAt + (size_t)basic[p] * P.ld, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(sync_stream());
+            for (int i = 0; i < m; i++) for (int p = 0; p < m; p++) B[(size_t)i * m + p] = cols[(size_t)p * P.ld + i];
+            if (!general_invert(B, m, inv)) return -GOMILP_ERR_LINSOLVE;
+            HIP_TRY(hipMemcpy2DAsync(w.binv[0], (size_t)P.ld * sizeof(double), inv.data(), (size_t)m * sizeof(double), (size_t)m * sizeof(double), m,
+                                     hipMemcpyHostToDevice, stream_));
+            HIP_TRY(sync_stream());   // (pageable source)
+            launch_tab_gemm(w.binv[0], P.ld, P.dAt, P.ld, m, nn, w.nonbasic, w.T[tcur_], ldt_, t_tiled_, stream_);
+            launches_++;
+            if (st) st->refreshes++;
+            if (getenv("GOMILP_DEBUG_LOOP")) fprintf(stderr, "exact_step: tableau rebuilt (column error %.3g of %.3g, m %d)\n", err, scale, m);
+        }
+    }
     std::vector<double> move(m);
     bool anyneg = false;
     for (int i = 0; i < m; i++) {
@@ -320,7 +358,9 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
     }
     if (!anyneg) return 2;                      // :328-330
     const int64_t p = min_idx(move.data(), m);  // :268
-    if (!(move[p] <= 0)) { *q_out = (int)q; *p_out = (int)p; return 0; }
+    if (!(move[p] <= 0)) {
+        *q_out = (int)q; *p_out = (int)p; return 0;
+    }
     // ---- :269 -> replaceBland (:347-383) on the same fresh quantities: candidates in position order with r <= -1e-14 after the
     // rounding of :252-256, each with its own computeMove; a zero-level row is only taken when the basis it gives is not
     // singular (mat.Cond(abTmp, 1) < 1e16 — here the exact kappa_1 on the host copy of A: the device Bland rule has no such test
@@ -778,6 +818,65 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
     launch_tab_r(w.T[tcur_], ldt_, m, nn, P.dc, w.basic, w.nonbasic, w.tscratch, w.R[rcur_], t_tiled_, stream_);
     launches_ += 2;
     *loop_rc = use_bt_ ? run_loop_bt(P, 2, tol, nn, st) : run_loop_tab(P, 2, tol, nn, st);
+    // gonum's condition guard on the basis the loop ends with (mat/lu.go:321 through simplex.go:236-239: the duals' solve of the
+    // iteration that finds the optimum reports mat.Condition when cond > 1e16 and the loop leaves with the current point): exact
+    // kappa_1 from the tableau for slack-basis starts of any size (bases of up to 64 rows have the pivot-by-pivot replay instead)
+    if (*loop_rc == GOMILP_OK && cond_guard_ && !binv_host && m > 64) {
+        double k1 = 0, kinf = 0;
+        if ((rc = cond_check(P, nn, &k1, &kinf)) != GOMILP_OK) return rc;
+        st->cond1_final = k1; st->condinf_final = kinf;
+        if (k1 > 1e16 || k1 != k1) *loop_rc = GOMILP_ERR_CONDITION;
+    }
+    return GOMILP_OK;
+}
+
+// exact kappa_1 / kappa_inf of the current basis from the resident tableau (tableau_kernels.hip: launch_cond_check); 0 when the work
+// buffers are too small for the sums (never for the shapes the tableau pipelines take)
+int Engine::cond_check(const Problem &P, int nn, double *k1, double *kinf) {
+    Work &w = *w_;
+    *k1 = *kinf = 0.0;
+    const size_t need = (size_t)ldt_ + 3 * (size_t)P.ld + 4;
+    if (need > (size_t)64 * w.cap_ldt) return GOMILP_OK;
+    launch_cond_check(w.T[tcur_], ldt_, P.m, nn, w.nonbasic, w.basic, P.dAt, P.ld, P.n - P.m, P.n, w.tscratch, t_tiled_, stream_);
+    launches_ += 3;
+    HIP_TRY(hipMemcpyAsync(w.h_vec, w.tscratch + (size_t)ldt_ + 3 * (size_t)P.ld, 4 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(sync_stream());
+    const double b1 = w.h_vec[0], binf = w.h_vec[2];
+    *k1 = b1 * w.h_vec[1];
+    *kinf = binf * w.h_vec[3];
+    if (!(*k1 > 1e16) && !(*kinf > 1e16)) return GOMILP_OK;   // (NaN: stays NaN — mat.Cond propagates it)
+    // Beyond the threshold (rare) the verdict is taken on a FRESH inverse of the basis on the host — on badly scaled LPs the updated
+    // tableau itself has lost digits (seen: 8.6e16 from the tableau where the basis has 1.9e13) — and with the reference's own
+    // number: gonum measures cond with Dgecon's Hager / Higham estimate of |B^-1| (lapack/gonum/dgecon.go:26-81,
+    // dlacn2.go:24-136), a lower bound of the exact norm within a small factor.
+    const int m = P.m;
+    std::vector<int32_t> basic(m);
+    HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(sync_stream());
+    for (int i = 0; i < m; i++) basic[i] = w.h_idx[i];
+    std::vector<double> cols((size_t)m * P.ld), B((size_t)m * m), inv;
+    for (int p = 0; p < m; p++)
+        HIP_TRY(hipMemcpyAsync(&cols[(size_t)p * P.ld], P.dAt + (size_t)basic[p] * P.ld, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(sync_stream());
+    for (int i = 0; i < m; i++) for (int p = 0; p < m; p++) B[(size_t)i * m + p] = cols[(size_t)p * P.ld + i];
+    const double tk1 = *k1, tkinf = *kinf;
+    if (!general_invert(B, m, inv)) { *k1 = *kinf = std::numeric_limits<double>::infinity(); return GOMILP_OK; }
+    double n1 = 0, ninf = 0, i1 = 0, iinf = 0;
+    {
+        std::vector<double> cb(m, 0.0), ci(m, 0.0);
+        for (int i = 0; i < m; i++) {
+            double rb = 0, ri = 0;
+            for (int p = 0; p < m; p++) { const double vb = fabs(B[(size_t)i * m + p]), vi = fabs(inv[(size_t)i * m + p]); rb += vb; ri += vi; cb[p] += vb; ci[p] += vi; }
+            ninf = std::max(ninf, rb); iinf = std::max(iinf, ri);
+        }
+        for (int p = 0; p < m; p++) { n1 = std::max(n1, cb[p]); i1 = std::max(i1, ci[p]); }
+    }
+    *k1 = n1 * i1; *kinf = ninf * iinf;
+    if (*k1 > 1e16 || *kinf > 1e16) {
+        *k1 = n1 * inverse_norm1_estimate(inv, m, false);
+        *kinf = ninf * inverse_norm1_estimate(inv, m, true);
+    }
+    if (getenv("GOMILP_DEBUG_LOOP")) fprintf(stderr, "cond_check: m %d tableau kappa_1 %.6g kappa_inf %.6g -> fresh %.6g %.6g\n", m, tk1, tkinf, *k1, *kinf);
     return GOMILP_OK;
 }
 

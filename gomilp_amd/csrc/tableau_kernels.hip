@@ -408,6 +408,93 @@ void launch_exact_r(const double *At, int ld, int m, int nn, const int32_t *nonb
     hipLaunchKernelGGL(k_exact_r, dim3((unsigned int)((ldt + 255) / 256)), dim3(256), 0, s, At, ld, m, nn, nonbasic, y, cost, r, ldt);
 }
 
+// ---- condition numbers of the current basis from the tableau (gonum's LU.Solve guards, mat/lu.go:301,321) -------------------------
+// A standard form that starts from its slack basis carries B^-1 inside the tableau: the columns of B^-1 are the tableau columns of the m
+// identity (slack) variables [slack0, nvar) — column j of T for one that is nonbasic at position j, the unit vector e_p for one that is
+// basic at position p.  So |B^-1|_1 and |B^-1|_inf are a column-sum / row-sum pass over T, and |B|_1, |B|_inf one over the m basic columns
+// of A: the EXACT kappa_1 and kappa_inf of any basis, at any size, for two passes of the tableau's size (the reference has gonum's Dgecon
+// estimate of the same numbers).
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// grid (ceil(ldt / 64), ceil(m / 64)), block (64, 4): thread (x, y) = column x of the block, rows y * 16 .. y * 16 + 15
+__global__ __launch_bounds__(256) void k_cond_tab(const double *__restrict__ T, int ldt, int m, int nn, const int32_t *__restrict__ nonbasic, int slack0,
+                                                  int nvar, double *__restrict__ colsum, double *__restrict__ rowsum, int tiled) {
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i0 = blockIdx.y * 64 + threadIdx.y * 16;
+    bool on = false;
+    if (j < nn) { const int var = nonbasic[j]; on = var >= slack0 && var < nvar; }
+    double cs = 0.0;
+    for (int r = 0; r < 16; r++) {
+        const int i = i0 + r;
+        const double v = (on && i < m) ? fabs(T[tab_idx(i, j, ldt, tiled)]) : 0.0;
+        cs += v;
+        const double rs = wave_sum_f64(v);   // the 64 lanes of a wave are 64 columns of row i
+        if (threadIdx.x == 0 && i < m) atomicAdd(rowsum + i, rs);
+    }
+    if (on) atomicAdd(colsum + j, cs);
+}
+// grid (ceil(m / 64), ceil(m / 64)), block (64, 4): thread (x, y) = row x of the block's row chunk, basic positions y * 16 .. + 15 of its
+// column chunk; At is column-major A, so the lanes of a wave read 64 consecutive doubles
+__global__ __launch_bounds__(256) void k_cond_basis(const double *__restrict__ At, int ld, int m, const int32_t *__restrict__ basic, double *__restrict__ colsumB,
+                                                    double *__restrict__ rowsumB) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int p0 = blockIdx.y * 64 + threadIdx.y * 16;
+    double rs = 0.0;
+    for (int r = 0; r < 16; r++) {
+        const int p = p0 + r;
+        const double v = (p < m && i < m) ? fabs(At[(size_t)basic[p] * ld + i]) : 0.0;
+        rs += v;
+        const double cs = wave_sum_f64(v);
+        if (threadIdx.x == 0 && p < m) atomicAdd(colsumB + p, cs);
+    }
+    if (i < m) atomicAdd(rowsumB + i, rs);
+}
+// one workgroup: out = {|B|_1, |B^-1|_1, |B|_inf, |B^-1|_inf}; a NaN anywhere makes the norm NaN (mat.Norm / mat.Cond propagate it)
+__global__ __launch_bounds__(1024) void k_cond_finish(const double *__restrict__ colsum, const double *__restrict__ rowsum, const double *__restrict__ colsumB,
+                                                      const double *__restrict__ rowsumB, int m, int nn, const int32_t *__restrict__ basic, int slack0, int nvar,
+                                                      double *__restrict__ out) {
+    __shared__ double red[4][16];
+    __shared__ int s_nan;
+    if (threadIdx.x == 0) s_nan = 0;
+    __syncthreads();
+    double b1 = 0, i1 = 0, binf = 0, iinf = 0;
+    bool bad = false;
+    for (int j = threadIdx.x; j < nn; j += 1024) { const double v = colsum[j]; bad |= v != v; i1 = fmax(i1, v); }
+    for (int p = threadIdx.x; p < m; p += 1024) {
+        const bool slack = basic[p] >= slack0 && basic[p] < nvar;
+        const double c = colsumB[p], r = rowsumB[p], q = rowsum[p] + (slack ? 1.0 : 0.0);
+        bad |= c != c || r != r || q != q;
+        b1 = fmax(b1, c); binf = fmax(binf, r); iinf = fmax(iinf, q);
+        if (slack) i1 = fmax(i1, 1.0);
+    }
+    if (bad) s_nan = 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        b1 = fmax(b1, __shfl_xor(b1, o)); i1 = fmax(i1, __shfl_xor(i1, o)); binf = fmax(binf, __shfl_xor(binf, o)); iinf = fmax(iinf, __shfl_xor(iinf, o));
+    }
+    if (lane == 0) { red[0][wv] = b1; red[1][wv] = i1; red[2][wv] = binf; red[3][wv] = iinf; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double v = 0;
+        for (int w2 = 0; w2 < 16; w2++) v = fmax(v, red[threadIdx.x][w2]);
+        out[threadIdx.x] = s_nan ? __builtin_nan("") : v;
+    }
+}
+// scratch: colsum[ldt] | rowsum[ld] | colsumB[ld] | rowsumB[ld] | out[4] (zeroed here)
+void launch_cond_check(const double *T, int ldt, int m, int nn, const int32_t *nonbasic, const int32_t *basic, const double *At, int ld, int slack0, int nvar,
+                       double *scratch, bool tiled, hipStream_t s) {
+    double *colsum = scratch, *rowsum = colsum + ldt, *colsumB = rowsum + ld, *rowsumB = colsumB + ld, *out = rowsumB + ld;
+    hipMemsetAsync(scratch, 0, ((size_t)ldt + 3 * (size_t)ld + 4) * sizeof(double), s);
+    hipLaunchKernelGGL(k_cond_tab, dim3((unsigned int)((nn + 63) / 64), (unsigned int)((m + 63) / 64)), dim3(64, 4), 0, s, T, ldt, m, nn, nonbasic, slack0, nvar, colsum, rowsum,
+                       tiled ? 1 : 0);
+    hipLaunchKernelGGL(k_cond_basis, dim3((unsigned int)((m + 63) / 64), (unsigned int)((m + 63) / 64)), dim3(64, 4), 0, s, At, ld, m, basic, colsumB, rowsumB);
+    hipLaunchKernelGGL(k_cond_finish, dim3(1), dim3(1024), 0, s, colsum, rowsum, colsumB, rowsumB, m, nn, basic, slack0, nvar, out);
+}
+
 void launch_tab_column(const double *T, int ldt, int m, int jp, const double *xb, double *dvec, double *move, bool tiled, hipStream_t s) {
     hipLaunchKernelGGL(k_tab_column, dim3((m + 255) / 256), dim3(256), 0, s, T, ldt, m, jp, xb, dvec, move, tiled ? 1 : 0);
 }

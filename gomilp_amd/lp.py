@@ -39,6 +39,7 @@ class Stats(C.Structure):
         ("seconds_final_solve", C.c_double), ("drift_xb", C.c_double), ("pivot_kernel_seconds", C.c_double * 4),
         ("seconds_final_device", C.c_double), ("seconds_final_host", C.c_double), ("lu_dense_steps", C.c_int64),
         ("lu_rounds", C.c_int64), ("art_exchanges", C.c_int64), ("cond_fallbacks", C.c_int64), ("device_retries", C.c_int64),
+        ("cond1_final", C.c_double), ("condinf_final", C.c_double),
     ]
 
 

@@ -67,6 +67,8 @@ typedef struct gomilp_lp_stats {
     int64_t cond_fallbacks;      /* exact condition-number evaluations made because a cheap guard was near a threshold */
     int64_t device_retries;      /* 1 when a transient device condition (a workgroup of the multi-workgroup block kernel was not
                                     resident in time) made the engine repeat the solve on the single-workgroup kernels */
+    double cond1_final;          /* exact kappa_1 / kappa_inf of the basis the Phase-II loop ended with, from the resident tableau (slack-basis */
+    double condinf_final;        /* starts beyond 64 rows; 0: not evaluated): kappa_1 > 1e16 -> GOMILP_ERR_CONDITION like mat/lu.go:321 */
 } gomilp_lp_stats;
 
 /* One record per pivot, execution order (Phase I first).  Same fields as the oracle's trace. */
