@@ -525,7 +525,10 @@ def main() -> int:
         out["batched"] = {"concurrent_lps": len(roots), "pivots": int(pb), "seconds": tb, "pivots_per_s": pb / tb, "vs_single": pb / tb / value,
                           "all_ok": bool((resb.status == lp.OK).all()), "device_batched": int(resb.stats["batched_relaxations"]),
                           "host_round_trips": int(resb.stats["supersteps"]),
-                          "note": "independent %dx%d LPs (seeds +100..) in one device-batched schedule on one GPU (gomilp_frontier_solve_roots): k_bt_innerG_batch, one XCD per LP, + the batched MFMA rank-16 update" % (m, n)}
+                          "note": ("independent %dx%d LPs (seeds +100..) through gomilp_frontier_solve_roots on one GPU: " % (m, n)) +
+                                  ("the pool's workers run them on persistent loop kernels side by side (up to four launches share the device, each with its pivot "
+                                   "workgroups on an XCD of its own; device_batched = 0)" if int(resb.stats["batched_relaxations"]) == 0 else
+                                   "one device-batched schedule: k_bt_innerG_batch, one XCD per LP, + the batched MFMA rank-16 update")}
         poolb.close()
 
     # ---- BASELINE config 4: one solve of the 4096x8192 LP

@@ -816,9 +816,9 @@ __device__ __forceinline__ void bt_loop_update_role(const BTArgs &a, const int u
 // workgroup per CU (launch_bt_loop), and every wait is bounded.
 template <int G, int NT, int RI, bool STAMP = false, int KB = 8>
 __global__ __launch_bounds__(NT) void k_bt_loop(BTArgs a) {
-    const int b = (int)blockIdx.x, nupd = (int)gridDim.x - G;
-    if ((b & 7) == 0 && (b >> 3) < G) { bt_innerG_body<G, NT, RI, 2 * KB, STAMP, true>(a, b >> 3, nupd); return; }
-    const int before = min(G, (b + 7) >> 3);   // pivot blocks in front of block b
+    const int b = (int)blockIdx.x, nupd = (int)gridDim.x - G, x = a.xcd & 7;
+    if ((b & 7) == x && (b >> 3) < G) { bt_innerG_body<G, NT, RI, 2 * KB, STAMP, true>(a, b >> 3, nupd); return; }
+    const int before = b <= x ? 0 : min(G, ((b - x - 1) >> 3) + 1);   // pivot blocks in front of block b
     bt_loop_update_role<NT, KB>(a, b - before, nupd, G);
 }
 

@@ -143,7 +143,7 @@ struct BTArgs {
     // with 8 lagging + up to 8 current terms.  U / V rows [8 (t & 1), 8 (t & 1) + 8) take the terms of block t.
     double *Tbuf[2];
     int32_t loop, nblocks;
-    int32_t par, pad_p;   // launch parity (DevState::tsel2, and the counter bases in the exchange buffer's header)
+    int32_t par, xcd;     // launch parity; XCD of the pivot workgroups (blocks xcd, xcd + 8, ...: concurrent loop kernels take different ones)  // (DevState::tsel2, and the counter bases in the exchange buffer's header)
     // Degenerate vertices: the reference recomputes x_B from a fresh LU every pivot (simplex.go:289), so basic variables at level
     // zero carry that solve's rounding noise, and `move[replace] <= 0` (:269) as well as the argmin among several zero-level rows
     // are decided by it.  guard > 0: a block stops (ST_NEED_EXACT) in front of a pivot whose winning ratio is <= guard; the host

@@ -4,6 +4,7 @@
 // surfaces as GOMILP_ERR_DEVICE.
 #include "engine_work.hpp"
 
+#include <condition_variable>
 #include <atomic>
 
 namespace gomilp {
@@ -36,9 +37,35 @@ Engine::~Engine() {
     if (stream_) hipStreamDestroy(stream_);
 }
 
-std::mutex &Engine::loop_mutex(int dev) {
-    static std::mutex mu[64];
-    return mu[dev & 63];
+// Persistent loop kernels wait for their own workgroups, so every workgroup of a launch must be resident.  The 128-thread shape
+// (up to 2048 rows: 136 workgroups of two waves, four fit a CU) leaves room for four launches at once, each with its pivot
+// workgroups on an XCD of its own; the 256- / 512-thread shapes fill the chip (one workgroup per CU) and run alone.
+namespace {
+struct LoopSlots { std::mutex mu; std::condition_variable cv; int used = 0; bool busy[4] = {false, false, false, false}; };
+LoopSlots &loop_slots(int dev) { static LoopSlots s[64]; return s[dev & 63]; }
+}  // namespace
+int Engine::loop_acquire(int dev, int weight) {
+    LoopSlots &L = loop_slots(dev);
+    std::unique_lock<std::mutex> lk(L.mu);
+    if (weight >= 4) {
+        L.cv.wait(lk, [&] { return L.used == 0; });
+        L.used = 4;
+        for (bool &b2 : L.busy) b2 = true;
+        return 0;
+    }
+    L.cv.wait(lk, [&] { return L.used < 4; });
+    L.used++;
+    for (int i = 0; i < 4; i++) if (!L.busy[i]) { L.busy[i] = true; return i; }
+    return 0;
+}
+void Engine::loop_release(int dev, int weight, int slot) {
+    LoopSlots &L = loop_slots(dev);
+    {
+        std::lock_guard<std::mutex> lk(L.mu);
+        if (weight >= 4) { L.used = 0; for (bool &b2 : L.busy) b2 = false; }
+        else { L.used--; L.busy[slot & 3] = false; }
+    }
+    L.cv.notify_all();
 }
 
 int Engine::set(const std::string &key, int64_t v) {

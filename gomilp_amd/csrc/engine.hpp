@@ -48,7 +48,8 @@ class Engine {
     explicit Engine(int device);
     ~Engine();
     int device() const { return device_; }
-    static std::mutex &loop_mutex(int dev);   // one persistent loop kernel per device at a time (engine_tableau.cpp run_loop_bt)
+    static int loop_acquire(int dev, int weight);          // slots for persistent loop kernels on a device (engine.cpp): returns the slot
+    static void loop_release(int dev, int weight, int slot);
     int set(const std::string &key, int64_t v);
 
     int64_t upload(const double *c, const double *A, int64_t lda, const double *b, int64_t m, int64_t n);

@@ -411,8 +411,15 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
     // The persistent loop kernel needs all its workgroups resident (they wait for each other) and takes one slot on every CU:
     // one at a time per device.  Concurrent solves of large LPs queue up here for the duration of their pivot loops (set-up and
     // final solve still overlap); many large LPs at once belong in the device-batched schedule (gomilp_frontier_solve_roots).
-    std::unique_lock<std::mutex> loop_lock;
-    if (lag) loop_lock = std::unique_lock<std::mutex>(loop_mutex(device_));
+    struct LoopSlot {
+        int dev, weight, slot = -1;
+        LoopSlot(int d, int w2, bool on) : dev(d), weight(w2) { if (on) slot = Engine::loop_acquire(d, w2); }
+        ~LoopSlot() { if (slot >= 0) Engine::loop_release(dev, weight, slot); }
+    };
+    // (weight: the 128-thread shape shares the device with up to three others, every other shape runs alone — engine.cpp)
+    const bool small_loop = lag && K == 8 && loop_g_ != 8 && !bt_stamps_ && bt_group_cfg(P.m, ldt_, (int)bt_groups_).nt == 256;
+    LoopSlot loop_slot(device_, small_loop ? 1 : 4, lag);
+    const int loop_xcd = (small_loop && loop_slot.slot > 0) ? 2 * loop_slot.slot : 0;
     bt_layout(P, tiled_plan);
     // persistent loop kernel: DevState::tsel2 hands the buffer that holds the tableau from launch to launch
     hs.tsel2[0] = hs.tsel2[1] = tcur_; hs.kdone2[0] = hs.kdone2[1] = 0; hs.loop_blocks = 0;
@@ -467,6 +474,7 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
             // 11.47 ms against 11.85 ms per solve of the metric LP for 8 x 256)
             if (ai.groups == 8 && ai.group_nt == 256 && ai.group_ri == 1 && loop_g_ != 8 && K == 8 && !bt_stamps_) { ai.groups = 16; ai.group_nt = 128; }
             ai.Tbuf[0] = w.T[0]; ai.Tbuf[1] = w.T[1];
+            ai.xcd = loop_xcd;
             ai.exact_once = exact_pending ? 1 : 0; exact_pending = false;
             ai.forced_q = forced_q_pending; ai.forced_p = forced_p_pending; forced_q_pending = forced_p_pending = -1;
             hipEvent_t e0 = nullptr, e1 = nullptr;
