@@ -1078,13 +1078,11 @@ static void bt_launch_nt(const BTArgs &a, const BtCfg &c, bool reg, size_t lds, 
         if (c.ri == 2) {
             const size_t lds = lds2 + (size_t)VL2 * 8 * NT * sizeof(double);
             if (lds > 64 * 1024) {
-                static bool attr = false;
-                if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner2<NT, 2, 2, 8, VL2>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); attr = true; }
+                lds_attr_once(reinterpret_cast<const void *>(&k_bt_inner2<NT, 2, 2, 8, VL2>), 140 * 1024);
             }
             if (a.stamps) {
                 if constexpr (NT >= 512) {   // diagnostic build: the two instances the headline sizes run
-                    static bool attr2 = false;
-                    if (!attr2) { hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner2<NT, 2, 2, 8, VL2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); attr2 = true; }
+                    lds_attr_once(reinterpret_cast<const void *>(&k_bt_inner2<NT, 2, 2, 8, VL2, true>), 140 * 1024);
                     hipExtLaunchKernelGGL((k_bt_inner2<NT, 2, 2, 8, VL2, true>), dim3(1), dim3(NT), lds, s, e0, e1, 0, a);
                     return;
                 }
@@ -1106,11 +1104,9 @@ void launch_bt_inner_groups(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEv
 void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     if (a.groups > 0 && a.tiled) { launch_bt_inner_groups(a, s, e0, e1); return; }
     const size_t lds = (size_t)(a.ldt + a.ldu) * sizeof(double) + (size_t)(a.ldu + a.ldt) * sizeof(int);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner<1024, 4, 4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner<1024, 8, 8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-        attr_done = true;
+    if (lds > 64 * 1024) {
+        lds_attr_once(reinterpret_cast<const void *>(&k_bt_inner<1024, 4, 4, 0>), 140 * 1024);
+        lds_attr_once(reinterpret_cast<const void *>(&k_bt_inner<1024, 8, 8, 0>), 140 * 1024);
     }
     const BtCfg c = bt_cfg(a.m, a.ldt, a.nt_force);
     const bool reg = c.kreg > 0 && a.kmax <= c.kreg;
@@ -1142,8 +1138,7 @@ bool bt_batch_supported(int m_max, int ldt_max) {
 template <int NT, int RI, int VL>
 static void bt_inner_batch_nt(const BatchLP *lps, const int *ids, const int *count, int nlp, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const size_t lds = (size_t)(RI + RI) * NT * (sizeof(double) + sizeof(int)) + (size_t)VL * 8 * NT * sizeof(double);
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) { hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bt_inner2_batch<NT, RI, RI, 8, VL>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); attr = true; }
+    if (lds > 64 * 1024) lds_attr_once(reinterpret_cast<const void *>(&k_bt_inner2_batch<NT, RI, RI, 8, VL>), 140 * 1024);
     hipExtLaunchKernelGGL((k_bt_inner2_batch<NT, RI, RI, 8, VL>), dim3(nlp), dim3(NT), lds, s, e0, e1, 0, lps, ids, count);
 }
 // ids / count: the active list of the previous control step (device); nlp: an upper bound of *count the host knows

@@ -154,6 +154,7 @@ int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value) {
     if (std::string(key) == "split_large") { pool->split_large = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "large_loop") { pool->large_loop = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "sample_batch") { pool->batch->set_sampling(value != 0); return GOMILP_OK; }
+    if (std::string(key) == "cond_guard") pool->batch->set_cond_guard((int)value);
     if (std::string(key) == "exact_degenerate") pool->batch->set_exact_degenerate((int)value);   // (and the workers' engines below)
     int rc = GOMILP_OK;
     for (auto &e : pool->eng) { const int r = e->set(key, value); if (r != GOMILP_OK) rc = r; }

@@ -93,7 +93,8 @@ bool BatchEngine::eligible(const Engine::RootView &R, int K_max, bool phase1) co
     if (R.verify_status != GOMILP_OK || !(R.unit_basis || R.gen)) return false;
     const int m = R.m + K_max, n = R.n + K_max;
     if (m >= n || !((n - m) < 2 * m)) return false;              // the tableau formulation (engine.cpp: use_tab)
-    if (n + 2 > 8000) return false;                              // k_b_ctrl keeps two int lists of n in (default-limit) LDS
+    if (n + 2 > 7700) return false;                              // k_b_ctrl keeps two int lists of n in LDS next to ~3 KB of static arrays (64 KB limit)
+    if (cond_guard_ && m <= 64) return false;                    // bases of up to 64 rows: the pivot-by-pivot replay of gonum's condition guards runs in Engine::solve only
     const int ldt1 = batch_ldt(n - m + (phase1 ? 1 : 0));
     return bt_batch_supported(m, ldt1);
 }

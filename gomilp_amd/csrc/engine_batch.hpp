@@ -26,6 +26,7 @@ class BatchEngine {
         const char *inner_kernel = "";
     };
     void set_sampling(bool on) { sampling_ = on; }
+    void set_cond_guard(int v) { cond_guard_ = v; }   // as the engine knob of the same name
     void set_exact_degenerate(int v) { exact_degenerate_ = v; }   // as the engine knob of the same name
     // called on the thread that runs the wave as soon as child i is terminal; basic / xb (m_i entries, host memory, valid
     // until the next run) are non-null for BS_DONE children whose status needs the final solve
@@ -52,6 +53,7 @@ class BatchEngine {
     int device_;
     bool sampling_ = false;
     int exact_degenerate_ = 1;
+    int cond_guard_ = 1;
     hipStream_t stream_ = nullptr, copy_stream_ = nullptr;
     Buf *b_;
 };

@@ -288,12 +288,7 @@ template <int NV>
 static int launch_uf_fused_t(const LPArgs &a, int pending, int nparts_price, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const int g = grid_rows(a.m);
     if (NV == 32) {  // 2 x 32 KiB of staged vectors + the reduction scratch exceed the default 64 KiB dynamic-LDS cap
-        static bool once = false;
-        if (!once) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_update_ftran_fused<NV>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4096 * (int)sizeof(double));
-            once = true;
-        }
+        lds_attr_once(reinterpret_cast<const void *>(&k_update_ftran_fused<NV>), 2 * 4096 * (int)sizeof(double));
     }
     hipExtLaunchKernelGGL((k_update_ftran_fused<NV>), dim3(g), dim3(kBlock), (size_t)a.ld * 2 * sizeof(double), s, e0, e1, 0,
                           a, pending, nparts_price);

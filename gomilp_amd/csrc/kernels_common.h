@@ -5,7 +5,22 @@
 
 #include "device_types.h"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 namespace gomilp {
+
+// Raise a kernel's dynamic-LDS limit once per (device, kernel): the attribute is per device, and launches come from many host
+// threads (flat contexts, pool workers, the two batch schedules).
+inline void lds_attr_once(const void *fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    if (done.insert(std::make_pair(dev, fn)).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
 
 // ------------------------------------------------------------------------------------------------
 // helpers
