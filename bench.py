@@ -16,9 +16,9 @@ ranks (one process per GPU, device-batched pivot loops per rank), closed by ONE 
 through the C-ABI (gomilp_incumbent_allreduce); value = relaxations per second of the whole job, scaling "strong".
 
 Rank 0 prints ONE JSON line.  `roofline` prices the kernel with the largest share of GPU time in the timed region — the
-persistent loop kernel k_bt_loop (pivot workgroups + update workgroups in one launch; its pace is set by the pivot chain:
-`bound` says "latency") — by its algorithmic bytes per block of 8 pivots over its HIP-event time per block against the HBM
-peak; `roofline.loop` does the same with the wall time of the whole pivot loop (launch boundaries and host waits included).  `cpu_baseline` times the CPU oracle (the reference algorithm: 3 fresh LU per pivot) on a
+persistent loop kernel k_bt_loop (pivot workgroups + update workgroups in one launch) — by its algorithmic bytes per full launch
+(64 blocks of 8 pivots: the rank-8 update's pass over the tableau + the pivot workgroups' columns, rows and terms) over the
+HIP-event time of that launch against the HBM peak; `limited_by` names what sets its pace (the pivot chain, not bandwidth); `roofline.loop` does the same with the wall time of the whole pivot loop (launch boundaries and host waits included).  `cpu_baseline` times the CPU oracle (the reference algorithm: 3 fresh LU per pivot) on a
 bounded sample of the same workload on the host cores.
 """
 from __future__ import annotations
