@@ -293,7 +293,8 @@ def main() -> int:
             out["scaling_bound"] = {"heaviest_child": solo, "note": "a wave cannot finish before its heaviest child: relaxations/s at any GPU count "
                                     "<= %d / %.2f ms; more GPUs only remove what the other children add to that" % (len(children), 1e3 * solo["seconds_alone"]),
                                     "max_relaxations_per_s": len(children) / solo["seconds_alone"]}
-        roof = {"bound": "latency", "kernel": "k_bt_inner2_batch<512,2,2,8,0>", "achieved": acc["pivots"] * alg_bytes / max(acc["inner"], 1e-30) / 1e9 if acc["inner"] > 0 else 0.0,
+        roof = {"bound": "hbm", "limited_by": "latency: one workgroup per relaxation, two workgroup-wide argmins and two dependent tableau reads per pivot",
+                "kernel": "k_bt_inner2_batch<512,2,2,8,0>", "achieved": acc["pivots"] * alg_bytes / max(acc["inner"], 1e-30) / 1e9 if acc["inner"] > 0 else 0.0,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "note": "one workgroup per relaxation, two workgroup-wide argmins and two dependent tableau reads per pivot: bound by "
                         "latency, not bandwidth; achieved = rank 0's pivots x algorithmic bytes per pivot / HIP-event time of its batched inner launches"}
@@ -330,6 +331,13 @@ def main() -> int:
     # ------------------------------------------------------------------------------------------------------------------
     if world > 1:
         fout, roof, _ = frontier_leg(args.steps, args.warmup)
+        wide = None
+        if args.frontier_wide_vars > args.frontier_vars:
+            # second line: a frontier wider than one GPU's 256 CUs (2^11 = 2048 children of the same root), sharded the same way — the
+            # shape where more GPUs can pay; compare with `frontier_wide` of the --gpus 1 line
+            wout, _, _ = frontier_leg(3, 2, nvars=args.frontier_wide_vars, light=True)
+            wide = {k: wout[k] for k in ("workload", "relaxations_per_s", "wave_seconds", "waves_timed", "pivots_per_wave", "feasible_children",
+                                         "host_fallbacks_per_wave", "device_batched_per_wave", "schedule")}
         if rank == 0:
             out = {
                 "metric": "LP relaxations/sec on the 256-wide B&B frontier of 512x1024 relaxations", "value": fout["relaxations_per_s"],
@@ -338,7 +346,7 @@ def main() -> int:
                 "dtype": "f64", "data": "synthetic",
                 "config": {"workload": fout["workload"], "parallelism": "frontier sharded over %d GPUs, device-batched pivot loops per GPU" % world,
                            "scale_from": "frontier.relaxations_per_s of the --gpus 1 line"},
-                "roofline": roof, "frontier": fout,
+                "roofline": roof, "frontier": fout, "frontier_wide": wide,
                 "mfma": {"util": 0.0, "why": "no GEMM-shaped step on this path: every relaxation has its own tableau (no shared operand for a batched "
                          "pricing GEMM) and the rank-8 update is HBM-bound at 1 flop/byte (f64 MFMA ridge ~10 flop/byte)"},
             }
@@ -434,7 +442,8 @@ def main() -> int:
             share_inner = t_inner / max(t_inner + t_upd, 1e-30)
             traffic, tsrc = newest_pmc(inner_name.split("<")[0] + "<")
             roofline = {
-                "bound": "latency", "kernel": inner_name, "time_share": share_inner * loop_s / dt,
+                "bound": "hbm", "limited_by": "latency (two argmins over all columns / rows and two dependent tableau reads per pivot)", "kernel": inner_name,
+                "time_share": share_inner * loop_s / dt,
                 "achieved": bytes_inner / t_inner / 1e9 if t_inner > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "traffic": traffic, "traffic_source": tsrc,
                 "bytes_per_launch": bytes_inner, "avg_launch_us": 1e6 * t_inner, "us_per_pivot": 1e6 * t_inner / K, "pivots_per_launch": K,
