@@ -287,6 +287,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             if constexpr (STAMP && !LOOP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         stamp(which * 5 + 2);
+        for (int dl = 0; dl < a.poll_delay; dl++) __builtin_amdgcn_s_sleep(1);
         if constexpr (G == 16) {
             // 16 records: two 16-byte loads per lane, both slots of the same record l & 15 — lanes 0..15 get (minimum, first index)
             // of record l directly, the other rows the winner's scalars (slots 2, 3, 4) and the XCC ids (slot 5)
@@ -309,16 +310,25 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             xm = vmin_f64(xm, dpp_f64<0x141>(xm));   // row_half_mirror
             xm = vmin_f64(xm, dpp_f64<0x140>(xm));   // row_mirror: lanes 0..15 all hold the minimum
             const bool mine = lane < 16 && val == xm;
-            double km = mine ? val2 : 4294967295.0;
-            km = vmin_f64(km, dpp_f64<0xB1>(km));
-            km = vmin_f64(km, dpp_f64<0x4E>(km));
-            km = vmin_f64(km, dpp_f64<0x141>(km));
-            km = vmin_f64(km, dpp_f64<0x140>(km));
-            const unsigned int mk = (unsigned int)(__ballot(mine && val2 == km) & 0xFFFFull);
-            const int gw = mk ? __builtin_ctz(mk) : 0;
+            const unsigned int mk0 = (unsigned int)(__ballot(mine) & 0xFFFFull);
+            int gw;
+            double bi;
+            if (__builtin_popcount(mk0) == 1) {   // (uniform) one record attains the minimum — the usual case: its index, no second reduction
+                gw = __builtin_ctz(mk0);
+                bi = readlane_f64(val2, gw);
+            } else {
+                double km = mine ? val2 : 4294967295.0;
+                km = vmin_f64(km, dpp_f64<0xB1>(km));
+                km = vmin_f64(km, dpp_f64<0x4E>(km));
+                km = vmin_f64(km, dpp_f64<0x141>(km));
+                km = vmin_f64(km, dpp_f64<0x140>(km));
+                const unsigned int mk = (unsigned int)(__ballot(mine && val2 == km) & 0xFFFFull);
+                gw = mk ? __builtin_ctz(mk) : 0;
+                bi = readlane_f64(km, 0);
+            }
             XWin r;
             r.m = readlane_f64(xm, 0);
-            r.i = (unsigned int)readlane_f64(km, 0);
+            r.i = (unsigned int)bi;
             r.p0 = readlane_f64(val, 16 + gw);
             r.p1 = readlane_f64(val, 32 + gw);
             r.p2 = readlane_f64(val, 48 + gw);
@@ -816,9 +826,12 @@ __device__ __forceinline__ void bt_loop_update_role(const BTArgs &a, const int u
 // workgroup per CU (launch_bt_loop), and every wait is bounded.
 template <int G, int NT, int RI, bool STAMP = false, int KB = 8>
 __global__ __launch_bounds__(NT) void k_bt_loop(BTArgs a) {
-    const int b = (int)blockIdx.x, nupd = (int)gridDim.x - G, x = a.xcd & 7;
+    const int b = (int)blockIdx.x, x = a.xcd & 7;
+    // update workgroups that take part (knob "loop_upd": fewer of them spread a block's traffic over more of the block time)
+    const int nupd = (a.upd_cap > 0 && a.upd_cap < (int)gridDim.x - G) ? a.upd_cap : (int)gridDim.x - G;
     if ((b & 7) == x && (b >> 3) < G) { bt_innerG_body<G, NT, RI, 2 * KB, STAMP, true>(a, b >> 3, nupd); return; }
     const int before = b <= x ? 0 : min(G, ((b - x - 1) >> 3) + 1);   // pivot blocks in front of block b
+    if (b - before >= nupd) return;
     bt_loop_update_role<NT, KB>(a, b - before, nupd, G);
 }
 

@@ -134,7 +134,7 @@ struct BTArgs {
     unsigned long long *stamps;   // diagnostic build only (knob "bt_stamps"): per-wave cycle sums per pivot segment
     double *xbuf;                 // multi-workgroup block kernel: exchange records in HBM (btg_kernels.hip)
     int32_t groups, group_ri;     // its workgroup count (0: single-workgroup kernels) and rows / columns per thread
-    int32_t fault, pad_f;         // knob "bt_fault" (tests): workgroup 1 of the multi-workgroup block kernel leaves at once
+    int32_t fault, upd_cap;         // knob "bt_fault" (tests): workgroup 1 of the multi-workgroup block kernel leaves at once
     int32_t group_nt, upd_valu;   // threads per workgroup; knob "bt_upd_valu": rank-16 update on the VALU instead of the matrix cores
     // Persistent loop kernel (btg_kernels.hip k_bt_loop; engine_tableau.cpp run_loop_bt): ONE launch runs up to `nblocks` blocks of
     // 8 pivots on the G workgroups of one XCD while the other workgroups of the same launch apply the rank-8 update of block
@@ -149,7 +149,7 @@ struct BTArgs {
     // are decided by it.  guard > 0: a block stops (ST_NEED_EXACT) in front of a pivot whose winning ratio is <= guard; the host
     // uploads the gonum-order x_B of the current basis and restarts with exact_once = 1 (the first pivot then decides as is).
     double guard;
-    int32_t exact_once, pad_g;
+    int32_t exact_once, poll_delay;   // (poll_delay: units of 64 cycles a wave waits between its post and its first poll, knob "poll_delay")
 };
 
 // shape of the multi-workgroup block kernel for a tableau (btg_kernels.hip): groups == 0 -> single-workgroup kernels

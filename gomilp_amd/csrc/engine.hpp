@@ -158,6 +158,8 @@ class Engine {
             bt_lag_ = 1,       // persistent loop kernel where the multi-workgroup block kernel runs (0: block kernel + update launches)
             loop_chunk_ = 512, // pivots per launch of the persistent loop kernel
             loop_grid_ = 0,    // its workgroups (0: one per CU)
+            poll_delay_ = 0,   // loop kernel: 64-cycle units between a wave's post and its first poll of an exchange
+            loop_upd_ = 0,     // update workgroups of the loop kernel that take part (0: all of the grid's)
             loop_g_ = 0,       // its pivot workgroups (0 / 16: 16 x 128 threads up to 2048 rows, 16 x 256 beyond; 8: 8 x 256 / 8 x 512)
             loop_k_ = 0,       // its pivots per block (0: 8 up to 2048 rows, 16 beyond; 8 / 16 forced where instantiated)
             exact_degenerate_ = 1,   // 0 never, 1 bases of up to 256 rows and every non-slack start, 2 always: pivots whose winning ratio is (nearly) zero are decided on a fresh gonum-order x_B

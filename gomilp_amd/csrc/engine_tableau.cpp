@@ -474,7 +474,7 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
             // 11.47 ms against 11.85 ms per solve of the metric LP for 8 x 256)
             if (ai.groups == 8 && ai.group_nt == 256 && ai.group_ri == 1 && loop_g_ != 8 && K == 8 && !bt_stamps_) { ai.groups = 16; ai.group_nt = 128; }
             ai.Tbuf[0] = w.T[0]; ai.Tbuf[1] = w.T[1];
-            ai.xcd = loop_xcd;
+            ai.xcd = loop_xcd; ai.upd_cap = (int)loop_upd_; ai.poll_delay = (int)poll_delay_;
             ai.exact_once = exact_pending ? 1 : 0; exact_pending = false;
             ai.forced_q = forced_q_pending; ai.forced_p = forced_p_pending; forced_q_pending = forced_p_pending = -1;
             hipEvent_t e0 = nullptr, e1 = nullptr;
