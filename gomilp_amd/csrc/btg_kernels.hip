@@ -105,7 +105,7 @@ struct BtWinG { double m; unsigned int i; };                   // a wave's own w
 template <int G, int NT, int RI, int KR, bool STAMP, bool LOOP = false>
 __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, const int nupd = 0) {
     constexpr int NW = NT / 64;
-    static_assert(!LOOP || KR == 16 || KR == 32, "loop mode: KR / 2 lagging + KR / 2 current terms");
+    static_assert(!LOOP || KR == 16 || KR == 24 || KR == 32, "loop mode: KR / 2 lagging + KR / 2 current terms");
     constexpr int KB = LOOP ? KR / 2 : KR;   // pivots per block
     static_assert(G == 2 || G == 4 || G == 8 || G == 16, "G");
     if (a.fault && g == 1) return;   // test hook: a workgroup that never takes part -> the others must give up (ST_XCHG_TIMEOUT)
@@ -420,7 +420,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
         if constexpr (LOOP) {
             // lane l fetches term l (newest first: this block's k terms, then the nl lagging ones): ONE load instruction
             // instead of 16 with scalar addresses each; the terms reach the multiply-adds as scalar operands
-            const int l = lane & (KR - 1);
+            const int l = lane & 31;   // (KR <= 32; lanes beyond the terms in use fetch nothing)
             const int trow = l < k ? cur0 + k - 1 - l : lag0 + nl - 1 - (l - k);
             const double tv = l < k + nl ? ld_term(a.V + (size_t)trow * a.ldt + q) : 0.0;
             if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(11); }   // column + term loads: issue -> data
@@ -591,7 +591,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
         }
         double up[KR];   // u_j[p] of the block's k earlier pivots, newest first (loop mode: then the lagging ones)
         if constexpr (LOOP) {
-            const int l = lane & (KR - 1);
+            const int l = lane & 31;   // (KR <= 32; lanes beyond the terms in use fetch nothing)
             const int trow = l < k ? cur0 + k - 1 - l : lag0 + nl - 1 - (l - k);
             const double tv = l < k + nl ? ld_term(a.U + (size_t)trow * a.ldu + p) : 0.0;
             if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(12); }   // row + term loads: issue -> data
@@ -911,6 +911,7 @@ void launch_bt_loop(const BTArgs &a, int ncu, hipStream_t s, hipEvent_t e0, hipE
         return;
     }
     if (G == 16 && a.group_nt == 128) { hipExtLaunchKernelGGL((k_bt_loop<16, 128, 1, false, 8>), dim3(std::max(grid, 136u)), dim3(128), 0, s, e0, e1, 0, a); return; }   // up to 2048 rows: 16 x 128 threads, blocks of 8
+    if (G == 16 && a.kmax == 12) { hipExtLaunchKernelGGL((k_bt_loop<16, 256, 1, false, 12>), dim3(std::max(grid, 136u)), dim3(256), 0, s, e0, e1, 0, a); return; }   // knob loop_k = 12
     if (G == 16) { hipExtLaunchKernelGGL((k_bt_loop<16, 256, 1, false, 16>), dim3(std::max(grid, 136u)), dim3(256), 0, s, e0, e1, 0, a); return; }   // 4096 rows: 16 x 256 threads, blocks of 16
     if (G == 2) hipExtLaunchKernelGGL((k_bt_loop<2, 512, 1>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);
     else if (G == 4) hipExtLaunchKernelGGL((k_bt_loop<4, 512, 1>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);

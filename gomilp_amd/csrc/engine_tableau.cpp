@@ -208,7 +208,7 @@ void Engine::bt_plan(const Problem &P, int *K, bool *tiled, bool *lag) const {
         // pivots, and 16 + 16 terms still fit the 256 registers of a 512-thread workgroup)
         if (lag && bt_lag_ && block_k_ == 0 && max_pivots_ == 0 && (!bt_stamps_ || gc.nt == 256) && bt_loop_supported(gc)) {
             *lag = true;
-            *K = (gc.nt == 512 && gc.groups == 8 && loop_k_ != 8) ? 16 : 8;
+            *K = (gc.nt == 512 && gc.groups == 8 && loop_k_ != 8) ? (loop_k_ == 12 && loop_g_ != 8 ? 12 : 16) : 8;
         }
         return;
     }
@@ -469,12 +469,17 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
             ai.loop = 1; ai.nblocks = (int)nblocks; ai.par = (int)(launch_no & 1);
             // 2049..4096 rows: 16 pivot workgroups of 256 threads (one wave per SIMD: the per-pivot chain of the 2048-row shape)
             // instead of 8 of 512 — inside the loop kernel only; set-up pivots and the batched schedule keep bt_group_cfg's shape
-            if (ai.groups == 8 && ai.group_nt == 512 && ai.group_ri == 1 && loop_g_ != 8 && K == 16) { ai.groups = 16; ai.group_nt = 256; }
+            if (ai.groups == 8 && ai.group_nt == 512 && ai.group_ri == 1 && loop_g_ != 8 && (K == 16 || K == 12)) { ai.groups = 16; ai.group_nt = 256; }
             // 1025..2048 rows: 16 x 128 threads (two waves per workgroup: a cheaper workgroup stage in front of every exchange; measured
             // 11.47 ms against 11.85 ms per solve of the metric LP for 8 x 256)
             if (ai.groups == 8 && ai.group_nt == 256 && ai.group_ri == 1 && loop_g_ != 8 && K == 8 && !bt_stamps_) { ai.groups = 16; ai.group_nt = 128; }
             ai.Tbuf[0] = w.T[0]; ai.Tbuf[1] = w.T[1];
             ai.xcd = loop_xcd; ai.upd_cap = (int)loop_upd_; ai.poll_delay = (int)poll_delay_;
+            // beyond 2048 rows the tableau pair (268 MB at 4096 x 4096) no longer fits the Infinity Cache: all 240 update workgroups
+            // stream a block at the full HBM rate in 51 of its 84 us and the pivot workgroups' dependent tableau reads queue behind
+            // them; 112 spread the same bytes over ~60 us (measured per solve of C4: 240: 50.3 ms, 170: 49.0, 140: 47.8, 110: 47.0, 90: 48.9,
+            // 70: 57.9 — update-bound from there)
+            if (ai.upd_cap == 0 && ai.groups == 16 && ai.group_nt == 256) ai.upd_cap = 112;
             ai.exact_once = exact_pending ? 1 : 0; exact_pending = false;
             ai.forced_q = forced_q_pending; ai.forced_p = forced_p_pending; forced_q_pending = forced_p_pending = -1;
             hipEvent_t e0 = nullptr, e1 = nullptr;
