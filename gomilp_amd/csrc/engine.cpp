@@ -200,11 +200,12 @@ int64_t Engine::upload(const double *c, const double *A, int64_t lda, const doub
         UP_TRY(dmalloc(&up_dA_, (size_t)m * n));
         up_dA_cap_ = (size_t)m * n;
     }
-    if (up_stats_cap_ < (size_t)3 * n + m) {
+    const size_t range_off = ((size_t)3 * n + m + 1) & ~(size_t)1;   // two 64-bit words behind the lists: max / min non-zero |a_ij|
+    if (up_stats_cap_ < range_off + 4) {
         if (up_stats_) hipFree(up_stats_);
         up_stats_ = nullptr; up_stats_cap_ = 0;
-        UP_TRY(dmalloc(&up_stats_, (size_t)3 * n + m));
-        up_stats_cap_ = (size_t)3 * n + m;
+        UP_TRY(dmalloc(&up_stats_, range_off + 4));
+        up_stats_cap_ = range_off + 4;
     }
     dA = up_dA_; dstats = up_stats_;
     if (!recycled) {
@@ -220,14 +221,15 @@ int64_t Engine::upload(const double *c, const double *A, int64_t lda, const doub
     UP_TRY(hipMemsetAsync(P->dc, 0, ((size_t)n + 1) * sizeof(double), stream_));
     UP_TRY(hipMemsetAsync(P->dc1, 0, ((size_t)n + 1) * sizeof(double), stream_));
     UP_TRY(hipMemsetAsync(P->db, 0, (size_t)ld * sizeof(double), stream_));
-    UP_TRY(hipMemsetAsync(dstats, 0, ((size_t)3 * n + m) * sizeof(int32_t), stream_));
+    UP_TRY(hipMemsetAsync(dstats, 0, (range_off + 2) * sizeof(int32_t), stream_));
+    UP_TRY(hipMemsetAsync(dstats + range_off + 2, 0xFF, 2 * sizeof(int32_t), stream_));
     UP_TRY(hipMemcpyAsync(P->dc, c, (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream_));
     UP_TRY(hipMemcpyAsync(P->db, b, (size_t)m * sizeof(double), hipMemcpyHostToDevice, stream_));
     const double one = 1.0;
     UP_TRY(hipMemcpyAsync(P->dc1 + n, &one, sizeof(double), hipMemcpyHostToDevice, stream_));
     launch_transpose_in(dA, n, m, n, P->dAt, ld, stream_);
-    launch_col_stats(P->dAt, ld, m, n, dstats, dstats + n, dstats + 2 * n, dstats + 3 * n, stream_);
-    std::vector<int32_t> hs((size_t)3 * n + m);
+    launch_col_stats(P->dAt, ld, m, n, dstats, dstats + n, dstats + 2 * n, dstats + 3 * n, reinterpret_cast<unsigned long long *>(dstats + range_off), stream_);
+    std::vector<int32_t> hs(range_off + 4);
     UP_TRY(hipMemcpyAsync(hs.data(), dstats, hs.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     UP_TRY(sync_stream());
     UP_TRY(hipGetLastError());
@@ -237,13 +239,12 @@ int64_t Engine::upload(const double *c, const double *A, int64_t lda, const doub
     P->allone.assign(hs.begin() + 2 * n, hs.begin() + 3 * n);
     P->hb.assign(b, b + m);
     P->hc.assign(c, c + n);
-    {   // spread of the entries: badly scaled inputs take the careful path (Engine::make_bt_args)
-        double amax = 0, amin = std::numeric_limits<double>::infinity();
-        for (int i = 0; i < m; i++) {
-            const double *row = A + (size_t)i * lda;
-            for (int j = 0; j < n; j++) { const double v = fabs(row[j]); if (v > amax) amax = v; if (v != 0 && v < amin) amin = v; }
-        }
-        P->scale_span = (amax > 0 && amin <= amax) ? amax / amin : 1.0;
+    {   // spread of the entries (k_col_stats): badly scaled inputs take the careful path (Engine::make_bt_args)
+        unsigned long long bits[2];
+        memcpy(bits, &hs[range_off], sizeof(bits));
+        double amax, amin;
+        memcpy(&amax, &bits[0], 8); memcpy(&amin, &bits[1], 8);
+        P->scale_span = (bits[0] != 0 && bits[1] != ~0ull && amin > 0 && amin <= amax) ? amax / amin : 1.0;
     }
     if ((size_t)m * n <= ((size_t)1 << 25)) {  // up to 256 MB: keep A for the general initial-basis path (equality rows, supplied basis)
         P->hA.resize((size_t)m * n);

@@ -264,8 +264,8 @@ void launch_b_init_ids(int *ids, int *count, int nlp, hipStream_t s);
 void launch_b_permute(const BatchLP *lps, const int *ids, const int *count, int bound, int m_max, int ldt_max, hipStream_t s);
 void launch_b_tab_r(const BatchLP *lps, const int *ids, const int *count, int bound, int m_max, int ldt_max, hipStream_t s);
 void launch_transpose_in(const double *A, int64_t lda, int m, int n, double *At, int ld, hipStream_t s);
-void launch_col_stats(const double *At, int ld, int m, int n, int32_t *nnz, int32_t *lastrow, int32_t *allone,
-                      int32_t *rowflag, hipStream_t s);
+void launch_col_stats(const double *At, int ld, int m, int n, int32_t *nnz, int32_t *lastrow, int32_t *allone, int32_t *rowflag, unsigned long long *range,
+                      hipStream_t s);
 void launch_set_binv_perm(double *binv, int ld, int m, const int32_t *rho, hipStream_t s);
 void launch_child_assemble(const double *At0, int ld0, int m0, int n0, double *At1, int ld1, int K, const int32_t *var,
                            const double *sign, hipStream_t s);

@@ -192,24 +192,35 @@ __global__ void k_transpose_in(const double *__restrict__ A, int64_t lda, int m,
 }
 
 // per column j of A (row of At): nnz, row of the last non-zero, all non-zeros equal to 1 ; and mark non-empty rows
+// range (optional): [0] = bits of max |a_ij|, [1] = bits of the smallest non-zero |a_ij| (positive doubles order like their bit patterns)
 __global__ __launch_bounds__(kBlock) void k_col_stats(const double *__restrict__ At, int ld, int m, int n, int32_t *nnz,
-                                                      int32_t *lastrow, int32_t *allone, int32_t *rowflag) {
+                                                      int32_t *lastrow, int32_t *allone, int32_t *rowflag, unsigned long long *range) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * kWavesPerBlock;
     for (int j = wave; j < n; j += nwaves) {
         const double *row = At + (size_t)j * ld;
         int cnt = 0, last = -1, one = 1;
+        unsigned long long hi = 0ull, lo = ~0ull;
         for (int i = lane; i < m; i += 64) {
             const double v = row[i];
-            if (v != 0) { cnt++; last = i; if (v != 1.0) one = 0; rowflag[i] = 1; }
+            if (v != 0) {
+                cnt++; last = i; if (v != 1.0) one = 0; rowflag[i] = 1;
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(fabs(v));
+                hi = bits > hi ? bits : hi; lo = bits < lo ? bits : lo;
+            }
         }
         for (int o = 32; o > 0; o >>= 1) {
             cnt += __shfl_xor(cnt, o, 64);
             last = max(last, __shfl_xor(last, o, 64));
             one &= __shfl_xor(one, o, 64);
+            const unsigned long long h2 = __shfl_xor(hi, o, 64), l2 = __shfl_xor(lo, o, 64);
+            hi = h2 > hi ? h2 : hi; lo = l2 < lo ? l2 : lo;
         }
-        if (lane == 0) { nnz[j] = cnt; lastrow[j] = last; allone[j] = one; }
+        if (lane == 0) {
+            nnz[j] = cnt; lastrow[j] = last; allone[j] = one;
+            if (range && cnt) { atomicMax(range, hi); atomicMin(range + 1, lo); }
+        }
     }
 }
 
@@ -426,8 +437,8 @@ void launch_transpose_in(const double *A, int64_t lda, int m, int n, double *At,
     hipLaunchKernelGGL(k_transpose_in, grid, block, 0, s, A, lda, m, n, At, ld);
 }
 void launch_col_stats(const double *At, int ld, int m, int n, int32_t *nnz, int32_t *lastrow, int32_t *allone,
-                      int32_t *rowflag, hipStream_t s) {
-    hipLaunchKernelGGL(k_col_stats, dim3(grid_for_rows(n)), dim3(kBlock), 0, s, At, ld, m, n, nnz, lastrow, allone, rowflag);
+                      int32_t *rowflag, unsigned long long *range, hipStream_t s) {
+    hipLaunchKernelGGL(k_col_stats, dim3(grid_for_rows(n)), dim3(kBlock), 0, s, At, ld, m, n, nnz, lastrow, allone, rowflag, range);
 }
 void launch_child_assemble(const double *At0, int ld0, int m0, int n0, double *At1, int ld1, int K, const int32_t *var,
                            const double *sign, hipStream_t s) {
