@@ -469,7 +469,7 @@ int gomilp_lp_simplex(const double *c, const double *A, int64_t lda, const doubl
         }
     }
     int rc;
-    int64_t id = gomilp_lp_upload(ctx, c, A, lda, b, m, n);
+    int64_t id = ctx->eng->upload(c, A, lda, b, m, n, true);   // (lazy host copy: Engine::upload)
     if (id < 0) rc = (int)-id;
     else {
         rc = gomilp_lp_solve_resident(ctx, id, tol, initial_basic, opt_f, opt_x, has_x, basis_out, stats);

@@ -162,7 +162,7 @@ int Engine::ensure_work(int m, int ncols) {
 // upload: A (row-major m x n) -> At ((n+1) x ld) in HBM, column statistics for verifyInputs and for
 // the unit-column fast path of findLinearlyIndependent (simplex.go:385-439, :611-637)
 // ------------------------------------------------------------------------------------------------
-int64_t Engine::upload(const double *c, const double *A, int64_t lda, const double *b, int64_t m64, int64_t n64) {
+int64_t Engine::upload(const double *c, const double *A, int64_t lda, const double *b, int64_t m64, int64_t n64, bool lazy_host) {
     std::lock_guard<std::mutex> g(mu_);
     if (!c || !A || !b || m64 <= 0 || n64 <= 0 || lda < n64 || m64 > (1 << 20) || n64 > (1 << 22)) return -GOMILP_ERR_BAD_SHAPE;
     const int m = (int)m64, n = (int)n64;
@@ -246,9 +246,15 @@ int64_t Engine::upload(const double *c, const double *A, int64_t lda, const doub
         memcpy(&amax, &bits[0], 8); memcpy(&amin, &bits[1], 8);
         P->scale_span = (bits[0] != 0 && bits[1] != ~0ull && amin > 0 && amin <= amax) ? amax / amin : 1.0;
     }
+    P->hA.clear();
+    P->lazy_host = false;
     if ((size_t)m * n <= ((size_t)1 << 25)) {  // up to 256 MB: keep A for the general initial-basis path (equality rows, supplied basis)
-        P->hA.resize((size_t)m * n);
-        for (int i = 0; i < m; i++) memcpy(&P->hA[(size_t)i * n], A + (size_t)i * lda, sizeof(double) * (size_t)n);
+        // (the flat call skips the copy of a large A — 67 MB, ~5 ms at the metric size — and fetches it from the device if a rare path asks)
+        if (lazy_host && (size_t)m * n > ((size_t)1 << 20)) P->lazy_host = true;
+        else {
+            P->hA.resize((size_t)m * n);
+            for (int i = 0; i < m; i++) memcpy(&P->hA[(size_t)i * n], A + (size_t)i * lda, sizeof(double) * (size_t)n);
+        }
     }
     // verifyInputs (simplex.go:404-438): rows first, then columns, first offender decides
     P->verify_status = GOMILP_OK;
@@ -432,6 +438,14 @@ int Engine::refresh_xb_y(const Problem &P, const double *cost) {
 // host copy of A for the general-basis path; children derive it from their root (subproblem.go:81-139)
 bool Engine::ensure_host_A(const Problem &P) {
     if (!P.hA.empty()) return true;
+    if (!P.is_child && P.lazy_host) {   // flat call: the copy was skipped at upload, At (column-major, resident) has the same numbers
+        const int m = P.m, n = P.n;
+        std::vector<double> at((size_t)n * P.ld);
+        if (hipMemcpyAsync(at.data(), P.dAt, at.size() * sizeof(double), hipMemcpyDeviceToHost, stream_) != hipSuccess || sync_stream() != hipSuccess) return false;
+        P.hA.resize((size_t)m * n);
+        for (int j = 0; j < n; j++) for (int i = 0; i < m; i++) P.hA[(size_t)i * n + j] = at[(size_t)j * P.ld + i];
+        return true;
+    }
     if (!P.is_child || !P.root_ptr) return false;
     const Problem &R = *P.root_ptr;
     // the root of a pool child may live in another worker's engine (gomilp_pool_add_root keeps extra roots in worker 0): its host

@@ -31,6 +31,7 @@ struct Problem {
     uint64_t serial = 0;      // unique per upload (device buffers are recycled: a pointer does not identify a problem)
     // children are recycled: their device buffers go back to a per-engine pool instead of hipFree (which synchronises
     // the whole device and would serialise the worker streams of a frontier pool)
+    bool lazy_host = false;   // no host copy of A was kept at upload: ensure_host_A downloads it (flat call only)
     double scale_span = 1.0;  // max |a_ij| / min nonzero |a_ij| of A: beyond 1e9 the solve keeps the degenerate-pivot guard on at every size
     bool is_child = false;
     size_t cap_at = 0, cap_c = 0, cap_b = 0;    // capacities in doubles
@@ -52,7 +53,9 @@ class Engine {
     static void loop_release(int dev, int weight, int slot);
     int set(const std::string &key, int64_t v);
 
-    int64_t upload(const double *c, const double *A, int64_t lda, const double *b, int64_t m, int64_t n);
+    // lazy_host: do not keep a host copy of a large A at upload (the flat call: the context is the caller's alone, and the copy is
+    // only read on rare paths — ensure_host_A fetches it from the device then)
+    int64_t upload(const double *c, const double *A, int64_t lda, const double *b, int64_t m, int64_t n, bool lazy_host = false);
     int free_problem(int64_t id);
     // child of a resident root: K branch-and-bound rows (var, sign, rhs) appended on the device (subproblem.go:141-159)
     int64_t upload_child(int64_t root, int K, const int32_t *var, const double *sign, const double *rhs);
