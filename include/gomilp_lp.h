@@ -112,7 +112,13 @@ int gomilp_ctx_device(const gomilp_ctx *ctx);
  * "trace" (1 = record pivots), "max_pivots" (safety cap, 0 = none).  Developer knobs of the pivot pipelines (tests force
  * kernel instances with them; results do not depend on them): "tableau", "blocked", "block_k", "bt_nt" (threads of the
  * single-workgroup block kernel), "bt_groups" (-1: single-workgroup block kernels only, 0: by shape, 2 / 4 / 8: that many
- * workgroups), "bt_old", "bt_stamps", "sample_events", "cond_guard".  Returns GOMILP_OK or GOMILP_ERR_BAD_SHAPE. */
+ * workgroups), "bt_old", "bt_stamps", "sample_events"; of the persistent loop kernel: "bt_lag" (0: the launch pairs of round 2),
+ * "loop_chunk" (pivots per launch), "loop_g" (8 / 16 pivot workgroups), "loop_k" (8 / 12 / 16 pivots per block), "loop_upd"
+ * (update workgroups that take part), "loop_grid", "poll_delay".  Knobs that DO change what is decided, and how faithfully:
+ * "exact_degenerate" (0 never, 1 default: bases of up to 256 rows, non-slack starts and badly scaled inputs, 2 always — degenerate,
+ * tied and tiny pivots are decided on fresh gonum-order solves), "cond_guard" (1 default: gonum's
+ * mat.Condition guard, from a pivot-by-pivot replay up to 64 rows and from the tableau's exact condition numbers beyond).
+ * Returns GOMILP_OK or GOMILP_ERR_BAD_SHAPE. */
 int gomilp_ctx_set(gomilp_ctx *ctx, const char *key, int64_t value);
 
 /* Upload a standard-form LP (row-major A, stride lda) and keep it resident.  Returns a problem id >= 0, or
