@@ -1,6 +1,6 @@
 """Developer tool: a few large parity cases against the (slow) CPU oracle: the 1024-thread kernels and the split
 triangular solves (m >= 1024)."""
-import sys, time; sys.path.insert(0, '/root/repo')
+import sys, time, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gomilp_amd import lp, synth
 from oracle import oracle as O

@@ -1,6 +1,6 @@
 """Developer tool: wide random parity sweep of the GPU path against the CPU oracle (status, pivot sequence, basis, x bits).
    gpurun -- python tools/parity_sweep.py [cases] [max_m]"""
-import sys, time; sys.path.insert(0, '/root/repo')
+import sys, time; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gomilp_amd import lp, synth
 from oracle import oracle as O
