@@ -573,7 +573,7 @@ static int luc_cfg(int m) {
     if (forced >= 0) return forced;
     return m <= 512 ? 0 : (m <= 1024 ? 1 : (m <= 2048 ? 2 : 3));
 }
-int lu_compressed_nb(int m) { const int c = luc_cfg(m); return c <= 1 ? 32 : (c == 2 ? 16 : 8); }
+int lu_compressed_nb(int m) { const int c = luc_cfg(m); return c <= 1 ? 32 : ((c == 2 || c == 4) ? 16 : 8); }
 
 void launch_luc_init(const LUArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(k_luc_init, dim3((a.m + 255) / 256), dim3(256), 0, s, a);
@@ -601,6 +601,7 @@ int launch_luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t
     if (c == 0) luc_rounds<512, 1, 32>(a, pivrow, nrounds, s);
     else if (c == 1) luc_rounds<1024, 1, 32>(a, pivrow, nrounds, s);
     else if (c == 2) luc_rounds<1024, 2, 16>(a, pivrow, nrounds, s);
+    else if (c == 4) luc_rounds<512, 4, 16>(a, pivrow, nrounds, s);   // developer knob only (GOMILP_LUC_CFG=4): measured below
     else luc_rounds<1024, 4, 8>(a, pivrow, nrounds, s);
     return 3 * nrounds;
 }
