@@ -404,6 +404,20 @@ int64_t gomilp_debug_find_independent(const double *A, int64_t lda, int64_t m, i
     return (int64_t)idx.size();
 }
 
+// diagnostic (host only): the condition-number estimate the engine takes its mat.Condition verdict on beyond the exact screen
+// (Engine::cond_check): |B|_1 times the Hager / Higham estimate of |B^-1|_1 (inf = 0; gonum: the duals' solve with ab^T), or
+// |B|_inf times the estimate of |B^-1|_inf (inf = 1: the solves with ab).  -1: singular to working precision.
+double gomilp_debug_cond_estimate(const double *B, int64_t n, int inf) {
+    if (!B || n <= 0 || n > 4096) return -1.0;
+    std::vector<double> b((size_t)n * n), inv;
+    for (int64_t i = 0; i < n * n; i++) b[(size_t)i] = B[i];
+    if (!gomilp::general_invert(b, (int)n, inv)) return -1.0;
+    double norm = 0;
+    if (!inf) { for (int64_t j = 0; j < n; j++) { double s2 = 0; for (int64_t i = 0; i < n; i++) s2 += fabs(b[(size_t)(i * n + j)]); norm = std::max(norm, s2); } }
+    else { for (int64_t i = 0; i < n; i++) { double s2 = 0; for (int64_t j = 0; j < n; j++) s2 += fabs(b[(size_t)(i * n + j)]); norm = std::max(norm, s2); } }
+    return norm * gomilp::inverse_norm1_estimate(inv, (int)n, inf != 0);
+}
+
 // diagnostic: the same search with the scan on the device (general_kernels.hip), on a problem resident in `ctx`
 int64_t gomilp_debug_find_independent_device(gomilp_ctx *ctx, int64_t problem, int64_t *idx_out, int64_t cap) {
     if (!ctx || !idx_out) return -GOMILP_ERR_BAD_SHAPE;

@@ -58,7 +58,7 @@ class FrontierStats(C.Structure):
 
 
 EXPORTS = [
-    "gomilp_lp_upload_child", "gomilp_pool_create", "gomilp_pool_destroy", "gomilp_pool_set", "gomilp_pool_set_root", "gomilp_frontier_solve", "gomilp_pool_add_root", "gomilp_frontier_solve_roots", "gomilp_pool_solve_root", "gomilp_debug_find_independent", "gomilp_debug_find_independent_device",
+    "gomilp_lp_upload_child", "gomilp_pool_create", "gomilp_pool_destroy", "gomilp_pool_set", "gomilp_pool_set_root", "gomilp_frontier_solve", "gomilp_pool_add_root", "gomilp_frontier_solve_roots", "gomilp_pool_solve_root", "gomilp_debug_find_independent", "gomilp_debug_find_independent_device", "gomilp_debug_cond_estimate",
     "gomilp_lp_simplex", "gomilp_ctx_create", "gomilp_ctx_destroy", "gomilp_ctx_device", "gomilp_ctx_set",
     "gomilp_lp_upload", "gomilp_lp_free", "gomilp_lp_solve_resident", "gomilp_lp_last_trace", "gomilp_version",
     "gomilp_device_count", "gomilp_compiled_arch", "gomilp_comm_unique_id", "gomilp_comm_create", "gomilp_comm_destroy",
@@ -107,6 +107,8 @@ def lib():
     L.gomilp_pool_add_root.argtypes = [C.c_void_p, dp, dp, C.c_int64, dp, C.c_int64, C.c_int64]
     L.gomilp_frontier_solve_roots.argtypes = [C.c_void_p, C.c_int64, i32p, ip, i32p, dp, dp, C.c_double, dp, dp, C.c_int64, i32p, i32p,
                                               C.POINTER(FrontierStats)]
+    L.gomilp_debug_cond_estimate.restype = C.c_double
+    L.gomilp_debug_cond_estimate.argtypes = [dp, C.c_int64, C.c_int]
     L.gomilp_debug_find_independent.restype = C.c_int64
     L.gomilp_debug_find_independent_device.restype = C.c_int64
     L.gomilp_debug_find_independent_device.argtypes = [C.c_void_p, C.c_int64, ip, C.c_int64]
@@ -444,3 +446,11 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def debug_cond_estimate(B, inf: bool = False) -> float:
+    """|B| * (Hager / Higham estimate of |B^-1|) in the 1-norm (inf = False) or the infinity norm — host only (no device)."""
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    n = B.shape[0]
+    assert B.shape == (n, n)
+    return float(lib().gomilp_debug_cond_estimate(_dp(B), n, 1 if inf else 0))

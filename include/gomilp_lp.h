@@ -230,6 +230,10 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
 int64_t gomilp_debug_find_independent(const double *A, int64_t lda, int64_t m, int64_t n, int64_t *idx_out, int fast);
 /* the same search with the column scan on the device, on a resident problem (tests compare the two) */
 int64_t gomilp_debug_find_independent_device(gomilp_ctx *ctx, int64_t problem, int64_t *idx_out, int64_t cap);
+/* Diagnostic (host only): the condition-number estimate behind the engine's mat.Condition verdicts (mat/lu.go:321 with
+ * lapack/gonum/dgecon.go:26-81, dlacn2.go:24-136) for a row-major n x n matrix: 1-norm (inf = 0) or infinity norm (inf = 1);
+ * -1 when B is singular to working precision.  Tests compare it with the checker's Dgecon. */
+double gomilp_debug_cond_estimate(const double *B, int64_t n, int inf);
 
 /* Library / device probes (no compute): used by the loader checks and by __graft_entry__. */
 const char *gomilp_version(void);
