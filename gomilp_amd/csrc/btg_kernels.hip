@@ -94,7 +94,7 @@ __device__ __forceinline__ bool spin_counter(const unsigned int *p, unsigned int
     }
     return false;
 }
-struct XWin { double m; unsigned int i; double p0, p1, p2; };    // winner of an exchange: value, first index, its scalars
+struct XWin { double m; unsigned int i; double p0, p1, p2, p3; };   // winner of an exchange: value, first index, its scalars (p3: its newest block term)
 struct BtWinG { double m; unsigned int i; };                   // a wave's own winner
 
 }  // namespace
@@ -232,7 +232,10 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
     // next reduction may overwrite them without another barrier.
     auto xchg = [&](int which) -> XWin {
         stamp(which * 5 + 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's term stores have reached L2 / memory before the post
+        // this wave's term stores have reached L2 / memory before the post.  Loop mode posts without that wait: the NEWEST term of the
+        // candidate travels in the record (slot 6), readers take the older ones from U / V, and those were awaited before the row phase
+        // that stored the newest (see there) — the stores of a pivot drain under the next pivot's exchanges instead of in front of them
+        if constexpr (!LOOP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         stamp(which * 5 + 1);
         xs += 1;
@@ -292,9 +295,9 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             // 16 records: two 16-byte loads per lane, both slots of the same record l & 15 — lanes 0..15 get (minimum, first index)
             // of record l directly, the other rows the winner's scalars (slots 2, 3, 4) and the XCC ids (slot 5)
             const int rec = lane & 15, grp = lane >> 4;
-            const bool actB = grp < 2;
+            const bool actB = grp < 3;
             const xpair *base = recs + (size_t)par * G * kXSlots + rec * kXSlots;
-            const xpair *srcA = base + (grp == 0 ? 0 : grp + 1), *srcB = base + (grp == 0 ? 1 : grp == 1 ? 5 : 0);
+            const xpair *srcA = base + (grp == 0 ? 0 : grp + 1), *srcB = base + (grp == 0 ? 1 : grp == 1 ? 5 : grp == 2 ? 6 : 0);
             xpair got[2];
             int spins = 0;
             for (;;) {
@@ -332,6 +335,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             r.p0 = readlane_f64(val, 16 + gw);
             r.p1 = readlane_f64(val, 32 + gw);
             r.p2 = readlane_f64(val, 48 + gw);
+            r.p3 = readlane_f64(val2, 32 + gw);
             if (first) {
                 fast = !dead && __all(grp != 1 || val2 == (double)myxcc);
                 first = false;
@@ -340,7 +344,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             return r;
         }
         // lane l reads slot l >> 3 of record l & 7: the G minima sit in lanes 0..G-1, their indices in lanes 8.., the scalars behind
-        const bool act = (lane & 7) < G && (lane >> 3) < 6;
+        const bool act = (lane & 7) < G && (lane >> 3) < 7;
         const xpair *src = recs + (size_t)par * G * kXSlots + (act ? (lane & 7) * kXSlots + (lane >> 3) : 0);
         xpair got[1];
         int spins = 0;
@@ -375,6 +379,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
         r.p0 = readlane_f64(val, 16 + gw);
         r.p1 = readlane_f64(val, 24 + gw);
         r.p2 = readlane_f64(val, 32 + gw);
+        r.p3 = readlane_f64(val, 48 + gw);
         if (first) {   // slot 5 of every record: the XCC the workgroup runs on
             fast = !dead && __all(!(act && (lane >> 3) == 5) || val == (double)myxcc);
             first = false;
@@ -390,6 +395,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             if ((unsigned int)gidx(s) == w.i) {
                 pay[wv][0] = rv[s];
                 pay[wv][1] = (double)nbasv[s];
+                pay[wv][3] = vreg[s][0];   // the newest v' of this column (slots 6 / 7 of the record)
             }
         if (lane == 0) { redM[wv] = w.m; redI[wv] = w.i; }
         return xchg(0);
@@ -403,12 +409,13 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
                 pay[wv][0] = dcol[s];
                 pay[wv][1] = xbv[s];
                 pay[wv][2] = (double)basv[s];
+                pay[wv][3] = ureg[s][0];   // the newest u of this row
             }
         if (lane == 0) { redM[wv] = w.m; redI[wv] = w.i; }
         return xchg(1);
     };
     // column q of the current tableau for this thread's rows; v'_j[q] of the block's k earlier pivots (newest first) from V
-    auto column = [&](int q, int k, double (&dcol)[RI]) {
+    auto column = [&](int q, int k, double (&dcol)[RI], double newest) {
         double d0[RI];
 #pragma unroll
         for (int s = 0; s < RI; s++) {
@@ -422,7 +429,8 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             // instead of 16 with scalar addresses each; the terms reach the multiply-adds as scalar operands
             const int l = lane & 31;   // (KR <= 32; lanes beyond the terms in use fetch nothing)
             const int trow = l < k ? cur0 + k - 1 - l : lag0 + nl - 1 - (l - k);
-            const double tv = l < k + nl ? ld_term(a.V + (size_t)trow * a.ldt + q) : 0.0;
+            double tv = l < k + nl ? ld_term(a.V + (size_t)trow * a.ldt + q) : 0.0;
+            if (l == 0 && k + nl > 0) tv = newest;   // (its store may still be in flight: the owner sent it with the record)
             if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(11); }   // column + term loads: issue -> data
 #pragma unroll
             for (int jj = 0; jj < KR; jj++) vq[jj] = readlane_f64(tv, jj);
@@ -487,7 +495,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
         stamp(-1);
         const bool forced = (k == 0 && blk == 0 && a.forced_q >= 0);
         int q, p, ent = 0, lea = 0;
-        double rq = 0, dpv = 1.0, xbp = 0;
+        double rq = 0, dpv = 1.0, xbp = 0, unew = 0;   // (unew: the newest u term of row p, out of the winner's record)
         bool bland = false;
         double dcol[RI];
         if (!forced) {
@@ -496,7 +504,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             q = (int)fq.i; rq = fq.p0; ent = (int)fq.p1;
             if (fq.i >= (unsigned int)a.nn) { q = 0; rq = __builtin_nan(""); }   // every r_j is NaN: MinIdx returns 0
             if (rq >= -a.tol) { status = ST_OPTIMAL; break; }                    // simplex.go:248
-            column(q, k, dcol);
+            column(q, k, dcol, fq.p3);
             XWin w;
             {
                 double mvv[RI];
@@ -504,7 +512,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
                 w = reduce_rows(mvv, dcol);
             }
             if (dead) break;
-            p = (int)w.i; dpv = w.p0; xbp = w.p1; lea = (int)w.p2;
+            p = (int)w.i; dpv = w.p0; xbp = w.p1; lea = (int)w.p2; unew = w.p3;
             const double mv = w.m;
             if (mv == inf || w.i >= (unsigned int)a.m) { status = ST_UNBOUNDED; break; }   // simplex.go:328-330
             if (a.guard > 0 && (mv <= a.guard || fabs(dpv) <= a.guard) && !(k == 0 && blk == 0 && a.exact_once)) { status = ST_NEED_EXACT; break; }   // degenerate (or nearly): decided on a fresh x_B
@@ -529,7 +537,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
                     cand = (int)fc.i;
                     const double rqc = fc.p0;
                     const int entc = (int)fc.p1;
-                    column(cand, k, dcol);
+                    column(cand, k, dcol, fc.p3);
                     XWin w2;
                     {
                         double mvv[RI];
@@ -539,7 +547,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
                     if (dead) break;
                     if (w2.m == inf || w2.i >= (unsigned int)a.m) { status = ST_UNBOUNDED; break; }   // :356-360
                     if (fabs(w2.m) > 1e-12) {   // :362
-                        q = cand; p = (int)w2.i; rq = rqc; ent = entc; dpv = w2.p0; xbp = w2.p1; lea = (int)w2.p2;
+                        q = cand; p = (int)w2.i; rq = rqc; ent = entc; dpv = w2.p0; xbp = w2.p1; lea = (int)w2.p2; unew = w2.p3;
                         found = true;
                         break;
                     }
@@ -550,7 +558,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
                     const XWin gw = reduce_rows(gl2, dcol);
                     if (dead) break;
                     if (gw.m == 0.0) {   // :368-379
-                        q = cand; p = (int)gw.i; rq = rqc; ent = entc; dpv = gw.p0; xbp = gw.p1; lea = (int)gw.p2;
+                        q = cand; p = (int)gw.i; rq = rqc; ent = entc; dpv = gw.p0; xbp = gw.p1; lea = (int)gw.p2; unew = gw.p3;
                         found = true;
                         break;
                     }
@@ -568,13 +576,13 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             if (dead) break;
             ent = (int)fc.p1;
             if (!a.forced_nocommit) rq = fc.p0;   // a pivot the host decided on fresh solves (exact_step): a pivot like any other
-            column(q, k, dcol);
+            column(q, k, dcol, fc.p3);
             double gl2[RI];
 #pragma unroll
             for (int s = 0; s < RI; s++) gl2[s] = (gidx(s) == p) ? 0.0 : inf;
             const XWin gw = reduce_rows(gl2, dcol);
             if (dead) break;
-            dpv = gw.p0; xbp = gw.p1; lea = (int)gw.p2;
+            dpv = gw.p0; xbp = gw.p1; lea = (int)gw.p2; unew = gw.p3;
         }
         // ---- row p for this thread's columns, reduced costs, block terms (formulas of k_bt_inner2)
         const double rinv = 1.0 / dpv, nrinv = -rinv;
@@ -593,7 +601,8 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
         if constexpr (LOOP) {
             const int l = lane & 31;   // (KR <= 32; lanes beyond the terms in use fetch nothing)
             const int trow = l < k ? cur0 + k - 1 - l : lag0 + nl - 1 - (l - k);
-            const double tv = l < k + nl ? ld_term(a.U + (size_t)trow * a.ldu + p) : 0.0;
+            double tv = l < k + nl ? ld_term(a.U + (size_t)trow * a.ldu + p) : 0.0;
+            if (l == 0 && k + nl > 0) tv = unew;
             if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(12); }   // row + term loads: issue -> data
 #pragma unroll
             for (int jj = 0; jj < KR; jj++) up[jj] = readlane_f64(tv, jj);
@@ -601,6 +610,9 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
 #pragma unroll
             for (int jj = 0; jj < KR; jj++) up[jj] = jj < k ? ld_term(a.U + (size_t)(k - 1 - jj) * a.ldu + p) : 0.0;
         }
+        // loop mode: the previous pivot's term stores have landed before this pivot's are issued — by this pivot's posts (which carry
+        // only the newest term) every older term is in U / V for the readers; in practice they landed during the exchanges
+        if constexpr (LOOP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int s = 0; s < RI; s++) {
             const int i = gidx(s);
