@@ -881,6 +881,11 @@ BtGroupCfg bt_group_cfg(int m, int ldt, int knob) {
     if (knob < 0) return c;
     const int need = m > ldt ? m : ldt;
     auto fits = [&](int G, int nt, int ri) { return (long)G * nt * ri >= need; };
+    if (knob == 16) {   // the loop-kernel shapes also below their default range (1024 rows and less: measurement knob)
+        if (need <= 2048) c = {8, 256, 1};
+        else if (need <= 4096) c = {8, 512, 1};
+        return c;
+    }
     if (knob == 2 || knob == 4 || knob == 8) {
         const int G = knob;
         if (fits(G, 512, 1)) c = {G, 512, 1};

@@ -84,7 +84,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "bt_upd_valu") bt_upd_valu_ = v ? 1 : 0;
     else if (key == "bt_fault") bt_fault_ = v ? 1 : 0;
     else if (key == "general_device") general_device_ = v ? 1 : 0;
-    else if (key == "bt_groups") { if (v != -1 && v != 0 && v != 2 && v != 4 && v != 8) return GOMILP_ERR_BAD_SHAPE; bt_groups_ = v; }
+    else if (key == "bt_groups") { if (v != -1 && v != 0 && v != 2 && v != 4 && v != 8 && v != 16) return GOMILP_ERR_BAD_SHAPE; bt_groups_ = v; }
     else if (key == "bt_stamps") bt_stamps_ = v ? 1 : 0;
     else if (key == "bt_lag") bt_lag_ = v ? 1 : 0;
     else if (key == "exact_degenerate") { if (v < 0 || v > 2) return GOMILP_ERR_BAD_SHAPE; exact_degenerate_ = v; }

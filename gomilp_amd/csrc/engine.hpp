@@ -134,6 +134,7 @@ class Engine {
     // one iteration of the reference on fresh solves (engine_tableau.cpp): the decision a degenerate or tied pivot needs
     int exact_step(const Problem &P, int phase, double tol, int nn, int *q_out, int *p_out, gomilp_lp_stats *st);
     int cond_check(const Problem &P, int nn, double *k1, double *kinf);
+    int groups_knob(const Problem &P) const;
     bool ensure_host_A(const Problem &P);
     // findLinearlyIndependent with the scan on the device (general_kernels.hip) and the last, square step on the host
     int find_independent_device(const Problem &P, std::vector<int32_t> &basic, std::vector<double> *binv_out);

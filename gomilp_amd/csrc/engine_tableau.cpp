@@ -196,8 +196,17 @@ void Engine::bt_layout(const Problem &P, bool tiled) {
     t_tiled_ = tiled;
 }
 
+// knob "bt_groups" as the shape functions see it: by default (0) relaxations of 769..1024 rows / columns also take the loop-kernel
+// shapes (value 16) — the persistent kernel's 3.75 us per pivot with the update hidden beat the single-workgroup block kernel's 3.1 us +
+// update + two launch boundaries per 8 pivots (C2: 5.27 -> 4.74 ms per loop); below that the two are level (512 rows: 1.21 ms both)
+int Engine::groups_knob(const Problem &P) const {
+    if (bt_groups_ != 0 || !bt_lag_ || bt_stamps_ || block_k_ != 0 || max_pivots_ != 0) return (int)bt_groups_;
+    const int need = std::max(P.m, ldt_);
+    return (need > 768 && need <= 1024) ? 16 : 0;
+}
+
 void Engine::bt_plan(const Problem &P, int *K, bool *tiled, bool *lag) const {
-    const BtGroupCfg gc = bt_old_ ? BtGroupCfg{0, 0, 0} : bt_group_cfg(P.m, ldt_, (int)bt_groups_);
+    const BtGroupCfg gc = bt_old_ ? BtGroupCfg{0, 0, 0} : bt_group_cfg(P.m, ldt_, groups_knob(P));
     if (lag) *lag = false;
     if (gc.groups) {   // multi-workgroup block kernel: 16 terms per row / column in registers, tiled layout
         *K = block_k_ > 0 ? (int)std::min<int64_t>(block_k_, 16) : 16;
@@ -237,7 +246,7 @@ BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int
     // (and for inputs whose entries span more than nine decades: their updated tableau loses digits, the exact steps check and rebuild it)
     a.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && (P.m <= 256 || gen_start_ || badly_scaled_))) ? 1e-9 : 0.0;
     if (a.tiled && !bt_old_) {
-        const BtGroupCfg gc = bt_group_cfg(P.m, ldt_, (int)bt_groups_);
+        const BtGroupCfg gc = bt_group_cfg(P.m, ldt_, groups_knob(P));
         a.groups = gc.groups; a.group_ri = gc.ri; a.group_nt = gc.nt; a.xbuf = w.xbuf;
     }
     return a;
@@ -417,7 +426,7 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
         ~LoopSlot() { if (slot >= 0) Engine::loop_release(dev, weight, slot); }
     };
     // (weight: the 128-thread shape shares the device with up to three others, every other shape runs alone — engine.cpp)
-    const bool small_loop = lag && K == 8 && loop_g_ != 8 && !bt_stamps_ && bt_group_cfg(P.m, ldt_, (int)bt_groups_).nt == 256;
+    const bool small_loop = lag && K == 8 && loop_g_ != 8 && !bt_stamps_ && bt_group_cfg(P.m, ldt_, groups_knob(P)).nt == 256;
     LoopSlot loop_slot(device_, small_loop ? 1 : 4, lag);
     const int loop_xcd = (small_loop && loop_slot.slot > 0) ? 2 * loop_slot.slot : 0;
     bt_layout(P, tiled_plan);
@@ -472,7 +481,9 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
             if (ai.groups == 8 && ai.group_nt == 512 && ai.group_ri == 1 && loop_g_ != 8 && (K == 16 || K == 12)) { ai.groups = 16; ai.group_nt = 256; }
             // 1025..2048 rows: 16 x 128 threads (two waves per workgroup: a cheaper workgroup stage in front of every exchange; measured
             // 11.47 ms against 11.85 ms per solve of the metric LP for 8 x 256)
-            if (ai.groups == 8 && ai.group_nt == 256 && ai.group_ri == 1 && loop_g_ != 8 && K == 8 && !bt_stamps_) { ai.groups = 16; ai.group_nt = 128; }
+            if (ai.groups == 8 && ai.group_nt == 256 && ai.group_ri == 1 && loop_g_ != 8 && K == 8 && !bt_stamps_) {
+                ai.groups = 16; ai.group_nt = 128;   // (8 x 128 threads measured the same at 1024 rows: 4.74 against 4.75 ms per loop of C2)
+            }
             ai.Tbuf[0] = w.T[0]; ai.Tbuf[1] = w.T[1];
             ai.xcd = loop_xcd; ai.upd_cap = (int)loop_upd_; ai.poll_delay = (int)poll_delay_;
             // beyond 2048 rows the tableau pair (268 MB at 4096 x 4096) no longer fits the Infinity Cache: all 240 update workgroups

@@ -13,5 +13,5 @@ for spec in sys.argv[2:]:
         r = p.solve(0.0)
         best = min(best, r.stats["seconds_pivot_loop"])
     n = r.stats["pivots_phase1"] + r.stats["pivots_phase2"]
-    print(name, spec, "status", r.status, "pivots", n, "best loop_ms %.3f" % (1e3 * best), "us/pivot %.3f" % (1e6 * best / n), "z %.17g" % r.z, flush=True)
+    print(name, spec, "status", r.status, "pivots", n, "total_ms %.3f" % (1e3 * r.stats["seconds_total"]), "best loop_ms %.3f" % (1e3 * best), "us/pivot %.3f" % (1e6 * best / n), "z %.17g" % r.z, flush=True)
     cx.close()
