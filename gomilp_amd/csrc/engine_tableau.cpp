@@ -196,13 +196,14 @@ void Engine::bt_layout(const Problem &P, bool tiled) {
     t_tiled_ = tiled;
 }
 
-// knob "bt_groups" as the shape functions see it: by default (0) relaxations of 769..1024 rows / columns also take the loop-kernel
-// shapes (value 16) — the persistent kernel's 3.75 us per pivot with the update hidden beat the single-workgroup block kernel's 3.1 us +
-// update + two launch boundaries per 8 pivots (C2: 5.27 -> 4.74 ms per loop); below that the two are level (512 rows: 1.21 ms both)
+// knob "bt_groups" as the shape functions see it: by default (0) relaxations of 600..1024 rows also take the loop-kernel shapes
+// (value 16) — the persistent kernel's 3.75 us per pivot with the update hidden beat the single-workgroup block kernel's 3.1 us +
+// update + two launch boundaries per 8 pivots (loop of C2: 5.27 -> 4.74 ms; 600 rows: 1.24 -> 1.13; 700: 2.56 -> 2.35; 900: 2.73 ->
+// 2.48); at 512 rows the two are level (1.21 ms both) and the 520-row children of the 512-row trees keep the single-workgroup kernel
 int Engine::groups_knob(const Problem &P) const {
     if (bt_groups_ != 0 || !bt_lag_ || bt_stamps_ || block_k_ != 0 || max_pivots_ != 0) return (int)bt_groups_;
     const int need = std::max(P.m, ldt_);
-    return (need > 768 && need <= 1024) ? 16 : 0;
+    return (P.m >= 600 && need <= 1024) ? 16 : 0;
 }
 
 void Engine::bt_plan(const Problem &P, int *K, bool *tiled, bool *lag) const {

@@ -2,7 +2,7 @@
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gomilp_amd import lp, synth
 name = sys.argv[1]
-m, seed = synth.CONFIGS[name]
+m, seed = synth.CONFIGS[name] if name in synth.CONFIGS else (int(name[1:]), 21)   # "m640": a 640-row LP of the same family
 c, A, b = synth.dense_lp_standard_form(m, seed)
 for spec in sys.argv[2:]:
     knobs = dict((k, int(v)) for k, v in (kv.split("=") for kv in spec.split(",") if kv))
