@@ -540,6 +540,24 @@ def main() -> int:
                                    "one device-batched schedule: k_bt_innerG_batch, one XCD per LP, + the batched MFMA rank-16 update")}
         poolb.close()
 
+    # ---- BASELINE config 2: the 1024x2048 LP (one relaxation, no B&B)
+    if args.c4 and args.workload == "M":
+        m2, seed2 = synth.CONFIGS["C2"]
+        c2, A2, b2 = synth.dense_lp_standard_form(m2, seed2)
+        cx2 = lp.Context(device=local_rank)
+        p2 = cx2.upload(c2, A2, b2)
+        p2.solve(0.0)
+        t1 = time.perf_counter()
+        r2 = p2.solve(0.0)
+        t2 = time.perf_counter() - t1
+        out["c2"] = {"workload": "C2: %dx%d dense LP (seed %d), one full solve" % (m2, 2 * m2, seed2), "status": int(r2.status),
+                     "pivots": int(r2.stats["pivots_phase2"]), "seconds": t2, "pivots_per_s": r2.stats["pivots_phase2"] / t2,
+                     "loop_us_per_pivot": 1e6 * r2.stats["seconds_pivot_loop"] / max(r2.stats["pivots_phase2"], 1),
+                     "note": "persistent loop kernel (16 x 128-thread pivot workgroups, blocks of 8), as at the metric size"}
+        p2.free()
+        cx2.close()
+        del c2, A2, b2
+
     # ---- BASELINE config 4: one solve of the 4096x8192 LP
     if args.c4 and args.workload != "C4":
         m4, seed4 = synth.CONFIGS["C4"]
