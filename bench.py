@@ -35,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LOOP_CHUNK = 512       # pivots per launch of the persistent loop kernel: handed to the engine (knob "loop_chunk") AND used by the byte model below
 
 
 def parse_args():
@@ -127,8 +128,41 @@ def main() -> int:
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    def summary_of(o):
+        """The handful of figures a reader of the line's first or last 2000 characters must find (the driver keeps a tail)."""
+        def g(*path):
+            cur = o
+            for k in path:
+                if not isinstance(cur, dict) or k not in cur or cur[k] is None:
+                    return None
+                cur = cur[k]
+            return cur
+        sm = {"value": o.get("value"), "unit": o.get("unit"), "ms_per_step": o.get("ms_per_step"),
+              "roofline_frac": g("roofline", "frac"), "us_per_pivot": g("roofline", "us_per_pivot"),
+              "final_solve_ms": None if g("breakdown", "final_solve_s") is None else 1e3 * g("breakdown", "final_solve_s") / max(o.get("steps", 1), 1),
+              "cpu_pivots_per_s": g("cpu_baseline", "value"),
+              "frontier_relaxations_per_s": g("frontier", "relaxations_per_s"), "frontier_wave_ms": None if g("frontier", "wave_seconds") is None else 1e3 * g("frontier", "wave_seconds"),
+              "frontier_scaling_bound_per_s": g("frontier", "scaling_bound", "max_relaxations_per_s"),
+              "heaviest_child_ms": None if g("frontier", "scaling_bound", "heaviest_child", "seconds_alone") is None else 1e3 * g("frontier", "scaling_bound", "heaviest_child", "seconds_alone"),
+              "frontier_wide_relaxations_per_s": g("frontier_wide", "relaxations_per_s"),
+              "c4_pivots_per_s": g("c4", "pivots_per_s"), "c2_pivots_per_s": g("c2", "pivots_per_s"),
+              "batched_vs_single": g("batched", "vs_single"), "batched_pivots_per_s": g("batched", "pivots_per_s"),
+              "milp_c3_relaxations_per_s": g("milp_c3", "relaxations_per_s"),
+              "degenerate_trees_relaxations_per_s": g("degenerate_trees", "relaxations_per_s"),
+              "warm_start_c3_pivots_per_node": g("warm_start", "c3", "warm_pivots_per_node")}
+        return {k: (round(v, 4) if isinstance(v, float) else v) for k, v in sm.items() if v is not None}
+
     def emit(obj):
-        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+        # `summary` sits right behind the contract keys AND closes the line (`summary_tail`): whichever end a log keeps, the figures are there
+        sm = summary_of(obj)
+        head_keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
+        line = {k: obj[k] for k in head_keys if k in obj}
+        line["summary"] = sm
+        for k, v in obj.items():
+            if k not in line:
+                line[k] = v
+        line["summary_tail"] = sm
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher environment: start it (before anything touches the GPU) and hand back its exit code
@@ -293,7 +327,7 @@ def main() -> int:
             out["scaling_bound"] = {"heaviest_child": solo, "note": "a wave cannot finish before its heaviest child: relaxations/s at any GPU count "
                                     "<= %d / %.2f ms; more GPUs only remove what the other children add to that" % (len(children), 1e3 * solo["seconds_alone"]),
                                     "max_relaxations_per_s": len(children) / solo["seconds_alone"]}
-        roof = {"bound": "hbm", "limited_by": "latency: one workgroup per relaxation, two workgroup-wide argmins and two dependent tableau reads per pivot",
+        roof = {"bound": "hbm", "bound_kind": "latency", "limited_by": "latency: one workgroup per relaxation, two workgroup-wide argmins and two dependent tableau reads per pivot",
                 "kernel": "k_bt_inner2_batch<512,2,2,8,0>", "achieved": acc["pivots"] * alg_bytes / max(acc["inner"], 1e-30) / 1e9 if acc["inner"] > 0 else 0.0,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "note": "one workgroup per relaxation, two workgroup-wide argmins and two dependent tableau reads per pivot: bound by "
@@ -361,7 +395,7 @@ def main() -> int:
     m, seed = synth.CONFIGS[args.workload]
     c, A, b = synth.dense_lp_standard_form(m, seed)
     n = A.shape[1]
-    ctx = lp.Context(device=local_rank, chunk=args.chunk, sample_events=args.sample_events)
+    ctx = lp.Context(device=local_rank, chunk=args.chunk, sample_events=args.sample_events, loop_chunk=LOOP_CHUNK)
     prob = ctx.upload(c, A, b)  # inputs resident in HBM before the timed region
 
     def step():
@@ -415,9 +449,9 @@ def main() -> int:
             loop_name = "k_bt_loop<16,128,1,8>" if need <= 2048 else "k_bt_loop<16,256,1,16>"
             traffic, tsrc = newest_pmc("k_bt_loop")
             bytes_block = bytes_inner + bytes_update
-            bpl = 512.0 / K   # sampled launches are full ones: loop_chunk (512 pivots) / K blocks
+            bpl = max(4.0, float(LOOP_CHUNK // int(K)))   # sampled launches are full ones: loop_chunk / K blocks (engine_tableau.cpp: blocks_per_chunk)
             roofline = {
-                "bound": "hbm", "kernel": loop_name, "time_share": loop_s / dt,
+                "bound": "hbm", "bound_kind": "latency", "kernel": loop_name, "time_share": loop_s / dt,
                 "achieved": bytes_block / t_inner / 1e9 if t_inner > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "traffic": traffic, "traffic_source": tsrc,
                 "bytes_per_launch": bpl * bytes_block, "avg_launch_us": 1e6 * t_inner * bpl, "blocks_per_launch": int(bpl),
@@ -442,7 +476,7 @@ def main() -> int:
             share_inner = t_inner / max(t_inner + t_upd, 1e-30)
             traffic, tsrc = newest_pmc(inner_name.split("<")[0] + "<")
             roofline = {
-                "bound": "hbm", "limited_by": "latency (two argmins over all columns / rows and two dependent tableau reads per pivot)", "kernel": inner_name,
+                "bound": "hbm", "bound_kind": "latency", "limited_by": "latency (two argmins over all columns / rows and two dependent tableau reads per pivot)", "kernel": inner_name,
                 "time_share": share_inner * loop_s / dt,
                 "achieved": bytes_inner / t_inner / 1e9 if t_inner > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "traffic": traffic, "traffic_source": tsrc,

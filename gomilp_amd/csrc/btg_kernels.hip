@@ -108,7 +108,9 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
     static_assert(!LOOP || KR == 16 || KR == 24 || KR == 32, "loop mode: KR / 2 lagging + KR / 2 current terms");
     constexpr int KB = LOOP ? KR / 2 : KR;   // pivots per block
     static_assert(G == 2 || G == 4 || G == 8 || G == 16, "G");
-    if (a.fault && g == 1) return;   // test hook: a workgroup that never takes part -> the others must give up (ST_XCHG_TIMEOUT)
+#ifdef GOMILP_DEBUG
+    if (a.fault && g == 1) return;   // test hook (diagnostic flavour only): a workgroup that never takes part -> the others must give up (ST_XCHG_TIMEOUT)
+#endif
     __shared__ double redM[16];
     __shared__ unsigned int redI[16];
     __shared__ double pay[16][4];

@@ -38,6 +38,7 @@ struct gomilp_pool {
     int batched = 1;            // knob: 0 = every relaxation through a worker's single-relaxation engine (round-1 path)
     std::unique_ptr<BatchEngine> batch;
     std::unique_ptr<BatchEngine> batch2;   // second schedule for waves of large relaxations (created on first use)
+    int cond_guard = 1, exact_degenerate = 1, sample_batch = 0;   // knob values kept for batch2: both halves of a split wave decide alike
     int split_large = 1;        // knob: waves of >= 4 large relaxations run as two interleaved schedules
     int large_loop = 0;         // knob: relaxations of 1025..2048 rows / columns run on the workers' persistent loop kernels (four at a
                                 // time, each with its pivot workgroups on an XCD of its own) instead of the batched launch pairs.  Off:
@@ -153,9 +154,22 @@ int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value) {
     if (std::string(key) == "batched") { pool->batched = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "split_large") { pool->split_large = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "large_loop") { pool->large_loop = value ? 1 : 0; return GOMILP_OK; }
-    if (std::string(key) == "sample_batch") { pool->batch->set_sampling(value != 0); return GOMILP_OK; }
-    if (std::string(key) == "cond_guard") pool->batch->set_cond_guard((int)value);
-    if (std::string(key) == "exact_degenerate") pool->batch->set_exact_degenerate((int)value);   // (and the workers' engines below)
+    if (std::string(key) == "sample_batch") {
+        pool->sample_batch = value != 0;
+        pool->batch->set_sampling(value != 0);
+        if (pool->batch2) pool->batch2->set_sampling(value != 0);
+        return GOMILP_OK;
+    }
+    if (std::string(key) == "cond_guard") {
+        pool->cond_guard = (int)value;
+        pool->batch->set_cond_guard((int)value);
+        if (pool->batch2) pool->batch2->set_cond_guard((int)value);
+    }
+    if (std::string(key) == "exact_degenerate") {   // (and the workers' engines below)
+        pool->exact_degenerate = (int)value;
+        pool->batch->set_exact_degenerate((int)value);
+        if (pool->batch2) pool->batch2->set_exact_degenerate((int)value);
+    }
     int rc = GOMILP_OK;
     for (auto &e : pool->eng) { const int r = e->set(key, value); if (r != GOMILP_OK) rc = r; }
     return rc;
@@ -267,7 +281,7 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
         const double t_up = busy_since(s0);
         const int rc = E.finish_from_basis(id, basic, xb, loop_rc, &z, x.data(), &hx, nullptr, &st);
         E.free_problem(id);
-        if (getenv("GOMILP_DEBUG_TASKS") && busy_since(s0) > 5e-3)
+        if (GOMILP_DBG_ENV("GOMILP_DEBUG_TASKS") && busy_since(s0) > 5e-3)
             fprintf(stderr, "slow finish: worker %d child %lld upload %.2f ms finish %.2f ms (device %.2f host %.2f) rounds %lld dense %lld\n", w, (long long)i, 1e3 * t_up,
                     1e3 * st.seconds_total, 1e3 * st.seconds_final_device, 1e3 * st.seconds_final_host, (long long)st.lu_rounds, (long long)st.lu_dense_steps);
         status_out[i] = rc; z_out[i] = z; has_x_out[i] = hx;
@@ -323,7 +337,12 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
         const bool two = pool->split_large && count >= 4 && gomilp::bt_batch_k(m_big, gomilp::batch_ldt(nn_big)) == 16;
         int rc;
         if (two) {
-            if (!pool->batch2) pool->batch2.reset(new BatchEngine(pool->device));
+            if (!pool->batch2) {
+                pool->batch2.reset(new BatchEngine(pool->device));
+                pool->batch2->set_cond_guard(pool->cond_guard);
+                pool->batch2->set_exact_degenerate(pool->exact_degenerate);
+                pool->batch2->set_sampling(pool->sample_batch != 0);
+            }
             const int64_t half = count / 2;
             BatchEngine::Stats bs2;
             int rc2 = GOMILP_OK;

@@ -1,6 +1,15 @@
 // Shared host/device plain structs for the gfx950 simplex engine.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
+
+// Diagnostic hooks exist only in the -DGOMILP_DEBUG flavour of the library (gomilp_amd/build.py, GOMILP_DEBUG_BUILD=1): the product
+// build reads no environment variable on its paths and carries no fault-injection branch in its kernels.
+#ifdef GOMILP_DEBUG
+#define GOMILP_DBG_ENV(name) getenv(name)
+#else
+#define GOMILP_DBG_ENV(name) (static_cast<const char *>(nullptr))
+#endif
 
 namespace gomilp {
 
@@ -254,6 +263,7 @@ struct LUArgs {
     int32_t *dense_flag;        // per step: 1 when the step did arithmetic (0 = unit-column fast path); nullable
     LUCtl *ctl;                 // compressed schedule only
     double *Lp, *Up;            // compressed schedule only: compact panels of the running round (32 x ldw each)
+    int32_t slots, pad;         // compressed schedule: the slot form of the panel (lu_compressed.hip k_luc_panel_slots; knob lu_blocked = 3, default)
 };
 
 }  // namespace gomilp

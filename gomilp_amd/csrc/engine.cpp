@@ -41,19 +41,21 @@ Engine::~Engine() {
 // (up to 2048 rows: 136 workgroups of two waves, four fit a CU) leaves room for four launches at once, each with its pivot
 // workgroups on an XCD of its own; the 256- / 512-thread shapes fill the chip (one workgroup per CU) and run alone.
 namespace {
-struct LoopSlots { std::mutex mu; std::condition_variable cv; int used = 0; bool busy[4] = {false, false, false, false}; };
+struct LoopSlots { std::mutex mu; std::condition_variable cv; int used = 0, big_waiting = 0; bool busy[4] = {false, false, false, false}; };
 LoopSlots &loop_slots(int dev) { static LoopSlots s[64]; return s[dev & 63]; }
 }  // namespace
 int Engine::loop_acquire(int dev, int weight) {
     LoopSlots &L = loop_slots(dev);
     std::unique_lock<std::mutex> lk(L.mu);
     if (weight >= 4) {
+        L.big_waiting++;   // from here on no further small launch is admitted: a stream of them would never let `used` reach 0
         L.cv.wait(lk, [&] { return L.used == 0; });
+        L.big_waiting--;
         L.used = 4;
         for (bool &b2 : L.busy) b2 = true;
         return 0;
     }
-    L.cv.wait(lk, [&] { return L.used < 4; });
+    L.cv.wait(lk, [&] { return L.used < 4 && L.big_waiting == 0; });
     L.used++;
     for (int i = 0; i < 4; i++) if (!L.busy[i]) { L.busy[i] = true; return i; }
     return 0;
@@ -76,13 +78,15 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "max_pivots") max_pivots_ = v < 0 ? 0 : v;
     else if (key == "sample_events") sample_events_ = v < 0 ? 0 : v;
     else if (key == "fused") fused_ = v ? 1 : 0;
-    else if (key == "lu_blocked") lu_blocked_ = v < 0 ? 0 : (v > 2 ? 2 : v);  // 0 per column, 1 blocked panels, 2 compressed rounds
+    else if (key == "lu_blocked") lu_blocked_ = v < 0 ? 0 : (v > 3 ? 3 : v);  // 0 per column, 1 blocked panels, 2 compressed rounds (sorted register panel), 3 compressed rounds (slot panel)
     else if (key == "tableau") tableau_ = v ? 1 : 0;
     else if (key == "blocked") blocked_ = v ? 1 : 0;
     else if (key == "bt_nt") { if (v != 0 && v != 256 && v != 512 && v != 1024) return GOMILP_ERR_BAD_SHAPE; bt_nt_ = v; }
     else if (key == "bt_old") bt_old_ = v ? 1 : 0;
     else if (key == "bt_upd_valu") bt_upd_valu_ = v ? 1 : 0;
-    else if (key == "bt_fault") bt_fault_ = v ? 1 : 0;
+#ifdef GOMILP_DEBUG
+    else if (key == "bt_fault") bt_fault_ = v ? 1 : 0;   // fault injection: diagnostic flavour only
+#endif
     else if (key == "general_device") general_device_ = v ? 1 : 0;
     else if (key == "bt_groups") { if (v != -1 && v != 0 && v != 2 && v != 4 && v != 8 && v != 16) return GOMILP_ERR_BAD_SHAPE; bt_groups_ = v; }
     else if (key == "bt_stamps") bt_stamps_ = v ? 1 : 0;
@@ -782,6 +786,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     const bool blocked = compressed || (lu_blocked_ && lu_blocked_supported(m));
     a.dense_flag = blocked ? w.denseflag : nullptr;
     a.ctl = w.luctl; a.Lp = w.luLp; a.Up = w.luUp;
+    a.slots = lu_blocked_ >= 3 ? 1 : 0; a.pad = 0;
     w.st_host->lu_singular = 0;
     sync_state_to_device();
     lu_rounds_ = 0;
@@ -790,7 +795,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
         // batch is sized from the number of columns that are dense for sure.
         launch_luc_init(a, stream_);
         launches_++;
-        const int nb = lu_compressed_nb(m);
+        const int nb = lu_compressed_nb(m, a.slots != 0);
         // measured: steps that do arithmetic ~ 3 x the non-unit columns (each of them usually turns a unit column dense)
         int batch = std::max(1, (3 * nonunit + nb - 1) / nb + 1);
         for (;;) {
@@ -851,7 +856,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     double logdet = 0;
     for (int i = 0; i < m; i++) logdet += log(fabs(diag[phys[i]]));
     *singular = w.st_host->lu_singular != 0 || exp(logdet) == 0;
-    if (*singular && getenv("GOMILP_DEBUG_LOOP")) {
+    if (*singular && GOMILP_DBG_ENV("GOMILP_DEBUG_LOOP")) {
         int nz = 0; double dmin = 1e300;
         for (int i = 0; i < m; i++) { if (diag[phys[i]] == 0) nz++; dmin = std::min(dmin, fabs(diag[phys[i]])); }
         fprintf(stderr, "final_solve: singular (transpose %d, m %d, nd %d, rounds %lld, lu_singular flag %d, logdet %g, zero diagonals %d, min |u_ii| %g, compressed %d)\n",
@@ -1374,6 +1379,7 @@ bool Engine::root_view(int64_t id, RootView *out) {
     std::lock_guard<std::mutex> g(mu_);
     if (id < 0 || (size_t)id >= problems_.size() || !problems_[id]) return false;
     const Problem &P = *problems_[id];
+    out->gen.reset();   // a view is reused across roots (gomilp_pool_set_root): never keep the previous root's searched basis
     out->m = P.m; out->n = P.n; out->ld = P.ld; out->dAt = P.dAt; out->dc = P.dc; out->db = P.db;
     out->verify_status = P.verify_status; out->serial = P.serial; out->hb = P.hb; out->hc = P.hc; out->scale_span = P.scale_span;
     out->rho0.assign(P.m, 0);
@@ -1583,7 +1589,7 @@ int Engine::find_independent_device(const Problem &P, std::vector<int32_t> &basi
             rcl = general_finish_last_column(P.hA, m, n, basic, cand - 1, binv_out);
         }
     }
-    if (getenv("GOMILP_DEBUG_GS")) fprintf(stderr, "gs: m %d scanned %d scan %.2f ms last column %.2f ms\n", m, w.gs_host->scanned, 1e3 * (t_scan - t_gs0), 1e3 * (now_s() - t_scan));
+    if (GOMILP_DBG_ENV("GOMILP_DEBUG_GS")) fprintf(stderr, "gs: m %d scanned %d scan %.2f ms last column %.2f ms\n", m, w.gs_host->scanned, 1e3 * (t_scan - t_gs0), 1e3 * (now_s() - t_scan));
     return rcl;
 }
 

@@ -293,8 +293,9 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
         double k1 = 0, kinf = 0;
         int rc0 = cond_check(P, nn, &k1, &kinf);
         if (rc0 != GOMILP_OK) return -rc0;
-        if (k1 > 1e16 || k1 != k1) return -GOMILP_ERR_CONDITION;
-        if (kinf > 1e16 || kinf != kinf) return -GOMILP_ERR_LINSOLVE;
+        // (kappa_inf belongs to the x_B solve that closed the PREVIOUS iteration, simplex.go:289-292: the reference would have left
+        // its loop there with mat.Condition, before this iteration's computeMove could report lp.ErrLinSolve)
+        if (k1 > 1e16 || k1 != k1 || kinf > 1e16 || kinf != kinf) return -GOMILP_ERR_CONDITION;
     }
     auto cost = [&](int var) -> double { return phase == 1 ? (var == n ? 1.0 : 0.0) : (var < n ? P.hc[var] : 0.0); };
     std::vector<double> cb(m), y, xb, dsol, col(m);
@@ -302,7 +303,7 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
     bool sing = false;
     int rc;
     if ((rc = final_solve(P, n, y, &sing, basic.data(), true, cb.data())) != GOMILP_OK) return -rc;
-    if (sing) { if (getenv("GOMILP_DEBUG_LOOP")) fprintf(stderr, "exact_step: ab^T singular (phase %d, m %d)\n", phase, m); return -GOMILP_ERR_LINSOLVE; }
+    if (sing) { if (GOMILP_DBG_ENV("GOMILP_DEBUG_LOOP")) fprintf(stderr, "exact_step: ab^T singular (phase %d, m %d)\n", phase, m); return -GOMILP_ERR_LINSOLVE; }
     {
         std::vector<double> ypad(P.ld, 0.0);
         std::copy(y.begin(), y.begin() + m, ypad.begin());
@@ -316,7 +317,7 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
     for (int j = 0; j < nn; j++) r[j] = w.h_vec[j];
     // x_B of this iteration (simplex.go:289 of the previous one): resident from here on
     if ((rc = final_solve(P, n, xb, &sing, basic.data())) != GOMILP_OK) return -rc;
-    if (sing) { if (getenv("GOMILP_DEBUG_LOOP")) fprintf(stderr, "exact_step: ab singular for x_B (phase %d, m %d)\n", phase, m); return -GOMILP_ERR_LINSOLVE; }
+    if (sing) { if (GOMILP_DBG_ENV("GOMILP_DEBUG_LOOP")) fprintf(stderr, "exact_step: ab singular for x_B (phase %d, m %d)\n", phase, m); return -GOMILP_ERR_LINSOLVE; }
     {
         std::vector<double> xpad(P.ld, 0.0);
         std::copy(xb.begin(), xb.begin() + m, xpad.begin());
@@ -355,7 +356,7 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
             launch_tab_gemm(w.binv[0], P.ld, P.dAt, P.ld, m, nn, w.nonbasic, w.T[tcur_], ldt_, t_tiled_, stream_);
             launches_++;
             if (st) st->refreshes++;
-            if (getenv("GOMILP_DEBUG_LOOP")) fprintf(stderr, "exact_step: tableau rebuilt (column error %.3g of %.3g, m %d)\n", err, scale, m);
+            if (GOMILP_DBG_ENV("GOMILP_DEBUG_LOOP")) fprintf(stderr, "exact_step: tableau rebuilt (column error %.3g of %.3g, m %d)\n", err, scale, m);
         }
     }
     std::vector<double> move(m);
@@ -615,7 +616,7 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
             w.loop_launches = 0;
             xchg_timeout_ = true;
         }
-        if (getenv("GOMILP_DEBUG_LOOP")) fprintf(stderr, "run_loop_bt: device status %d after %lld pivots (lag %d, loop_blocks %d)\n", hs.status, (long long)hs.pivots, (int)lag, hs.loop_blocks);
+        if (GOMILP_DBG_ENV("GOMILP_DEBUG_LOOP")) fprintf(stderr, "run_loop_bt: device status %d after %lld pivots (lag %d, loop_blocks %d)\n", hs.status, (long long)hs.pivots, (int)lag, hs.loop_blocks);
         ret = GOMILP_ERR_DEVICE;
         break;
     }
@@ -850,7 +851,8 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         double k1 = 0, kinf = 0;
         if ((rc = cond_check(P, nn, &k1, &kinf)) != GOMILP_OK) return rc;
         st->cond1_final = k1; st->condinf_final = kinf;
-        if (k1 > 1e16 || k1 != k1) *loop_rc = GOMILP_ERR_CONDITION;
+        // kappa_inf: the x_B solve behind the last pivot (simplex.go:289-292, CondNorm = MaxRowSum) ends the loop with mat.Condition too
+        if (k1 > 1e16 || k1 != k1 || kinf > 1e16 || kinf != kinf) *loop_rc = GOMILP_ERR_CONDITION;
     }
     return GOMILP_OK;
 }
@@ -901,7 +903,7 @@ int Engine::cond_check(const Problem &P, int nn, double *k1, double *kinf) {
         *k1 = n1 * inverse_norm1_estimate(inv, m, false);
         *kinf = ninf * inverse_norm1_estimate(inv, m, true);
     }
-    if (getenv("GOMILP_DEBUG_LOOP")) fprintf(stderr, "cond_check: m %d tableau kappa_1 %.6g kappa_inf %.6g -> fresh %.6g %.6g\n", m, tk1, tkinf, *k1, *kinf);
+    if (GOMILP_DBG_ENV("GOMILP_DEBUG_LOOP")) fprintf(stderr, "cond_check: m %d tableau kappa_1 %.6g kappa_inf %.6g -> fresh %.6g %.6g\n", m, tk1, tkinf, *k1, *kinf);
     return GOMILP_OK;
 }
 

@@ -309,6 +309,271 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
 #undef GOMILP_FOR_ROWS
 }
 
+// ---- slot form of the panel (round 4; default) -------------------------------------------------------------------------------
+// Same arithmetic, same step order, another register discipline.  k_luc_panel above keeps its NB columns SORTED in registers: every
+// dense step shifts all of them by one (the update folded into the shift behind 64-bit selects), and a column that becomes dense
+// inside the round is inserted at its sorted position through a select chain over all NB registers — ~390 VALU instructions per
+// wave and step, 4 waves per SIMD: the panel was issue-bound on ONE CU (4.7 us per dense step at 2048 rows, 20 % of the metric
+// solve).  Here a column lives in a fixed SLOT for as long as it is listed:
+//   * the step's column is the live slot with the smallest column index (wave 0: one DPP minimum over <= 32 lanes); its register is
+//     read with a UNIFORM dynamic index (v_movrels: the slot number is the same in every lane);
+//   * only the live slots are updated (uniform branch per slot: 1 LDS broadcast read + 2 VALU per row), nothing is shifted;
+//   * the slot of the step's own column is free afterwards, so a unit column that just became dense ALWAYS finds a slot (no
+//     dropping), and a round goes on for up to SMAX dense steps instead of ending when the first NB columns are used up;
+//   * columns still live when the round ends (step cap, or the run met a dense column that is not listed) are handed to the
+//     trailing kernels through the record the old panel used for dropped columns: rows that left while the column was listed hold
+//     final values in it, all other rows still hold the original.
+// Rows of retired rows keep whatever the later updates make of them (never read again): no predication on the update itself.
+template <int T, int RPT, int NB, int SMAX>
+__global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__restrict__ pivrow) {
+    constexpr int NW = T / 64;
+    constexpr int MAXM = T * RPT;
+    static_assert(NB <= 32 && SMAX <= 32 && NW <= 16, "slots / steps per round are recorded in 32-entry tables");
+    typedef unsigned short idx_t;            // m <= 4096
+    typedef double vec __attribute__((ext_vector_type(NB)));
+    constexpr idx_t NONE = 0xFFFF;
+    __shared__ idx_t s_lpos[MAXM];    // logical position of physical row R
+    __shared__ idx_t s_rowat[MAXM];   // physical row at logical position
+    __shared__ idx_t s_unit[MAXM];    // unit_row per column (NONE: not a unit column)
+    __shared__ idx_t s_ucol[MAXM];    // inverse: the unit column of a row (NONE: none)
+    __shared__ unsigned char s_active[MAXM];
+    __shared__ double prow[2][NB];    // the pivot row's values by slot
+    __shared__ double s_rinv[2];
+    __shared__ double redM[2][16];
+    __shared__ unsigned int redL[2][16];
+    __shared__ int s_slotcol[NB];     // column listed in each slot
+    __shared__ int s_slotin[NB];      // dense step after which it joined (-1: round start)
+    __shared__ int s_nload, s_stop, s_limit, s_sigma, s_ins;
+    LUCtl *ctl = a.ctl;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m = a.m;
+    const size_t ldw = (size_t)a.ldw;
+    const int k0 = ctl->k_next;
+    if (k0 >= m) {
+        if (tid == 0) { ctl->nsteps = 0; ctl->ndrop = 0; }
+        return;
+    }
+    for (int R = tid; R < MAXM; R += T) {
+        const bool in = R < m;
+        s_lpos[R] = (idx_t)(in ? a.lpos[R] : R);
+        s_active[R] = (in && a.rowstep[R] < 0) ? 1 : 0;
+        const int ur = (in && a.unit_row) ? a.unit_row[R] : -1;
+        s_unit[R] = ur < 0 ? NONE : (idx_t)ur;
+        s_ucol[R] = NONE;
+    }
+    __syncthreads();
+    for (int R = tid; R < m; R += T) {
+        s_rowat[s_lpos[R]] = (idx_t)R;
+        if (s_unit[R] != NONE) s_ucol[s_unit[R]] = (idx_t)R;   // column R is the unit vector of row s_unit[R]
+    }
+    if (w == 0) {
+        // the first NB columns >= k0 that are dense for sure
+        int n = 0;
+        for (int base = k0; base < m && n < NB; base += 64) {
+            const int k = base + lane;
+            bool dense = false;
+            if (k < m) {
+                const idx_t ur = s_unit[k];
+                dense = ur == NONE || !s_active[ur];
+            }
+            const unsigned long long mask = __ballot(dense);
+            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            if (dense && n + rank < NB) s_slotcol[n + rank] = k;
+            n += __popcll(mask);
+        }
+        if (lane == 0) s_nload = n < NB ? n : NB;
+        if (lane < NB) s_slotin[lane] = -1;
+    }
+    __syncthreads();
+    const int nload = s_nload;
+    unsigned int live = nload >= 32 ? 0xFFFFFFFFu : ((1u << nload) - 1u);   // uniform: every thread keeps the same copy
+    vec v[RPT];
+    int Rr[RPT];
+    bool act[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+        Rr[r] = tid + r * T;
+        act[r] = (Rr[r] < m) && s_active[Rr[r] < m ? Rr[r] : 0];
+        const double *src = a.W + (act[r] ? Rr[r] : 0);
+#pragma unroll
+        for (int c = 0; c < NB; c++) v[r][c] = (act[r] && c < nload) ? src[(size_t)s_slotcol[c < nload ? c : 0] * ldw] : 0.0;
+    }
+    __syncthreads();   // every thread has taken its rows' `act` from s_active before wave 0's first run clears entries
+    int kcur = k0, s = 0, k1 = m;
+    int pend_slot = -1, pend_col = 0, pend_k = 0;   // (uniform) a column that joined in the previous step: lane 0 of wave 0 lists it
+#pragma unroll 1
+    for (;;) {
+        if (w == 0) {
+            if (lane == 0 && pend_slot >= 0) { s_slotcol[pend_slot] = pend_col; s_slotin[pend_slot] = pend_k; }
+            // the next listed column: smallest column index among the live slots
+            const unsigned int key = (lane < NB && ((live >> lane) & 1u)) ? (unsigned int)s_slotcol[lane < NB ? lane : 0] : 0x7FFFFFFFu;
+            unsigned int mn = row_min_u32(key);
+            mn = min((unsigned int)__builtin_amdgcn_readlane((int)mn, 0), (unsigned int)__builtin_amdgcn_readlane((int)mn, 16));
+            const bool listed = live != 0 && s < SMAX;
+            const int limit = listed ? (int)mn : m;
+            const unsigned long long hit = __ballot(key == mn && lane < NB);
+            const int sigma = hit ? (int)__builtin_ctzll(hit) : 0;
+            // run of bookkeeping steps [kcur, limit) (see k_luc_panel)
+            int k = kcur;
+            for (;;) {
+                const int kk = k + lane;
+                const idx_t ur = kk < limit ? s_unit[kk] : NONE;
+                const bool triv = ur != NONE && s_active[ur];
+                const unsigned long long nt = __ballot(!triv);
+                const int cnt = nt ? (int)__builtin_ctzll(nt) : 64;
+                for (int j = 0; j < cnt; j++) {
+                    const int urj = __builtin_amdgcn_readlane((int)ur, j);
+                    if (lane == 0) {
+                        const idx_t jp = s_lpos[urj], Q = s_rowat[k + j];
+                        s_lpos[Q] = jp; s_rowat[jp] = Q;
+                        s_lpos[urj] = (idx_t)(k + j); s_rowat[k + j] = (idx_t)urj;
+                        s_active[urj] = 0;
+                    }
+                }
+                k += cnt;
+                if (cnt < 64) break;   // the limit or a step that needs arithmetic
+            }
+            if (lane == 0) { s_stop = k; s_limit = limit; s_sigma = sigma; }
+        }
+        pend_slot = -1;
+        __syncthreads();
+        const int kstop = s_stop, limit = s_limit;
+        const int sigma = __builtin_amdgcn_readfirstlane(s_sigma);
+        // rows retired by the run become U rows: their entries in the listed columns are final
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            if (act[r] && !s_active[Rr[r]]) {
+                const int kt = s_lpos[Rr[r]];
+                a.rowstep[Rr[r]] = kt; pivrow[kt] = Rr[r];
+                double *dst = a.W + Rr[r];
+#pragma unroll
+                for (int c = 0; c < NB; c++)
+                    if ((live >> c) & 1u) dst[(size_t)s_slotcol[c] * ldw] = v[r][c];
+                act[r] = false;
+            }
+        }
+        if (kstop < limit || live == 0 || s >= SMAX) { k1 = kstop; break; }
+        const int k = limit;
+        // ---- dense step k on slot sigma: first maximum of |a_ik| in LAPACK row order (as k_luc_panel)
+        double x[RPT];
+        double xm = __builtin_inf();
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            x[r] = v[r][sigma];   // uniform index
+            if (act[r]) xm = vmin_f64(xm, -fabs(x[r]));
+        }
+        const double wm = wave_min_f64(xm);
+        unsigned int lk = 0xFFFFFFFFu;
+        int lpr[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            lpr[r] = -1;
+            if (act[r] && -fabs(x[r]) == wm) { lpr[r] = s_lpos[Rr[r]]; lk = min(lk, (unsigned int)lpr[r]); }
+        }
+        lk = row_min_u32(lk);
+        lk = min(min((unsigned int)__builtin_amdgcn_readlane((int)lk, 15), (unsigned int)__builtin_amdgcn_readlane((int)lk, 31)),
+                 min((unsigned int)__builtin_amdgcn_readlane((int)lk, 47), (unsigned int)__builtin_amdgcn_readlane((int)lk, 63)));
+        double *rm = redM[s & 1];
+        unsigned int *rl = redL[s & 1];
+        if (lane == 0) { rm[w] = wm; rl[w] = lk; }
+        __syncthreads();
+        const double bx = lane < NW ? rm[lane] : __builtin_inf();
+        const double bm = readlane_f64(row_min_f64(bx), 15);
+        const unsigned int bk = (lane < NW && bx == bm) ? rl[lane] : 0xFFFFFFFFu;
+        const int jp = (int)(unsigned int)__builtin_amdgcn_readlane((int)row_min_u32(bk), 15);
+        double *pr = prow[s & 1];
+        bool owner[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            owner[r] = act[r] && lpr[r] == jp;
+            if (owner[r]) {
+                const int P = Rr[r];
+#pragma unroll
+                for (int cc = 0; cc < NB; cc++) pr[cc] = v[r][cc];
+                s_rinv[s & 1] = 1.0 / x[r];   // dgetf2.go:54-56 scales by the reciprocal
+                act[r] = false;
+                s_active[P] = 0;
+                a.rowstep[P] = k; pivrow[k] = P;
+                if (a.dense_flag) a.dense_flag[k] = 1;
+                ctl->steps[s] = k; ctl->prow[s] = P;
+                const idx_t Q = s_rowat[k];   // dlaswp.go: the row at logical k moves to jp
+                s_lpos[Q] = (idx_t)jp; s_rowat[jp] = Q;
+                s_lpos[P] = (idx_t)k; s_rowat[k] = (idx_t)P;
+                // taking row P makes the unit column of P (if it is still to come) dense from this step on
+                const idx_t uc = s_ucol[P];
+                s_ins = (uc != NONE && (int)uc > k) ? (int)uc : -1;
+            }
+        }
+        __syncthreads();
+        // the pivot row's U entries go to W behind the barrier, off everybody's critical path (slot sigma holds column k)
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            if (owner[r]) {
+                double *dst = a.W + Rr[r];
+#pragma unroll
+                for (int cc = 0; cc < NB; cc++)
+                    if ((live >> cc) & 1u) dst[(size_t)(cc == sigma ? k : s_slotcol[cc]) * ldw] = v[r][cc];
+            }
+        }
+        const double piv = pr[sigma];
+        const bool singular = (piv == 0);  // dgetf2.go:48-49: no scaling, the rank-1 update is a no-op
+        if (singular && tid == 0) a.st->lu_singular = 1;
+        const double rinv = s_rinv[s & 1];
+        const int k2 = s_ins;
+        double *wcol = a.W + (size_t)k * ldw;      // column k of L\U
+        double *lcol = a.Lp + (size_t)s * ldw;     // compact panel: -l (0 for rows that are not active)
+        double nl[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            nl[r] = 0.0;
+            if (act[r]) {
+                const double l = singular ? x[r] : __dmul_rn(x[r], rinv);
+                wcol[Rr[r]] = l;
+                nl[r] = singular ? 0.0 : -l;
+                lcol[Rr[r]] = nl[r];
+            } else if (Rr[r] < a.ldw) lcol[Rr[r]] = 0.0;
+        }
+        const unsigned int others = live & ~(1u << sigma);
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < RPT; r++) any = any || act[r];
+        if (!singular && __any(any)) {   // (a wave whose rows have all left skips the update; Dger does not skip zero multipliers)
+#pragma unroll
+            for (int c = 0; c < NB; c++) {
+                if ((others >> c) & 1u) {
+                    const double pc = pr[c];
+#pragma unroll
+                    for (int r = 0; r < RPT; r++) v[r][c] = __dadd_rn(__dmul_rn(nl[r], pc), v[r][c]);
+                }
+            }
+        }
+        if (k2 >= 0) {
+            // the unit column of the pivot row is e_P: 0 + (-l) * 1 for the active rows, from this step on; it takes the slot this
+            // step's column leaves
+#pragma unroll
+            for (int r = 0; r < RPT; r++) v[r][sigma] = (act[r] && !singular) ? __dadd_rn(__dmul_rn(nl[r], 1.0), 0.0) : 0.0;
+            pend_slot = sigma; pend_col = k2; pend_k = k;
+        } else live = others;
+        s++;
+        kcur = k + 1;
+    }
+    for (int R = tid; R < m; R += T) a.lpos[R] = s_lpos[R];
+    if (tid == 0) {
+        // columns still listed: rows that left at steps [joined, k1) hold final values in them (retire / the pivot rows' stores)
+        int nd = 0;
+        for (int c = 0; c < NB; c++)
+            if ((live >> c) & 1u) {
+                const bool pend = c == pend_slot;   // (joined in the very last step: not in the tables yet)
+                ctl->dropcol[nd] = pend ? pend_col : s_slotcol[c];
+                ctl->dropin[nd] = pend ? pend_k : s_slotin[c];
+                ctl->dropout[nd] = k1;
+                nd++;
+            }
+        ctl->k0 = k0; ctl->k1 = k1; ctl->k_next = k1; ctl->nsteps = s; ctl->ndrop = nd;
+        ctl->rounds += 1;
+    }
+}
+
 // dense pivot rows of the round, columns j >= k1:  u_s = a[P_s] + sum_{t<s} (-l[P_s][t]) * u_t  (ascending t, the
 // Dtrsm of dgetrf.go:57-60) into the compact panel Up; the trailing kernel writes them back into W together with all
 // other rows.  In a column the panel dropped, a pivot row that left while the column was listed is final already.
@@ -566,14 +831,32 @@ static void luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_
         hipLaunchKernelGGL((k_luc_trail<NB>), dim3((m + 63) / 64, (m + 63) / 64), dim3(256), 0, s, a);
     }
 }
+// slot form: up to kLucSlotSteps dense steps per round whatever the number of register slots
+constexpr int kLucSlotSteps = 32;
+template <int T, int RPT, int NB>
+static void luc_rounds_slots(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t s) {
+    const int m = a.m;
+    for (int r = 0; r < nrounds; r++) {
+        hipLaunchKernelGGL((k_luc_panel_slots<T, RPT, NB, kLucSlotSteps>), dim3(1), dim3(T), 0, s, a, pivrow);
+        hipLaunchKernelGGL((k_luc_usolve<kLucSlotSteps>), dim3((m + 63) / 64), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_luc_trail<kLucSlotSteps>), dim3((m + 63) / 64, (m + 63) / 64), dim3(256), 0, s, a);
+    }
+}
 
 bool lu_compressed_supported(int m) { return m <= 4096; }
 static int luc_cfg(int m) {
-    static const int forced = [] { const char *e = getenv("GOMILP_LUC_CFG"); return e ? atoi(e) : -1; }();   // developer knob, read once
+#ifdef GOMILP_DEBUG
+    static const int forced = [] { const char *e = getenv("GOMILP_LUC_CFG"); return e ? atoi(e) : -1; }();   // developer knob (diagnostic flavour), read once
     if (forced >= 0) return forced;
+#endif
     return m <= 512 ? 0 : (m <= 1024 ? 1 : (m <= 2048 ? 2 : 3));
 }
-int lu_compressed_nb(int m) { const int c = luc_cfg(m); return c <= 1 ? 32 : ((c == 2 || c == 4) ? 16 : 8); }
+// dense steps a round can take (the host sizes its batches of rounds with it)
+int lu_compressed_nb(int m, bool slots) {
+    if (slots) return kLucSlotSteps;
+    const int c = luc_cfg(m);
+    return c <= 1 ? 32 : ((c == 2 || c == 4) ? 16 : 8);
+}
 
 void launch_luc_init(const LUArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(k_luc_init, dim3((a.m + 255) / 256), dim3(256), 0, s, a);
@@ -597,6 +880,14 @@ void launch_luc_pack(const LUArgs &a, const int32_t *dlist, int nd, double *Wd, 
 // enqueue `nrounds` rounds; returns the number of kernel launches
 int launch_luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t s) {
     const int m = a.m;
+    if (a.slots) {
+        // (threads x rows per thread x register slots: 128 VGPRs per thread at 1024 threads hold 2 x 16 or 4 x 8 columns)
+        if (m <= 512) luc_rounds_slots<512, 1, 32>(a, pivrow, nrounds, s);
+        else if (m <= 1024) luc_rounds_slots<512, 2, 32>(a, pivrow, nrounds, s);
+        else if (m <= 2048) luc_rounds_slots<1024, 2, 16>(a, pivrow, nrounds, s);
+        else luc_rounds_slots<1024, 4, 8>(a, pivrow, nrounds, s);
+        return 3 * nrounds;
+    }
     const int c = luc_cfg(m);
     if (c == 0) luc_rounds<512, 1, 32>(a, pivrow, nrounds, s);
     else if (c == 1) luc_rounds<1024, 1, 32>(a, pivrow, nrounds, s);

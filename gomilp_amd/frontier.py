@@ -83,13 +83,8 @@ def allreduce_incumbent(z_local: float, idx_local: int, dist=None, device=None, 
             tab[r, 0], tab[r, 1] = z_local, float(idx_local)
         dist.all_reduce(tab, op=dist.ReduceOp.MIN)
         return _lp.incumbent_pick(tab.numpy())
-    import torch
-    tz = torch.tensor([z_local], dtype=torch.float64, device=device)
-    dist.all_reduce(tz, op=dist.ReduceOp.MIN)
-    zg = float(tz[0])
-    ti = torch.tensor([idx_local if z_local == zg else BIG_INDEX], dtype=torch.int64, device=device)
-    dist.all_reduce(ti, op=dist.ReduceOp.MIN)
-    return zg, int(ti[0])
+    raise ValueError("incumbent exchange on a device goes through the C-ABI (lp.Comm -> gomilp_incumbent_allreduce); "
+                     "torch.distributed is only the CPU rehearsal path (gloo)")
 
 
 def solve_wave(solve_shard: Callable[[List[list]], tuple], children: List[list], integrality: Sequence[bool],
