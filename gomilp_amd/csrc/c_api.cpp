@@ -91,6 +91,10 @@ struct gomilp_pool {
     }
 };
 
+#ifdef GOMILP_DEBUG
+namespace gomilp { void luc_stamps_read(unsigned long long *out); }
+#endif
+
 extern "C" {
 
 const char *gomilp_version(void) { return "gomilp_amd 0.1 (gfx950)"; }
@@ -446,6 +450,11 @@ int64_t gomilp_debug_find_independent_device(gomilp_ctx *ctx, int64_t problem, i
     for (size_t k = 0; k < idx.size() && (int64_t)k < cap; k++) idx_out[k] = idx[k];
     return (int64_t)idx.size();
 }
+
+#ifdef GOMILP_DEBUG
+// diagnostic flavour only: cycle sums of the final-solve panel kernel (lu_compressed.hip), 4 waves x 16 segments
+void gomilp_debug_luc_stamps(unsigned long long *out) { gomilp::luc_stamps_read(out); }
+#endif
 
 int64_t gomilp_lp_last_trace(gomilp_ctx *ctx, gomilp_pivot *out, int64_t cap) {
     if (!ctx) return -1;

@@ -324,13 +324,32 @@ __global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__
 //     trailing kernels through the record the old panel used for dropped columns: rows that left while the column was listed hold
 //     final values in it, all other rows still hold the original.
 // Rows of retired rows keep whatever the later updates make of them (never read again): no predication on the update itself.
+#ifdef GOMILP_DEBUG
+// diagnostic flavour: cycles (s_memtime) per segment of a dense step, summed over the launches of a process by wave 0 .. 3:
+// [wave][segment], segment 15 = dense steps; gomilp_debug_luc_stamps() hands them out
+__device__ unsigned long long g_luc_stamps[4 * 16];
+#define LUC_STAMP(S)                                                                      \
+    do {                                                                                  \
+        unsigned long long t_;                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if ((S) >= 0) tacc[(S) >= 0 ? (S) : 0] += t_ - tprev;                             \
+        tprev = t_;                                                                       \
+    } while (0)
+#else
+#define LUC_STAMP(S) do { } while (0)
+#endif
 template <int T, int RPT, int NB, int SMAX>
 __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__restrict__ pivrow) {
     constexpr int NW = T / 64;
     constexpr int MAXM = T * RPT;
     static_assert(NB <= 32 && SMAX <= 32 && NW <= 16, "slots / steps per round are recorded in 32-entry tables");
     typedef unsigned short idx_t;            // m <= 4096
-    typedef double vec __attribute__((ext_vector_type(NB)));
+    // register columns in tuples of at most 16 doubles: the widest the uniform dynamic index (v_movrels) reaches; wider vectors go to scratch
+    constexpr int NH = (NB + 15) / 16, VW = NB / NH;
+    static_assert(NH * VW == NB, "NB: 8, 16 or 32");
+    typedef double vec __attribute__((ext_vector_type(VW)));
     constexpr idx_t NONE = 0xFFFF;
     __shared__ idx_t s_lpos[MAXM];    // logical position of physical row R
     __shared__ idx_t s_rowat[MAXM];   // physical row at logical position
@@ -341,8 +360,7 @@ __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__rest
     __shared__ double s_rinv[2];
     __shared__ double redM[2][16];
     __shared__ unsigned int redL[2][16];
-    __shared__ int s_slotcol[NB];     // column listed in each slot
-    __shared__ int s_slotin[NB];      // dense step after which it joined (-1: round start)
+    __shared__ int s_slotcol[NB];     // columns listed at the start of the round (afterwards the slot tables live in registers)
     __shared__ int s_nload, s_stop, s_limit, s_sigma, s_ins;
     LUCtl *ctl = a.ctl;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -382,12 +400,14 @@ __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__rest
             n += __popcll(mask);
         }
         if (lane == 0) s_nload = n < NB ? n : NB;
-        if (lane < NB) s_slotin[lane] = -1;
     }
     __syncthreads();
     const int nload = s_nload;
+    // the slot tables live in registers, replicated in every wave (lane c = slot c; every change is uniform): no LDS round trip per slot
+    int myslotcol = (lane < NB && lane < nload) ? s_slotcol[lane < NB ? lane : 0] : 0x7FFFFFFF;
+    int myslotin = -1;
     unsigned int live = nload >= 32 ? 0xFFFFFFFFu : ((1u << nload) - 1u);   // uniform: every thread keeps the same copy
-    vec v[RPT];
+    vec v[RPT][NH];
     int Rr[RPT];
     bool act[RPT];
 #pragma unroll
@@ -396,17 +416,24 @@ __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__rest
         act[r] = (Rr[r] < m) && s_active[Rr[r] < m ? Rr[r] : 0];
         const double *src = a.W + (act[r] ? Rr[r] : 0);
 #pragma unroll
-        for (int c = 0; c < NB; c++) v[r][c] = (act[r] && c < nload) ? src[(size_t)s_slotcol[c < nload ? c : 0] * ldw] : 0.0;
+        for (int c = 0; c < NB; c++) v[r][c / VW][c % VW] = (act[r] && c < nload) ? src[(size_t)__builtin_amdgcn_readlane(myslotcol, c) * ldw] : 0.0;
     }
     __syncthreads();   // every thread has taken its rows' `act` from s_active before wave 0's first run clears entries
+    // The column loads above are the only global loads of this kernel.  Retire them HERE, with an instruction the compiler's wait
+    // pass sees (inline asm would be opaque to it): otherwise it must assume, on every path of the loop below, that a register
+    // column may still be in flight, and guards each use with s_waitcnt vmcnt(0) — which on gfx9 also waits for every STORE issued
+    // so far: the step's multiplier / U-row stores (fire-and-forget by design) landed on the critical path, several times per step.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+#ifdef GOMILP_DEBUG
+    unsigned long long tacc[16] = {}, tprev = 0;
+#endif
+    LUC_STAMP(-1);
     int kcur = k0, s = 0, k1 = m;
-    int pend_slot = -1, pend_col = 0, pend_k = 0;   // (uniform) a column that joined in the previous step: lane 0 of wave 0 lists it
 #pragma unroll 1
     for (;;) {
         if (w == 0) {
-            if (lane == 0 && pend_slot >= 0) { s_slotcol[pend_slot] = pend_col; s_slotin[pend_slot] = pend_k; }
             // the next listed column: smallest column index among the live slots
-            const unsigned int key = (lane < NB && ((live >> lane) & 1u)) ? (unsigned int)s_slotcol[lane < NB ? lane : 0] : 0x7FFFFFFFu;
+            const unsigned int key = (lane < NB && ((live >> lane) & 1u)) ? (unsigned int)myslotcol : 0x7FFFFFFFu;
             unsigned int mn = row_min_u32(key);
             mn = min((unsigned int)__builtin_amdgcn_readlane((int)mn, 0), (unsigned int)__builtin_amdgcn_readlane((int)mn, 16));
             const bool listed = live != 0 && s < SMAX;
@@ -435,8 +462,9 @@ __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__rest
             }
             if (lane == 0) { s_stop = k; s_limit = limit; s_sigma = sigma; }
         }
-        pend_slot = -1;
+        LUC_STAMP(0);   // wave 0: next column + the run of bookkeeping steps
         __syncthreads();
+        LUC_STAMP(1);   // barrier 1
         const int kstop = s_stop, limit = s_limit;
         const int sigma = __builtin_amdgcn_readfirstlane(s_sigma);
         // rows retired by the run become U rows: their entries in the listed columns are final
@@ -448,18 +476,24 @@ __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__rest
                 double *dst = a.W + Rr[r];
 #pragma unroll
                 for (int c = 0; c < NB; c++)
-                    if ((live >> c) & 1u) dst[(size_t)s_slotcol[c] * ldw] = v[r][c];
+                    if ((live >> c) & 1u) dst[(size_t)__builtin_amdgcn_readlane(myslotcol, c) * ldw] = v[r][c / VW][c % VW];
                 act[r] = false;
             }
         }
         if (kstop < limit || live == 0 || s >= SMAX) { k1 = kstop; break; }
         const int k = limit;
+        LUC_STAMP(2);   // retire
         // ---- dense step k on slot sigma: first maximum of |a_ik| in LAPACK row order (as k_luc_panel)
         double x[RPT];
         double xm = __builtin_inf();
 #pragma unroll
         for (int r = 0; r < RPT; r++) {
-            x[r] = v[r][sigma];   // uniform index
+            if constexpr (NH == 1) x[r] = v[r][0][sigma & (VW - 1)];   // uniform index
+            else {   // (masked: an index beyond the tuple, even on a path not taken, would address a foreign register; the empty asm keeps the
+                     // uniform branch a branch — if-converted, it becomes a 32-instruction select of whole tuples in front of the index)
+                if (sigma < VW) { asm volatile(""); x[r] = v[r][0][sigma & (VW - 1)]; }
+                else { asm volatile(""); x[r] = v[r][NH - 1][sigma & (VW - 1)]; }
+            }
             if (act[r]) xm = vmin_f64(xm, -fabs(x[r]));
         }
         const double wm = wave_min_f64(xm);
@@ -476,7 +510,9 @@ __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__rest
         double *rm = redM[s & 1];
         unsigned int *rl = redL[s & 1];
         if (lane == 0) { rm[w] = wm; rl[w] = lk; }
+        LUC_STAMP(3);   // own pivot search
         __syncthreads();
+        LUC_STAMP(4);   // barrier 2
         const double bx = lane < NW ? rm[lane] : __builtin_inf();
         const double bm = readlane_f64(row_min_f64(bx), 15);
         const unsigned int bk = (lane < NW && bx == bm) ? rl[lane] : 0xFFFFFFFFu;
@@ -489,7 +525,7 @@ __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__rest
             if (owner[r]) {
                 const int P = Rr[r];
 #pragma unroll
-                for (int cc = 0; cc < NB; cc++) pr[cc] = v[r][cc];
+                for (int cc = 0; cc < NB; cc++) pr[cc] = v[r][cc / VW][cc % VW];
                 s_rinv[s & 1] = 1.0 / x[r];   // dgetf2.go:54-56 scales by the reciprocal
                 act[r] = false;
                 s_active[P] = 0;
@@ -504,7 +540,9 @@ __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__rest
                 s_ins = (uc != NONE && (int)uc > k) ? (int)uc : -1;
             }
         }
+        LUC_STAMP(5);   // workgroup pivot + publish
         __syncthreads();
+        LUC_STAMP(6);   // barrier 3
         // the pivot row's U entries go to W behind the barrier, off everybody's critical path (slot sigma holds column k)
 #pragma unroll
         for (int r = 0; r < RPT; r++) {
@@ -512,10 +550,11 @@ __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__rest
                 double *dst = a.W + Rr[r];
 #pragma unroll
                 for (int cc = 0; cc < NB; cc++)
-                    if ((live >> cc) & 1u) dst[(size_t)(cc == sigma ? k : s_slotcol[cc]) * ldw] = v[r][cc];
+                    if ((live >> cc) & 1u) dst[(size_t)__builtin_amdgcn_readlane(myslotcol, cc) * ldw] = v[r][cc / VW][cc % VW];
             }
         }
-        const double piv = pr[sigma];
+        const double prl = pr[lane & (NB - 1)];   // lane c holds the pivot row's value in slot c: ONE LDS round trip, then scalar broadcasts
+        const double piv = readlane_f64(prl, sigma);
         const bool singular = (piv == 0);  // dgetf2.go:48-49: no scaling, the rank-1 update is a no-op
         if (singular && tid == 0) a.st->lu_singular = 1;
         const double rinv = s_rinv[s & 1];
@@ -538,37 +577,55 @@ __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__rest
 #pragma unroll
         for (int r = 0; r < RPT; r++) any = any || act[r];
         if (!singular && __any(any)) {   // (a wave whose rows have all left skips the update; Dger does not skip zero multipliers)
+            // branch-free over the slots: a slot that is not listed takes (-l) * 0 (its register holds nothing anybody reads) — a
+            // uniform branch per slot came out as two taken branches per LIVE slot (bodies moved out of line): ~2500 cycles at 32 slots
+            const double prz = (lane < NB && ((others >> (lane & 31)) & 1u)) ? prl : 0.0;
 #pragma unroll
             for (int c = 0; c < NB; c++) {
-                if ((others >> c) & 1u) {
-                    const double pc = pr[c];
+                const double pc = readlane_f64(prz, c);
 #pragma unroll
-                    for (int r = 0; r < RPT; r++) v[r][c] = __dadd_rn(__dmul_rn(nl[r], pc), v[r][c]);
-                }
+                for (int r = 0; r < RPT; r++) v[r][c / VW][c % VW] = __dadd_rn(__dmul_rn(nl[r], pc), v[r][c / VW][c % VW]);
             }
         }
         if (k2 >= 0) {
             // the unit column of the pivot row is e_P: 0 + (-l) * 1 for the active rows, from this step on; it takes the slot this
             // step's column leaves
 #pragma unroll
-            for (int r = 0; r < RPT; r++) v[r][sigma] = (act[r] && !singular) ? __dadd_rn(__dmul_rn(nl[r], 1.0), 0.0) : 0.0;
-            pend_slot = sigma; pend_col = k2; pend_k = k;
+            for (int r = 0; r < RPT; r++) {
+                const double vn = (act[r] && !singular) ? __dadd_rn(__dmul_rn(nl[r], 1.0), 0.0) : 0.0;
+                if constexpr (NH == 1) v[r][0][sigma & (VW - 1)] = vn;
+                else {
+                    if (sigma < VW) { asm volatile(""); v[r][0][sigma & (VW - 1)] = vn; }
+                    else { asm volatile(""); v[r][NH - 1][sigma & (VW - 1)] = vn; }
+                }
+            }
+            if (lane == sigma) { myslotcol = k2; myslotin = k; }
         } else live = others;
         s++;
         kcur = k + 1;
+        LUC_STAMP(7);   // elimination
     }
+#ifdef GOMILP_DEBUG
+    if (lane == 0 && w < 4) {
+        for (int sg = 0; sg < 8; sg++) atomicAdd(&g_luc_stamps[w * 16 + sg], tacc[sg]);
+        if (w == 0) atomicAdd(&g_luc_stamps[15], (unsigned long long)s);
+    }
+#endif
     for (int R = tid; R < m; R += T) a.lpos[R] = s_lpos[R];
+    // columns still listed: rows that left at steps [joined, k1) hold final values in them (retire / the pivot rows' stores)
+    int ndl = 0;
+    if (w == 0) {
+        const bool on = lane < NB && ((live >> lane) & 1u);
+        const unsigned long long msk = __ballot(on);
+        ndl = __popcll(msk);
+        if (on) {
+            const int at = __popcll(msk & ((1ull << lane) - 1ull));
+            ctl->dropcol[at] = myslotcol; ctl->dropin[at] = myslotin; ctl->dropout[at] = k1;
+        }
+    }
     if (tid == 0) {
-        // columns still listed: rows that left at steps [joined, k1) hold final values in them (retire / the pivot rows' stores)
-        int nd = 0;
-        for (int c = 0; c < NB; c++)
-            if ((live >> c) & 1u) {
-                const bool pend = c == pend_slot;   // (joined in the very last step: not in the tables yet)
-                ctl->dropcol[nd] = pend ? pend_col : s_slotcol[c];
-                ctl->dropin[nd] = pend ? pend_k : s_slotin[c];
-                ctl->dropout[nd] = k1;
-                nd++;
-            }
+        const int nd = ndl;
+        // (table above): rows that left at steps [joined, k1) hold final values in them (retire / the pivot rows' stores)
         ctl->k0 = k0; ctl->k1 = k1; ctl->k_next = k1; ctl->nsteps = s; ctl->ndrop = nd;
         ctl->rounds += 1;
     }
@@ -882,6 +939,27 @@ int launch_luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t
     const int m = a.m;
     if (a.slots) {
         // (threads x rows per thread x register slots: 128 VGPRs per thread at 1024 threads hold 2 x 16 or 4 x 8 columns)
+#ifdef GOMILP_DEBUG
+        static const int forced = [] { const char *e = getenv("GOMILP_LUC_SLOTS"); return e ? atoi(e) : -1; }();   // developer knob (diagnostic flavour): panel shape
+        if (forced >= 0) {
+            bool done = true;
+            switch (forced) {
+                case 10: if (m <= 2048) luc_rounds_slots<256, 8, 8>(a, pivrow, nrounds, s); else done = false; break;
+                case 11: if (m <= 2048) luc_rounds_slots<512, 4, 16>(a, pivrow, nrounds, s); else done = false; break;
+                case 12: if (m <= 2048) luc_rounds_slots<1024, 2, 16>(a, pivrow, nrounds, s); else done = false; break;
+                case 13: if (m <= 2048) luc_rounds_slots<512, 4, 8>(a, pivrow, nrounds, s); else done = false; break;
+                case 20: if (m <= 1024) luc_rounds_slots<512, 2, 32>(a, pivrow, nrounds, s); else done = false; break;
+                case 21: if (m <= 1024) luc_rounds_slots<256, 4, 16>(a, pivrow, nrounds, s); else done = false; break;
+                case 22: if (m <= 1024) luc_rounds_slots<512, 2, 16>(a, pivrow, nrounds, s); else done = false; break;
+                case 23: if (m <= 1024) luc_rounds_slots<1024, 1, 32>(a, pivrow, nrounds, s); else done = false; break;
+                case 30: if (m <= 512) luc_rounds_slots<256, 2, 32>(a, pivrow, nrounds, s); else done = false; break;
+                case 31: if (m <= 512) luc_rounds_slots<256, 2, 16>(a, pivrow, nrounds, s); else done = false; break;
+                case 32: if (m <= 512) luc_rounds_slots<128, 4, 16>(a, pivrow, nrounds, s); else done = false; break;
+                default: done = false;
+            }
+            if (done) return 3 * nrounds;
+        }
+#endif
         if (m <= 512) luc_rounds_slots<512, 1, 32>(a, pivrow, nrounds, s);
         else if (m <= 1024) luc_rounds_slots<512, 2, 32>(a, pivrow, nrounds, s);
         else if (m <= 2048) luc_rounds_slots<1024, 2, 16>(a, pivrow, nrounds, s);
@@ -896,5 +974,9 @@ int launch_luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t
     else luc_rounds<1024, 4, 8>(a, pivrow, nrounds, s);
     return 3 * nrounds;
 }
+
+#ifdef GOMILP_DEBUG
+void luc_stamps_read(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_luc_stamps), sizeof(unsigned long long) * 64); }
+#endif
 
 }  // namespace gomilp

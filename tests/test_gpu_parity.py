@@ -175,7 +175,7 @@ def test_blocked_lu_equals_per_column_lu_bitwise(m, seed):
     as the one-launch-per-column schedule (simplex_kernels.hip k_lu_step), which the small cases pin to the oracle."""
     c, A, b = synth.dense_lp_standard_form(m, seed)
     res = []
-    for blocked in (2, 1, 0):   # compressed rounds (default), blocked panels, one launch per column
+    for blocked in (3, 2, 1, 0):   # compressed rounds with the slot panel (default) / the sorted register panel, blocked panels, one launch per column
         cx = lp.Context(lu_blocked=blocked)
         try:
             rl = cx.upload(c, A, b)
@@ -183,18 +183,19 @@ def test_blocked_lu_equals_per_column_lu_bitwise(m, seed):
             rl.free()
         finally:
             cx.close()
-    for r in res[:2]:
-        assert r.status == lp.OK == res[2].status
-        assert np.array_equal(r.basis, res[2].basis)
-        assert np.array_equal(r.x, res[2].x) and r.z == res[2].z
-    assert res[0].stats["lu_rounds"] > 0 and res[0].stats["lu_dense_steps"] == res[1].stats["lu_dense_steps"]
+    for r in res[:3]:
+        assert r.status == lp.OK == res[3].status
+        assert np.array_equal(r.basis, res[3].basis)
+        assert np.array_equal(r.x, res[3].x) and r.z == res[3].z
+    assert res[0].stats["lu_rounds"] > 0 and res[1].stats["lu_rounds"] > 0
+    assert res[0].stats["lu_dense_steps"] == res[1].stats["lu_dense_steps"] == res[2].stats["lu_dense_steps"]
     # the unit-column fast path of the panel kernel must be deterministic (it once raced: repeat the solve)
     cx = lp.Context()
     try:
         rl = cx.upload(c, A, b)
         for _ in range(3):
             again = rl.solve(0.0)
-            assert again.status == lp.OK and np.array_equal(again.x, res[1].x) and again.z == res[1].z
+            assert again.status == lp.OK and np.array_equal(again.x, res[3].x) and again.z == res[3].z
         rl.free()
     finally:
         cx.close()
