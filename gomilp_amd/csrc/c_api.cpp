@@ -40,6 +40,10 @@ struct gomilp_pool {
     std::unique_ptr<BatchEngine> batch2;   // second schedule for waves of large relaxations (created on first use)
     int cond_guard = 1, exact_degenerate = 1, sample_batch = 0;   // knob values kept for batch2: both halves of a split wave decide alike
     int split_large = 1;        // knob: waves of >= 4 large relaxations run as two interleaved schedules
+    int split_phase = 1;        // knob: relaxations that start feasible (Phase II from the slack basis: the long pivot chains of a wave) and
+                                // relaxations that need Phase I (on a B&B frontier mostly proved infeasible within a few pivots) run as two
+                                // schedules side by side: a block step of the wide group (hundreds of tableaus gathered / updated) no longer
+                                // sits between two blocks of a long chain
     int large_loop = 0;         // knob: relaxations of 1025..2048 rows / columns run on the workers' persistent loop kernels (four at a
                                 // time, each with its pivot workgroups on an XCD of its own) instead of the batched launch pairs.  Off:
                                 // measured 342 k pivots/s for 4 metric LPs against 391 k batched — four updates streaming at once
@@ -157,6 +161,7 @@ int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value) {
     std::lock_guard<std::mutex> g(pool->call_mu);
     if (std::string(key) == "batched") { pool->batched = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "split_large") { pool->split_large = value ? 1 : 0; return GOMILP_OK; }
+    if (std::string(key) == "split_phase") { pool->split_phase = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "large_loop") { pool->large_loop = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "sample_batch") {
         pool->sample_batch = value != 0;
@@ -340,13 +345,65 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
         for (int r = 0; r < nroots; r++) { m_big = std::max(m_big, views[r]->m + K_max); nn_big = std::max(nn_big, views[r]->n - views[r]->m + (any_p1 ? 1 : 0)); }
         const bool two = pool->split_large && count >= 4 && gomilp::bt_batch_k(m_big, gomilp::batch_ldt(nn_big)) == 16;
         int rc;
-        if (two) {
+        auto make_batch2 = [&] {
             if (!pool->batch2) {
                 pool->batch2.reset(new BatchEngine(pool->device));
                 pool->batch2->set_cond_guard(pool->cond_guard);
                 pool->batch2->set_exact_degenerate(pool->exact_degenerate);
                 pool->batch2->set_sampling(pool->sample_batch != 0);
             }
+        };
+        auto merge_stats = [&](const BatchEngine::Stats &bs2) {
+            bs.launches += bs2.launches; bs.supersteps = std::max(bs.supersteps, bs2.supersteps); bs.blocks += bs2.blocks; bs.blocks_sampled += bs2.blocks_sampled;
+            bs.seconds_inner += bs2.seconds_inner; bs.seconds_update += bs2.seconds_update; bs.seconds_total = std::max(bs.seconds_total, bs2.seconds_total);
+        };
+        // relaxations that start feasible (slack basis, b >= 0, every branch right-hand side >= 0: Phase II at once) against those that
+        // need Phase I
+        std::vector<int64_t> grp_f, grp_p;
+        if (pool->split_phase && !two && count >= 16) {
+            std::vector<char> root_ok(nroots, 0);
+            for (int r = 0; r < nroots; r++) {
+                bool ok = views[r]->unit_basis;
+                for (double v : views[r]->hb) if (v < -1e-13) { ok = false; break; }
+                root_ok[r] = ok ? 1 : 0;
+            }
+            for (int64_t i = 0; i < count; i++) {
+                bool f = root_ok[root_of ? root_of[i] : 0] != 0;
+                for (int64_t k = koff[i]; k < koff[i + 1] && f; k++) if (rhs[k] < -1e-13) f = false;
+                (f ? grp_f : grp_p).push_back(i);
+            }
+        }
+        if (!grp_f.empty() && !grp_p.empty()) {
+            // gather each group's description (the schedules take contiguous lists)
+            struct Group { std::vector<int32_t> root_of, var; std::vector<int64_t> koff; std::vector<double> sign, rhs; };
+            auto gather = [&](const std::vector<int64_t> &idx, Group &g) {
+                g.koff.push_back(0);
+                for (int64_t i : idx) {
+                    g.root_of.push_back(root_of ? root_of[i] : 0);
+                    for (int64_t k = koff[i]; k < koff[i + 1]; k++) { g.var.push_back(var[k]); g.sign.push_back(sign[k]); g.rhs.push_back(rhs[k]); }
+                    g.koff.push_back((int64_t)g.var.size());
+                }
+                if (g.var.empty()) { g.var.push_back(0); g.sign.push_back(0); g.rhs.push_back(0); }   // (valid pointers for K = 0 everywhere)
+            };
+            Group gf, gp;
+            gather(grp_f, gf); gather(grp_p, gp);
+            make_batch2();
+            BatchEngine::Stats bs2;
+            int rc2 = GOMILP_OK;
+            auto on_done_f = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) { on_done_at(grp_f[(size_t)i], o, basic, xb); };
+            auto on_done_p = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) { on_done_at(grp_p[(size_t)i], o, basic, xb); };
+            pool->batch->set_low_priority(true);   // the wide group yields to the long chains
+            std::thread t2([&] {
+                hipSetDevice(pool->device);
+                rc2 = pool->batch2->run_roots(views.data(), nroots, gf.root_of.data(), (int64_t)grp_f.size(), gf.koff.data(), gf.var.data(), gf.sign.data(), gf.rhs.data(), tol, on_done_f, &bs2);
+            });
+            rc = pool->batch->run_roots(views.data(), nroots, gp.root_of.data(), (int64_t)grp_p.size(), gp.koff.data(), gp.var.data(), gp.sign.data(), gp.rhs.data(), tol, on_done_p, &bs);
+            t2.join();
+            pool->batch->set_low_priority(false);
+            if (rc == GOMILP_OK) rc = rc2;
+            merge_stats(bs2);
+        } else if (two) {
+            make_batch2();
             const int64_t half = count / 2;
             BatchEngine::Stats bs2;
             int rc2 = GOMILP_OK;
@@ -358,8 +415,7 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
             rc = pool->batch->run_roots(views.data(), nroots, root_of, half, koff, var, sign, rhs, tol, on_done, &bs);
             t2.join();
             if (rc == GOMILP_OK) rc = rc2;
-            bs.launches += bs2.launches; bs.supersteps += bs2.supersteps; bs.blocks += bs2.blocks; bs.blocks_sampled += bs2.blocks_sampled;
-            bs.seconds_inner += bs2.seconds_inner; bs.seconds_update += bs2.seconds_update; bs.seconds_total = std::max(bs.seconds_total, bs2.seconds_total);
+            merge_stats(bs2);
         } else {
             rc = pool->batch->run_roots(views.data(), nroots, root_of, count, koff, var, sign, rhs, tol, on_done, &bs);
         }

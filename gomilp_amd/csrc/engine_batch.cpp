@@ -81,11 +81,13 @@ BatchEngine::BatchEngine(int device) : device_(device), b_(new Buf) {}
 
 BatchEngine::~BatchEngine() {
     hipSetDevice(device_);
-    if (stream_) hipStreamSynchronize(stream_);
+    if (stream_hi_) hipStreamSynchronize(stream_hi_);
+    if (stream_lo_) hipStreamSynchronize(stream_lo_);
     if (copy_stream_) hipStreamSynchronize(copy_stream_);
     b_->free_all();
     delete b_;
-    if (stream_) hipStreamDestroy(stream_);
+    if (stream_hi_) hipStreamDestroy(stream_hi_);
+    if (stream_lo_) hipStreamDestroy(stream_lo_);
     if (copy_stream_) hipStreamDestroy(copy_stream_);
 }
 
@@ -105,9 +107,16 @@ int BatchEngine::ensure(int nlp, int m_max, int n_max, int ldt1, int64_t ktot) {
         // a hardware queue of its own: streams of one priority share a small round-robin pool of queues (4 per process), and a
         // worker's final-solve launches that land in the schedule's queue would wait behind a whole superstep every time
         int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) B_TRY(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
-        else B_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) {
+            B_TRY(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
+            B_TRY(hipStreamCreateWithPriority(&stream_lo_, hipStreamNonBlocking, lo));
+        } else {
+            B_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+            B_TRY(hipStreamCreateWithFlags(&stream_lo_, hipStreamNonBlocking));
+        }
+        stream_hi_ = stream_;
     }
+    stream_ = low_priority_ ? stream_lo_ : stream_hi_;   // (both idle between runs: every run ends with a synchronize)
     if (!copy_stream_) B_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
     Buf &b = *b_;
     if (!b.d_active) {

@@ -26,6 +26,9 @@ class BatchEngine {
         const char *inner_kernel = "";
     };
     void set_sampling(bool on) { sampling_ = on; }
+    // stream priority of the schedule (before its first run): a wave split into a long-chain group and a wide group gives the long
+    // chains the higher priority, so their one-workgroup launches are dispatched ahead of the wide group's hundreds of workgroups
+    void set_low_priority(bool low) { low_priority_ = low; }
     void set_cond_guard(int v) { cond_guard_ = v; }   // as the engine knob of the same name
     void set_exact_degenerate(int v) { exact_degenerate_ = v; }   // as the engine knob of the same name
     // called on the thread that runs the wave as soon as child i is terminal; basic / xb (m_i entries, host memory, valid
@@ -51,10 +54,10 @@ class BatchEngine {
     struct Buf;
     int ensure(int nlp, int m_max, int n_max, int ldt1, int64_t ktot);
     int device_;
-    bool sampling_ = false;
+    bool sampling_ = false, low_priority_ = false;
     int exact_degenerate_ = 1;
     int cond_guard_ = 1;
-    hipStream_t stream_ = nullptr, copy_stream_ = nullptr;
+    hipStream_t stream_ = nullptr, stream_hi_ = nullptr, stream_lo_ = nullptr, copy_stream_ = nullptr;   // stream_: the one this run uses
     Buf *b_;
 };
 
