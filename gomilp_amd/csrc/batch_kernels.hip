@@ -37,6 +37,7 @@ __host__ __device__ __forceinline__ int b_ldt(int nn) { return ((nn + 63) / 64) 
 __device__ __forceinline__ void b_reset_state(DevState *st) {
     st->done = 0; st->status = ST_RUNNING; st->pivots = 0; st->kdone = 0; st->bland_steps = 0; st->trace_len = 0;
     st->max_pivots = 0; st->lu_singular = 0;
+    st->kdone2[0] = st->kdone2[1] = 0; st->loop_blocks = 0;
 }
 
 // ---- set-up: slack basis of the child, feasibility, Phase-I order ---------------------------------------------------
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(kBlock) void k_b_setup(BatchLP *__restrict__ lps) {
         lp.tcur = 0; lp.do_permute = 0; lp.do_r = 0; lp.wrapped = 0; lp.piv1 = lp.piv2 = lp.bland = 0;
         lp.status = 0;
         b_reset_state(lp.st);
+        lp.st->tsel2[0] = lp.st->tsel2[1] = 0;
         if (!infeasible) {
             lp.phase1_used = 0;
             a.nn = nn2; a.ldt = b_ldt(nn2); a.phase = 2; a.tol = lp.tol_user; a.kmax = 0;   // no pivot in the forced round
@@ -170,7 +172,9 @@ __global__ void k_b_gather(const BatchLP *__restrict__ lps) {
 
 // ---- the stage machine ----------------------------------------------------------------------------------------------
 // dynamic LDS: 2 * (n_max + 2) ints (flags, old positions)
-__global__ __launch_bounds__(kBlock) void k_b_ctrl(BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count, BatchOut *__restrict__ outs) {
+// loop_par >= 0: the blocks of this superstep ran in the persistent loop kernel (launch parity loop_par): it left the buffer that holds
+// the tableau in DevState::tsel2 (bt_kernels.hip k_b_loop)
+__global__ __launch_bounds__(kBlock) void k_b_ctrl(BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count, BatchOut *__restrict__ outs, int loop_par) {
     extern __shared__ __attribute__((aligned(16))) int sh_ctrl[];
     __shared__ int s_scan[kBlock];
     __shared__ double s_red[kBlock];
@@ -182,7 +186,10 @@ __global__ __launch_bounds__(kBlock) void k_b_ctrl(BatchLP *__restrict__ lps, co
     const int m = lp.m, n = lp.n;
     const int stage = lp.stage;
     DevState *st = lp.st;
-    if (tid == 0) { lp.do_permute = 0; lp.do_r = 0; s_added = -1; }
+    if (tid == 0) {
+        lp.do_permute = 0; lp.do_r = 0; s_added = -1;
+        if (loop_par >= 0) { lp.tcur = st->tsel2[(loop_par ^ 1) & 1] & 1; lp.bt.T = lp.T[lp.tcur]; }
+    }
     __syncthreads();
     bool to_phase2 = false;   // uniform
     if (stage == BS_FORCED) {
@@ -343,6 +350,8 @@ __global__ __launch_bounds__(kBlock) void k_b_ctrl(BatchLP *__restrict__ lps, co
     }
     __syncthreads();
     if (tid == 0) {
+        st->tsel2[0] = st->tsel2[1] = lp.tcur;   // the next loop launch (either parity) starts from the current buffer
+        st->kdone2[0] = st->kdone2[1] = 0;
         BatchOut &o = outs[li];
         o.stage = lp.stage; o.status = lp.status; o.wrapped = lp.wrapped; o.phase1_used = lp.phase1_used;
         o.piv1 = lp.piv1; o.piv2 = lp.piv2; o.bland = lp.bland;
@@ -439,9 +448,9 @@ void launch_b_gather(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStr
     hipLaunchKernelGGL(k_b_gather, grid, block, 0, s, lps);
 }
 // ids_in / count_in: the active list the previous control step left (everybody at the start); bound >= *count_in on the host
-void launch_b_ctrl(BatchLP *lps, const int *ids_in, const int *count_in, int bound, int n_max, BatchOut *outs, int *ids_out, int *count_out, hipStream_t s) {
+void launch_b_ctrl(BatchLP *lps, const int *ids_in, const int *count_in, int bound, int n_max, BatchOut *outs, int *ids_out, int *count_out, int loop_par, hipStream_t s) {
     const size_t lds = (size_t)2 * (n_max + 2) * sizeof(int);
-    hipLaunchKernelGGL(k_b_ctrl, dim3(bound), dim3(kBlock), lds, s, lps, ids_in, count_in, outs);
+    hipLaunchKernelGGL(k_b_ctrl, dim3(bound), dim3(kBlock), lds, s, lps, ids_in, count_in, outs, loop_par);
     hipLaunchKernelGGL(k_b_compact, dim3(1), dim3(kBlock), 0, s, lps, ids_in, count_in, ids_out, count_out);
 }
 void launch_b_init_ids(int *ids, int *count, int nlp, hipStream_t s) {

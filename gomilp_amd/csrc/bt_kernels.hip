@@ -30,6 +30,7 @@
 
 #include "device_types.h"
 #include "kernels_common.h"
+#include "bt_loop.h"
 
 namespace gomilp {
 
@@ -320,9 +321,14 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
 __device__ __forceinline__ unsigned int tile_off(unsigned int i, unsigned int j, unsigned int ldt);
 struct BtWin { double m; unsigned int i; };   // minimum and the first index that attains it (0xFFFFFFFF: none, all NaN)
 
-template <int NT, int RI, int CJ, int KR, int VL, bool STAMP = false>
-__device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
+// LOOP: the pivot role of the batched persistent loop kernel (k_b_loop below): up to a.nblocks blocks of KR / 2 pivots in one launch; the
+// registers hold the running block's terms AND the previous block's (not yet in the tableau buffer this block reads: the update
+// workgroups of the same launch apply them beside this block) — the protocol of k_bt_loop (bt_loop.h) with ONE pivot workgroup.
+template <int NT, int RI, int CJ, int KR, int VL, bool STAMP = false, bool LOOP = false>
+__device__ __forceinline__ void bt_inner2_body(const BTArgs &a, const int nupd = 0) {
     constexpr int NW = NT / 64;
+    static_assert(!LOOP || (VL == 0 && !STAMP && (KR & 1) == 0), "loop mode: all terms in registers, KR / 2 lagging + KR / 2 current");
+    constexpr int KB = LOOP ? KR / 2 : KR;   // pivots per block
     // STAMP: diagnostic build (context knob "bt_stamps"): every wave sums the shader cycles it spends in each segment of
     // a pivot (s_memtime, cdna_hip_programming.md §7 "In-kernel stamps") and adds them to a.stamps[wave][segment]; the
     // loads are waited for where a segment ends, so this build's run time is not the product kernel's
@@ -366,7 +372,28 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
     const double inf = __builtin_inf();
     const unsigned int ldt = (unsigned int)a.ldt;
     const char *Tb = reinterpret_cast<const char *>(a.T);   // byte offsets in 32 bits: saddr + voffset addressing
-    auto ldT = [&](unsigned int elem) -> double { return *reinterpret_cast<const double *>(Tb + (elem << 3)); };
+    // loop mode: the buffer the update workgroups finished two blocks ago — they write it from other CUs while this launch runs: agent scope
+    auto ldT = [&](unsigned int elem) -> double {
+        if constexpr (LOOP) return ld_agent(reinterpret_cast<const double *>(Tb + (elem << 3)));
+        else return *reinterpret_cast<const double *>(Tb + (elem << 3));
+    };
+    // loop mode: counters and buffer choice handed from launch to launch (bt_loop.h; G = 1 pivot workgroup)
+    const int sel0 = LOOP ? (a.par ? st->tsel2[1] : st->tsel2[0]) : 0;
+    const double *hdr_in = a.xbuf + 1 + 5 * (LOOP ? a.par : 0);
+    double *hdr_out = a.xbuf + 1 + 5 * (LOOP ? (a.par ^ 1) : 0);
+    unsigned int blk_base = 0, upd_base[4] = {0, 0, 0, 0};
+    if constexpr (LOOP) {
+        blk_base = (unsigned int)(unsigned long long)hdr_in[0];
+#pragma unroll
+        for (int j = 0; j < 4; j++) upd_base[j] = (unsigned int)(unsigned long long)hdr_in[1 + j];
+    }
+    unsigned int *blk_cnt = reinterpret_cast<unsigned int *>(a.xbuf + kXSync), *upd_cnt = reinterpret_cast<unsigned int *>(a.xbuf + kXSync + 16);
+    auto hand_on = [&](int nb) {   // counters in step for the next launch after nb blocks
+        hdr_out[0] = (double)(unsigned int)(blk_base + (unsigned int)nb);
+#pragma unroll
+        for (int j = 0; j < 4; j++) hdr_out[1 + j] = (double)(unsigned int)(upd_base[j] + (unsigned int)nupd * (unsigned int)(nb > j ? (nb - 1 - j) / 4 + 1 : 0));
+    };
+    __shared__ int s_ok;
     double x0[RI], r0[CJ];
     int b0[RI], n0[CJ];
 #pragma unroll
@@ -382,7 +409,18 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
         n0[s] = j < a.nn ? a.nonbasic[j] : 0;
     }
     if (done) {
-        if (tid == 0) st->kdone = 0;
+        if constexpr (LOOP) {
+            // a launch behind the end of the loop: release the update workgroups (they wait for block 0; nothing to apply) and keep
+            // counters and buffer choice in step
+            if (tid == 0) {
+                __hip_atomic_store(&st->kdone2[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(blk_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                st->tsel2[a.par ^ 1] = sel0;
+                st->loop_blocks = 0;
+                hand_on(1);
+            }
+        } else if (tid == 0) st->kdone = 0;
         return;
     }
     double ureg[RI][KR], vreg[CR > 0 ? CR : 1][KR];
@@ -535,9 +573,42 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
         }
     };
 
+    int nbe = 0, cur0 = 0;   // loop mode: blocks run by this launch; first U / V row of the running block
+    bool dead = false;       // loop mode: an update counter made no progress within the limit
+    for (int blk = 0; blk < (LOOP ? a.nblocks : 1); blk++) {
+    if constexpr (LOOP) {
+        // block blk reads the tableau after blk - 1 blocks: the update of block blk - 2 must be through (nupd arrivals per block)
+        if (blk >= 2) {
+            if (wv == 0) {
+                const int cj = (blk - 2) & 3;
+                const unsigned int ub = cj == 0 ? upd_base[0] : cj == 1 ? upd_base[1] : cj == 2 ? upd_base[2] : upd_base[3];
+                const bool ok = spin_counter(upd_cnt + 16 * cj * 2, ub + (unsigned int)nupd * (unsigned int)((blk - 2) / 4 + 1), 0);
+                if (lane == 0) s_ok = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (!s_ok) { dead = true; status = ST_XCHG_TIMEOUT; }
+            __syncthreads();   // (s_ok is rewritten by the next block's wait)
+            if (dead) break;
+        }
+        Tb = reinterpret_cast<const char *>(((sel0 ^ (blk > 0 ? blk - 1 : 0)) & 1) ? a.Tbuf[1] : a.Tbuf[0]);
+        cur0 = (blk & 1) * KB;
+        if (blk > 0) {   // entries 0..KB-1 = the previous block (now lagging), KB.. = the block before it: in the tableau by now
+#pragma unroll
+            for (int s = 0; s < RI; s++) {
+#pragma unroll
+                for (int j = KB; j < KR; j++) ureg[s][j] = 0;
+            }
+#pragma unroll
+            for (int s = 0; s < CJ; s++) {
+#pragma unroll
+                for (int j = KB; j < KR; j++) vreg[s < CR ? s : 0][j] = 0;
+            }
+        }
+        kd = 0;
+    }
     for (int k = 0; k < a.kmax; k++) {
         BT_STAMP(-1);
-        const bool forced = (k == 0 && a.forced_q >= 0);
+        const bool forced = (k == 0 && blk == 0 && a.forced_q >= 0);
         int q, p;
         double rq = 0, dpv = 1.0, xbp = 0;
         const double *vq = &payA[0][1], *up = &payB[0][2];
@@ -551,7 +622,7 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
 #pragma unroll
                 for (int s = 0; s < CJ; s++) rv[s] = r_s[tid + s * NT];
                 fq = reduce_cols(rv, rq, vq);
-                if (a.guard > 0 && !(k == 0 && a.exact_once)) {
+                if (a.guard > 0 && !(k == 0 && blk == 0 && a.exact_once)) {
                     // Guard mode (BTArgs::guard).  The reference takes this decision on reduced costs recomputed from a fresh LU
                     // (simplex.go:236-248): a minimum within the guard of the stop threshold, or two columns within the guard of each
                     // other (integer data: exact ties), is decided by that solve's rounding noise — the host repeats it (ST_NEED_EXACT)
@@ -598,7 +669,7 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
             // degenerate (or nearly), or two rows within 1e-9 of each other: decided on a fresh gonum-order x_B (DevTypes: BTArgs::guard)
             // (a winning pivot element below the guard too: the updated tableau drifts by ~1e-12 on nearly dependent rows, where the fresh
             // column has an exact zero that the reference's 1e-13 rounding removes from the test — pivoting there gave singular bases)
-            if (a.guard > 0 && !(k == 0 && a.exact_once) && (mv <= a.guard || mv2 - mv <= a.guard * fmax(1.0, fabs(mv)) || fabs(dpv) <= a.guard)) { status = ST_NEED_EXACT; break; }
+            if (a.guard > 0 && !(k == 0 && blk == 0 && a.exact_once) && (mv <= a.guard || mv2 - mv <= a.guard * fmax(1.0, fabs(mv)) || fabs(dpv) <= a.guard)) { status = ST_NEED_EXACT; break; }
             if (mv <= 0) {
                 // ---- replaceBland (simplex.go:347-383): candidates in position order with r_i <= -1e-14 after the
                 // 1e-13 rounding of :252-256; the mat.Cond guard of :377 is replaced by |d| >= 1e-13
@@ -659,8 +730,12 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
         const double rinv = 1.0 / dpv, nrinv = -rinv;
         const double mult = rq * rinv;
         const double theta = xbp * rinv;
-        char *Vk = reinterpret_cast<char *>(a.V + (size_t)k * a.ldt);
-        char *Uk = reinterpret_cast<char *>(a.U + (size_t)k * a.ldu);
+        char *Vk = reinterpret_cast<char *>(a.V + (size_t)(cur0 + k) * a.ldt);
+        char *Uk = reinterpret_cast<char *>(a.U + (size_t)(cur0 + k) * a.ldu);
+        auto st_term = [&](char *row, unsigned int idx, double val) {   // loop mode: read by the update workgroups of the same launch
+            if constexpr (LOOP) st_agent(reinterpret_cast<double *>(row + (idx << 3)), val);
+            else *reinterpret_cast<double *>(row + (idx << 3)) = val;
+        };
         // the row loads go out first: the u terms / x_B update below need nothing from them and run under their latency
         double vrow[CJ];
 #pragma unroll
@@ -674,7 +749,7 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
             if (i < a.ldu) {
                 const double u = (i == p) ? rinv - 1.0 : dcol[s] * nrinv;   // rows >= m: dcol = 0
                 if (i < a.m) xb_s[i] = (i == p) ? theta : __builtin_fma(-theta, dcol[s], xb_s[i]);
-                *reinterpret_cast<double *>(Uk + ((unsigned int)i << 3)) = u;
+                st_term(Uk, (unsigned int)i, u);
 #pragma unroll
                 for (int jj = KR - 1; jj > 0; jj--) ureg[s][jj] = ureg[s][jj - 1];
                 ureg[s][0] = u;
@@ -700,7 +775,7 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
                 // reduced costs (positional): r_j - (r_q/d_p) v_j ; the leaving variable takes slot q
                 r_s[j] = (j == q) ? -mult : __builtin_fma(-mult, v, r_s[j]);
                 const double vprime = (j == q) ? dpv + 1.0 : v;
-                *reinterpret_cast<double *>(Vk + ((unsigned int)j << 3)) = vprime;
+                st_term(Vk, (unsigned int)j, vprime);
                 if (s < CR) {
 #pragma unroll
                     for (int jj = KR - 1; jj > 0; jj--) vreg[s < CR ? s : 0][jj] = vreg[s < CR ? s : 0][jj - 1];
@@ -731,6 +806,24 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
         }
         kd = k + 1;
     }
+    nbe = blk + 1;
+    if constexpr (LOOP) {
+        // hand the block to the update workgroups: every term store of this workgroup has landed (agent scope), then the pivot count
+        // (and the end of the loop), then the arrival that releases them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(&st->kdone2[blk & 1], kd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (status != ST_RUNNING) {
+                __hip_atomic_store(&st->status, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&st->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(blk_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (status != ST_RUNNING) break;
+    }
+    }
     if constexpr (STAMP) {
         if (a.stamps && lane == 0) {
 #pragma unroll
@@ -755,7 +848,21 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a) {
     if (tid == 0) {
         st->trace_len = trace_len;
         st->pivots = npiv;
-        st->kdone = kd;
+        if constexpr (LOOP) {
+            if (dead) {
+                // the update workgroups stopped arriving: nothing after this point can be trusted to be applied — the status says so
+                // (the batched schedule hands the relaxation to a worker, which starts from the root data)
+                st->tsel2[a.par ^ 1] = sel0;
+                st->loop_blocks = nbe;
+                hand_on(nbe);
+            } else {
+                // the update workgroups apply every block with pivots before the launch ends: the tableau after them
+                const int napplied = kd > 0 ? nbe : nbe - 1;
+                st->tsel2[a.par ^ 1] = sel0 ^ (napplied & 1);
+                st->loop_blocks = nbe;
+                hand_on(nbe);
+            }
+        } else st->kdone = kd;
         st->bland_steps += blands;
         if (status != ST_RUNNING) { st->done = 1; st->status = status; }
     }
@@ -775,6 +882,34 @@ __global__ __launch_bounds__(NT) void k_bt_inner2_batch(const BatchLP *__restric
     if (stage == BS_DONE || stage == BS_HOST) return;
     const BTArgs a = lp.bt;
     bt_inner2_body<NT, RI, CJ, KR, VL, false>(a);
+}
+
+// ---- batched persistent loop kernel (round 4) -----------------------------------------------------------------------------------------
+// The launch pairs above put the rank-8 update of EVERY block on the chain of a relaxation (26 us of pivots, then 7 us of update, then a
+// launch boundary), and a wave's long chains wait at every block step for whatever else the step carries.  Here the relaxation at
+// position s of the active list gets ONE pivot workgroup (bt_inner2_body in loop mode: 8 current + 8 lagging terms in registers, the
+// tableau read from the buffer the update finished two blocks ago) and NU update workgroups (bt_loop.h: matrix cores, ping-pong between
+// the relaxation's two tableau buffers) for up to `nblocks` blocks of one launch — the protocol of k_bt_loop with one pivot workgroup,
+// counters and buffer choice per relaxation (its own exchange buffer and DevState).  Placement: block b = x + 8 j runs on XCD x (blocks
+// are dealt round-robin over the XCDs); position s = (j / (1 + NU)) * 8 + x, role j % (1 + NU): all workgroups of a relaxation share one
+// L2.  Every workgroup of the launch must be resident (they wait for each other): the host launches at most one workgroup per CU.
+// Stages with a host-chosen or no pivot (BS_FORCED, BS_P2_START, BS_EXCH: kmax < 8) run one block.
+template <int NT, int RI, int KB, int NU>
+__global__ __launch_bounds__(NT) void k_b_loop(const BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count, int nblocks, int par) {
+    const unsigned int x8 = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const int slot = (int)((j / (1u + NU)) * 8u + x8), role = (int)(j % (1u + NU));
+    if (slot >= *count) return;
+    const BatchLP &lp = lps[ids[slot]];
+    const int stage = lp.stage;
+    if (stage == BS_DONE || stage == BS_HOST) return;
+    BTArgs a = lp.bt;
+    a.Tbuf[0] = lp.T[0]; a.Tbuf[1] = lp.T[1];
+    a.loop = 1; a.par = par;
+    // (the host counts blocks of 8 pivots: a launch with shorter blocks runs more of them)
+    if (a.kmax >= KB) { a.kmax = KB; a.nblocks = nblocks * (8 / KB); }
+    else a.nblocks = 1;
+    if (role == 0) bt_inner2_body<NT, RI, RI, 2 * KB, 0, false, true>(a, NU);
+    else bt_loop_update_role<NT, KB, true>(a, role - 1, NU, 1);
 }
 
 // T[i, j] += sum_{k < kdone} U[k][i] * V[k][j]  — in place, one streaming pass.
@@ -1147,6 +1282,23 @@ void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count,
     const BtCfg c = bt_cfg(m_max, ldt_max, 0);
     if (c.ri == 2) { if (c.nt == 512) bt_inner_batch_nt<512, 2, 0>(lps, ids, count, nlp, s, e0, e1); else bt_inner_batch_nt<1024, 2, 1>(lps, ids, count, nlp, s, e0, e1); }
     else bt_inner_batch_nt<512, 4, 0>(lps, ids, count, nlp, s, e0, e1);
+}
+// batched persistent loop kernel: relaxations of up to 1024 rows / columns (two rows + two columns per thread)
+constexpr int kBLoopNU = 7;   // update workgroups per relaxation: 1 + 7 = 8 workgroups, four relaxations per XCD, 32 per launch
+// relaxations per launch: one workgroup per CU at most, and one relaxation's worth of CUs per XCD left to the other streams (the second
+// schedule of a split wave, the workers' final solves): a loop launch holds its CUs for a whole superstep
+int b_loop_slots(int ncu) { return 8 * std::max(1, ncu / (8 * (1 + kBLoopNU)) - 1); }
+bool b_loop_supported(int m_max, int ldt_max) {
+    if (bt_batch_k(m_max, ldt_max) != 8) return false;
+    const BtCfg c = bt_cfg(m_max, ldt_max, 0);
+    return c.ri == 2 && c.nt == 512 && (ldt_max & 63) == 0;
+}
+// Blocks of 4 pivots inside a launch: 4 current + 4 lagging terms per row / column (184 VGPRs).  Blocks of 8 — 16 terms — spill ~50
+// dwords per lane into the pivot loop of a 512-thread workgroup: measured 4.9 instead of 3.4 ms for the heaviest child of the C5 wave.
+void launch_b_loop(const BatchLP *lps, const int *ids, const int *count, int nlp, int nblocks, int par, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const unsigned int grid = 8u * (unsigned int)((nlp + 7) / 8) * (1u + kBLoopNU);
+    const size_t lds = (size_t)(2 + 2) * 512 * (sizeof(double) + sizeof(int));
+    hipExtLaunchKernelGGL((k_b_loop<512, 2, 4, kBLoopNU>), dim3(grid), dim3(512), lds, s, e0, e1, 0, lps, ids, count, nblocks, par);
 }
 const char *bt_batch_kernel_name(int m_max, int ldt_max) {
     if (bt_batch_k(m_max, ldt_max) == 16) return bt_group_cfg(m_max, ldt_max, 0).nt == 256 ? "k_bt_innerG_batch<8,256,1,16>" : "k_bt_innerG_batch<8,512,1,16>";

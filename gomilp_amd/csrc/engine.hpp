@@ -259,11 +259,15 @@ int bt_batch_k(int m_max, int ldt_max);
 void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void launch_bt_update_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 const char *bt_batch_kernel_name(int m_max, int ldt_max);
+// batched persistent loop kernel (bt_kernels.hip k_b_loop): relaxations per launch on a device with ncu CUs; shapes it takes
+int b_loop_slots(int ncu);
+bool b_loop_supported(int m_max, int ldt_max);
+void launch_b_loop(const BatchLP *lps, const int *ids, const int *count, int nlp, int nblocks, int par, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 // batch_kernels.hip
 int batch_ldt(int nn);
 void launch_b_setup(BatchLP *lps, int nlp, hipStream_t s);
 void launch_b_gather(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s);
-void launch_b_ctrl(BatchLP *lps, const int *ids_in, const int *count_in, int bound, int n_max, BatchOut *outs, int *ids_out, int *count_out, hipStream_t s);
+void launch_b_ctrl(BatchLP *lps, const int *ids_in, const int *count_in, int bound, int n_max, BatchOut *outs, int *ids_out, int *count_out, int loop_par, hipStream_t s);
 void launch_b_init_ids(int *ids, int *count, int nlp, hipStream_t s);
 void launch_b_permute(const BatchLP *lps, const int *ids, const int *count, int bound, int m_max, int ldt_max, hipStream_t s);
 void launch_b_tab_r(const BatchLP *lps, const int *ids, const int *count, int bound, int m_max, int ldt_max, hipStream_t s);

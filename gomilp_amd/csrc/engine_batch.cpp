@@ -192,7 +192,12 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
     // pivots per block and block kernel of this wave's shape class: large relaxations run the 8-workgroup kernel (one XCD each)
     const int kb = bt_batch_k(m_max, ldt1);
     const BtGroupCfg grp = bt_group_cfg(m_max, ldt1, 0);
-    if (kb == 16) B_TRY(hipMemsetAsync(b.d_xbuf, 0, (size_t)nlp * bt_xbuf_doubles() * sizeof(double), stream_));   // no exchange has happened
+    B_TRY(hipMemsetAsync(b.d_xbuf, 0, (size_t)nlp * bt_xbuf_doubles() * sizeof(double), stream_));   // no exchange has happened, every counter at 0
+    // the persistent loop kernel takes the block steps whenever the active relaxations fit one launch (one workgroup per CU at most)
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_) != hipSuccess || ncu <= 0) ncu = 64;
+    const int loop_slots = (loop_ && b_loop_supported(m_max, ldt1)) ? b_loop_slots(ncu) : 0;
+    int loop_launches = 0;
     // ---- root data the kernels read in place + the unit-column rows of each root's slack basis
     std::vector<const int32_t *> rho_of(nroots, nullptr);
     for (int r = 0; r < nroots; r++) {
@@ -240,7 +245,8 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         lp.tol_user = tol; lp.kblock = kb; lp.stage = BS_HOST;
         // degenerate pivots are decided on a fresh gonum-order x_B: such a relaxation is handed to the worker path (ST_NEED_EXACT -> BS_HOST)
         lp.bt.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && (lp.m <= 256 || lp.gen || R.scale_span > 1e9))) ? 1e-9 : 0.0;
-        if (kb == 16) { lp.bt.groups = grp.groups; lp.bt.group_ri = grp.ri; lp.bt.group_nt = grp.nt; lp.bt.xbuf = b.d_xbuf + (size_t)i * bt_xbuf_doubles(); }
+        lp.bt.xbuf = b.d_xbuf + (size_t)i * bt_xbuf_doubles();
+        if (kb == 16) { lp.bt.groups = grp.groups; lp.bt.group_ri = grp.ri; lp.bt.group_nt = grp.nt; }
     }
     B_TRY(hipMemsetAsync(b.d_active, 0, kMaxSteps * sizeof(int), stream_));
     B_TRY(hipMemsetAsync(b.d_out, 0, (size_t)nlp * sizeof(BatchOut), stream_));   // stage 0 = not terminal
@@ -262,9 +268,27 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         return GOMILP_OK;
     };
     // the blocks of superstep `step` work on the active list the control step of superstep step - 1 left behind
-    auto blocks = [&](int nb) {
+    int last_loop_par = -1;   // parity of the loop launch that ran the blocks of the superstep being enqueued (-1: launch pairs)
+    auto blocks = [&](int nb, bool allow_loop) {
         const int *ids = b.d_ids[(step + 1) & 1];
         const int *cnt = step == 0 ? b.d_active + (kMaxSteps - 1) : b.d_active + (step - 1);
+        last_loop_par = -1;
+        if (allow_loop && loop_slots > 0 && bound <= loop_slots) {
+            hipEvent_t e[2] = {nullptr, nullptr};
+            if (sampling_) {
+                while (b.samp_ev.size() < (size_t)(nsamp + 1) * 4) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) break; b.samp_ev.push_back(ev); }
+                if (b.samp_ev.size() >= (size_t)(nsamp + 1) * 4) {
+                    e[0] = b.samp_ev[(size_t)nsamp * 4]; e[1] = b.samp_ev[(size_t)nsamp * 4 + 1];
+                    hipEventRecord(b.samp_ev[(size_t)nsamp * 4 + 2], stream_); hipEventRecord(b.samp_ev[(size_t)nsamp * 4 + 3], stream_);   // (no separate update launch)
+                    nsamp++;
+                }
+            }
+            last_loop_par = loop_launches & 1;
+            launch_b_loop(b.d_lps, ids, cnt, bound, nb, last_loop_par, stream_, e[0], e[1]);
+            loop_launches++;
+            S.launches += 1; S.blocks += nb; S.loop_launches += 1;
+            return;
+        }
         for (int t = 0; t < nb; t++) {
             hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
             if (sampling_) {
@@ -280,7 +304,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
     auto control = [&](bool permute) {
         const int *ids = b.d_ids[(step + 1) & 1];
         const int *cnt = step == 0 ? b.d_active + (kMaxSteps - 1) : b.d_active + (step - 1);
-        launch_b_ctrl(b.d_lps, ids, cnt, bound, n_max, b.d_out, b.d_ids[step & 1], b.d_active + step, stream_);
+        launch_b_ctrl(b.d_lps, ids, cnt, bound, n_max, b.d_out, b.d_ids[step & 1], b.d_active + step, last_loop_par, stream_);
         if (permute) launch_b_permute(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_);
         launch_b_tab_r(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_);
         S.launches += permute ? 5 : 4;
@@ -289,7 +313,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
     launch_b_setup(b.d_lps, nlp, stream_);
     launch_b_gather(b.d_lps, nlp, m_max, ldt1, stream_);
     S.launches += 2;
-    blocks(1);
+    blocks(1, false);   // (set-up pivots: one block each, launch pair)
     control(false);
     if ((rc = snapshot(0)) != GOMILP_OK) return rc;
     S.seconds_setup = bnow() - t0;
@@ -337,9 +361,11 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         // enqueue superstep step + 1 before waiting for the snapshot of superstep `step`: the GPU never idles for the host
         // wide waves shed their quick relaxations early (short supersteps first: the batched update of hundreds of tableaus is
         // what a block step costs there); a narrow wave is a few single-workgroup chains: longer supersteps, fewer round trips
-        const int nb = nlp <= 16 ? (step < 2 ? 4 : 8) : (step < 2 ? 1 : (step < 4 ? 2 : (step < 8 ? 4 : 8)));
+        int nb = nlp <= 16 ? (step < 2 ? 4 : 8) : (step < 2 ? 1 : (step < 4 ? 2 : (step < 8 ? 4 : 8)));
+        // a loop launch has no boundary between its blocks: longer supersteps (fewer control steps on the chain) once the wave is narrow
+        if (loop_slots > 0 && bound <= loop_slots && step >= 2) nb = bound <= 8 ? 16 : 8;
         step++;
-        blocks(nb);
+        blocks(nb, true);
         control(true);
         if ((rc = snapshot(step % kRing)) != GOMILP_OK) return rc;
         S.supersteps++;

@@ -19,7 +19,7 @@ class BatchEngine {
         int64_t piv1 = 0, piv2 = 0, bland = 0;
     };
     struct Stats {
-        int64_t launches = 0, supersteps = 0, blocks = 0;
+        int64_t launches = 0, supersteps = 0, blocks = 0, loop_launches = 0;
         double seconds_setup = 0, seconds_total = 0;
         double seconds_inner = 0, seconds_update = 0;   // HIP-event time of the sampled block launches (set_sampling)
         int64_t blocks_sampled = 0;
@@ -29,6 +29,7 @@ class BatchEngine {
     // stream priority of the schedule (before its first run): a wave split into a long-chain group and a wide group gives the long
     // chains the higher priority, so their one-workgroup launches are dispatched ahead of the wide group's hundreds of workgroups
     void set_low_priority(bool low) { low_priority_ = low; }
+    void set_loop(bool on) { loop_ = on; }   // block steps in the persistent loop kernel where the active relaxations fit one launch (default on)
     void set_cond_guard(int v) { cond_guard_ = v; }   // as the engine knob of the same name
     void set_exact_degenerate(int v) { exact_degenerate_ = v; }   // as the engine knob of the same name
     // called on the thread that runs the wave as soon as child i is terminal; basic / xb (m_i entries, host memory, valid
@@ -54,7 +55,7 @@ class BatchEngine {
     struct Buf;
     int ensure(int nlp, int m_max, int n_max, int ldt1, int64_t ktot);
     int device_;
-    bool sampling_ = false, low_priority_ = false;
+    bool sampling_ = false, low_priority_ = false, loop_ = true;
     int exact_degenerate_ = 1;
     int cond_guard_ = 1;
     hipStream_t stream_ = nullptr, stream_hi_ = nullptr, stream_lo_ = nullptr, copy_stream_ = nullptr;   // stream_: the one this run uses

@@ -11,6 +11,7 @@ feas = [i for i, ch in enumerate(children) if all(r >= -1e-13 for (_, _, r) in c
 infe = [i for i in range(len(children)) if i not in feas]
 print("feasible-start children:", feas)
 pool = lp.FrontierPool(workers=4, batched=1)
+if len(sys.argv) > 1: pool.set("batch_loop", int(sys.argv[1]))
 pool.set_root(c, A, b)
 def t(label, chs, n=6):
     best = 1e9
@@ -25,7 +26,7 @@ t("phase-I group alone", [children[i] for i in infe])
 t("feasible group alone", [children[i] for i in feas])
 pool.close()
 # single path: block kernel thread count at 512 rows
-for nt in (0, 256):
+for nt in ():
     cx = lp.Context(bt_nt=nt); p = cx.upload(c, A, b)
     for _ in range(3): r = p.solve(0.0)
     print("C3 root bt_nt", nt, "loop %.3f ms pivots %d" % (1e3 * r.stats["seconds_pivot_loop"], r.stats["pivots_phase2"]), flush=True)
