@@ -797,7 +797,9 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
         launches_++;
         const int nb = lu_compressed_nb(m, a.slots != 0);
         // measured: steps that do arithmetic ~ 3 x the non-unit columns (each of them usually turns a unit column dense)
-        int batch = std::max(1, (3 * nonunit + nb - 1) / nb + 1);
+        // (the slot panel takes up to nb steps per round whatever the order of the columns; a wrong guess costs one more look at the
+        // control block, a generous one a run of empty rounds of three launches each)
+        int batch = a.slots ? std::max(1, (std::min(m, (5 * nonunit) / 2) + nb - 1) / nb) : std::max(1, (3 * nonunit + nb - 1) / nb + 1);
         for (;;) {
             launches_ += launch_luc_rounds(a, w.rho, batch, stream_);
             HIP_TRY(hipMemcpyAsync(w.luctl_host, w.luctl, sizeof(LUCtl), hipMemcpyDeviceToHost, stream_));

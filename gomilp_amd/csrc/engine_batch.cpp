@@ -363,7 +363,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         // what a block step costs there); a narrow wave is a few single-workgroup chains: longer supersteps, fewer round trips
         int nb = nlp <= 16 ? (step < 2 ? 4 : 8) : (step < 2 ? 1 : (step < 4 ? 2 : (step < 8 ? 4 : 8)));
         // a loop launch has no boundary between its blocks: longer supersteps (fewer control steps on the chain) once the wave is narrow
-        if (loop_slots > 0 && bound <= loop_slots && step >= 2) nb = bound <= 8 ? 16 : 8;
+        if (loop_slots > 0 && bound <= loop_slots && step >= 2) nb = bound <= 8 ? (step >= 3 ? 32 : 16) : 8;
         step++;
         blocks(nb, true);
         control(true);
@@ -374,7 +374,9 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         active = *b.h_active[prev_slot];
         bound = std::max(active, 1);   // the count only falls: a safe grid size for everything enqueued from here on
         if ((rc = harvest(prev_slot)) != GOMILP_OK) return rc;
-        flush_pending(false);
+        // narrow waves are a few long chains: whoever finished is handed to its final solve at once (the copy of its basis takes ~10 us;
+        // polling would leave it waiting for the next superstep — and the last one for the superstep enqueued behind the end)
+        flush_pending(active == 0 || nlp <= 16);
         if (active == 0 || last_possible) break;
     }
     // the superstep enqueued behind the deciding snapshot: no-op launches when every relaxation was terminal
