@@ -50,6 +50,9 @@ class Result:
     waves: int = 0
     relaxations: int = 0
     pivots: int = 0
+    warm_started: int = 0        # warm mode: relaxations that started from their parent's basis, of which handed back to the cold path
+    warm_fallbacks: int = 0
+    pivots_dual: int = 0
 
 
 def convert_to_equalities(c, A, b, G, h):
@@ -77,9 +80,13 @@ def max_fun_branch_point(c, integrality) -> int:
 
 
 def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int = 8, device: int = -1,
-               pool=None) -> Result:
+               pool=None, warm: bool = False, dual_budget: int = 0) -> Result:
     """milpProblem.solve (ilp.go:75-116) with every relaxation on the GPU.  `max_nodes` stands in for the context
-    deadline of the reference (its tree does not terminate on many inputs: SURVEY.md §3.4)."""
+    deadline of the reference (its tree does not terminate on many inputs: SURVEY.md §3.4).
+
+    warm (opt-in; /root/reference/README.md TODO "initiate the simplex at solution of parent"): every node that branches keeps its final
+    basis resident (gomilp_frontier_solve_warm), its two children start from it with the dual simplex; a parent is released once both
+    children are solved.  Statuses, decisions and z agree with the cold run to 1e-9 (tests), the pivot paths do not."""
     c = np.asarray(c, dtype=np.float64)
     integrality = list(integrality)
     if G is not None:
@@ -96,7 +103,11 @@ def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int
     if own_pool:
         pool = lp.FrontierPool(device=device, workers=workers)   # (a caller that solves several MILPs keeps one pool)
     pool.set_root(c0, A0, b0)
-    r = pool.solve_root(0.0)                             # subproblem.go:172
+    if warm:   # the root through the batched schedule, so that its final state can stay resident for its children
+        rr = pool.solve_warm([[]], tags=[0], keep=[1])
+        r = lp.LPResult(int(rr.status[0]), float(rr.z[0]), rr.x[0].copy() if rr.has_x[0] else None, None, rr.stats)
+    else:
+        r = pool.solve_root(0.0)                         # subproblem.go:172
     root.status, root.z, root.x = r.status, r.z, r.x
     out.relaxations, out.pivots = 1, r.stats["pivots_phase1"] + r.stats["pivots_phase2"]
     if r.status != lp.OK:
@@ -113,6 +124,7 @@ def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int
     incumbent: Optional[Node] = None
     queue: List[Node] = []
     next_id = 0
+    kids_left: dict = {}
 
     def check(node: Node) -> Optional[str]:
         nonlocal incumbent, next_id
@@ -157,7 +169,17 @@ def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int
                 out.error = "DeadlineExceeded"
                 break
             wave, queue = queue[:budget], queue[budget:]
-            res = pool.solve([nd.constraints for nd in wave])
+            if warm:
+                res = pool.solve_warm([nd.constraints for nd in wave], parents=[nd.parent for nd in wave], tags=[nd.id for nd in wave],
+                                      keep=[1] * len(wave), dual_budget=dual_budget)
+                out.pivots += res.stats["pivots_dual"]
+                out.warm_started += res.stats["warm_started"]; out.warm_fallbacks += res.stats["warm_fallbacks"]; out.pivots_dual += res.stats["pivots_dual"]
+                for nd in wave:   # a parent whose two children are solved is not needed any more
+                    kids_left[nd.parent] = kids_left.get(nd.parent, 2) - 1
+                    if kids_left[nd.parent] == 0:
+                        pool.release_warm(nd.parent)
+            else:
+                res = pool.solve([nd.constraints for nd in wave])
             out.waves += 1
             out.relaxations += len(wave)
             out.pivots += res.stats["pivots_phase1"] + res.stats["pivots_phase2"]

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(kBlock) void k_b_setup(BatchLP *__restrict__ lps) {
     __shared__ unsigned int si[kWavesPerBlock];
     __shared__ int s_bad;
     BatchLP &lp = lps[blockIdx.x];
+    if (lp.warm) return;   // (k_b_setup_warm)
     const int tid = threadIdx.x, m = lp.m, n = lp.n;
     if (tid == 0) s_bad = 0;
     __syncthreads();
@@ -129,9 +130,55 @@ __global__ __launch_bounds__(kBlock) void k_b_setup(BatchLP *__restrict__ lps) {
     }
 }
 
+// ---- warm start: the child = its parent's final basis + the slack of its ONE new branch row (the last of its list) -----------------------
+// Parent state (WarmStore, engine_batch.cpp): tableau T_p (wm rows, 4x4 tiles, this child's ldt), updated x_B, positional lists, map
+// variable -> position (>= 0 basic, -1 - position nonbasic).  New row:  sign * x_var + s = rhs  with x_var = x_B[pv] - T_p[pv, :] x_N
+// (var basic at pv) or x_var = the nonbasic variable itself — so the slack is basic at position 0 with
+//   x_B[0] = rhs - sign * x_B_p[pv]   (rhs when var is nonbasic),   T[0, :] = -sign * T_p[pv, :]   (sign * e_jq),
+// the parent's rows behind it.  The reduced costs of the parent's optimum stay valid (the slack costs nothing): the basis is dual
+// feasible, and primal infeasible at most in row 0 — the dual simplex repairs that (k_bt_inner2_dual_batch), or finds the row without
+// a negative entry: infeasible.
+__global__ __launch_bounds__(kBlock) void k_b_setup_warm(BatchLP *__restrict__ lps) {
+    BatchLP &lp = lps[blockIdx.x];
+    if (!lp.warm) return;
+    const int tid = threadIdx.x, m = lp.m, n = lp.n, wm = lp.wm;
+    const int kk = lp.K - 1;
+    const int var = lp.var[kk];
+    const double sign = lp.sign[kk], rhs = lp.rhs[kk];
+    const int pv = lp.wposvar[var];
+    const int nn2 = n - m;
+    for (int pos = tid; pos < lp.ldu; pos += kBlock) {
+        double x = 0.0;
+        if (pos == 0) { x = rhs - sign * (pv >= 0 ? lp.wxb[pv] : 0.0); lp.basic[0] = n - 1; }
+        else if (pos < m) { x = lp.wxb[pos - 1]; lp.basic[pos] = lp.wbasic[pos - 1]; }
+        lp.xb[pos] = x;
+    }
+    for (int jp = tid; jp < nn2; jp += kBlock) lp.nonbasic[jp] = lp.wnonbasic[jp];
+    if (tid == 0) {
+        BTArgs &a = lp.bt;
+        a.m = m; a.ldu = lp.ldu; a.T = lp.T[0]; a.U = lp.U; a.V = lp.V; a.r = lp.R; a.xb = lp.xb;
+        a.basic = lp.basic; a.nonbasic = lp.nonbasic; a.st = lp.st; a.trace = nullptr; a.trace_cap = 0;
+        a.nt_force = 0; a.tiled = 1; a.old_only = 0; a.stamps = nullptr;
+        lp.tcur = 0; lp.do_permute = 0; lp.do_r = 0; lp.wrapped = 0; lp.piv1 = lp.piv2 = lp.bland = 0; lp.pivd = 0;
+        lp.status = 0; lp.phase1_used = 0;
+        b_reset_state(lp.st);
+        lp.st->tsel2[0] = lp.st->tsel2[1] = 0;
+        a.nn = nn2; a.ldt = b_ldt(nn2); a.phase = 2; a.tol = lp.tol_user; a.kmax = 0;   // no pivot before the reduced costs exist
+        a.forced_q = a.forced_p = -1; a.forced_nocommit = 0;
+        lp.stage = wm + 1 == m ? BS_DUAL_START : BS_HOST;
+    }
+}
+
 // ---- T[pos, jp] = A'[rho(pos)][var(jp)] in 4x4 tiles, A' = [[A0, 0], [G#, I_K]] never materialised ---------------------
 __device__ __forceinline__ double b_entry(const BatchLP &lp, int pos, int jp, int nn) {
     if (pos >= lp.m || jp >= nn) return 0.0;
+    if (lp.warm) {   // row 0 = the new branch row in the parent's nonbasic terms, then the parent's rows (k_b_setup_warm)
+        const int ldt = b_ldt(nn);
+        if (pos > 0) return lp.wT[tab_idx(pos - 1, jp, ldt, 1)];
+        const int kk = lp.K - 1, pv = lp.wposvar[lp.var[kk]];
+        if (pv >= 0) return -lp.sign[kk] * lp.wT[tab_idx(pv, jp, ldt, 1)];
+        return (-1 - pv) == jp ? lp.sign[kk] : 0.0;
+    }
     if (lp.gen) {
         const int nn0 = lp.n0 - lp.m0;
         if (jp >= nn0) return lp.art[pos];   // the artificial (tableau space, by position: k_b_setup)
@@ -156,7 +203,7 @@ __device__ __forceinline__ double b_entry(const BatchLP &lp, int pos, int jp, in
 __global__ void k_b_gather(const BatchLP *__restrict__ lps) {
     __shared__ double tile[32][33];
     const BatchLP &lp = lps[blockIdx.z];
-    if (lp.stage == BS_HOST || lp.stage == BS_DONE) return;
+    if (lp.stage == BS_HOST || lp.stage == BS_DONE || lp.stage == BS_COLD) return;
     const int m = lp.m, nn = lp.bt.nn, ldt = lp.bt.ldt;
     const int m4 = (m + 3) & ~3;
     const int p0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
@@ -212,6 +259,34 @@ __global__ __launch_bounds__(kBlock) void k_b_ctrl(BatchLP *__restrict__ lps, co
             lp.bt.kmax = lp.kblock;
             b_reset_state(st);
             lp.do_r = 1; lp.r_phase = 2; lp.stage = BS_P2;
+        }
+    } else if (stage == BS_DUAL_START) {
+        // warm start: reduced costs exist now; is the new row violated at the parent's optimum?
+        if (tid == 0) {
+            b_reset_state(st);
+            lp.bt.kmax = lp.kblock;
+            lp.do_r = 1; lp.r_phase = 2;   // r = c_N - c_B^T T of the parent's basis (k_b_tab_r, behind this step)
+            const bool violated = lp.xb[0] < -1e-13;   // (initPosTol: what initializeFromBasic calls infeasible, simplex.go:447-471)
+            lp.bt.tol = violated ? 1e-13 : lp.tol_user;   // the dual loop's tolerance is the primal feasibility tolerance
+            lp.stage = violated ? BS_DUAL : BS_P2;
+        }
+    } else if (stage == BS_DUAL) {
+        if (tid == 0) {
+            if (st->done) {
+                const int status = st->status;
+                lp.pivd += st->pivots;
+                if (status == ST_OPTIMAL) {   // primal feasible again: the primal loop confirms the optimum (usually without a pivot)
+                    b_reset_state(st);
+                    lp.bt.tol = lp.tol_user;
+                    lp.stage = BS_P2;
+                } else if (status == ST_DUAL_INFEASIBLE) {
+                    lp.status = 2;   // lp.ErrInfeasible
+                    lp.stage = BS_DONE;
+                } else lp.stage = BS_COLD;
+            } else if (lp.pivd + st->pivots >= lp.dual_budget) {
+                lp.pivd += st->pivots;
+                lp.stage = BS_COLD;   // budget spent: the caller takes the cold path for this relaxation
+            }
         }
     } else if (stage == BS_P1 && st->done) {
         const int status = st->status;
@@ -354,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void k_b_ctrl(BatchLP *__restrict__ lps, co
         st->kdone2[0] = st->kdone2[1] = 0;
         BatchOut &o = outs[li];
         o.stage = lp.stage; o.status = lp.status; o.wrapped = lp.wrapped; o.phase1_used = lp.phase1_used;
-        o.piv1 = lp.piv1; o.piv2 = lp.piv2; o.bland = lp.bland;
+        o.piv1 = lp.piv1; o.piv2 = lp.piv2; o.bland = lp.bland; o.pivd = lp.pivd; o.tcur = lp.tcur; o.pad = 0;
     }
 }
 
@@ -367,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void k_b_compact(const BatchLP *__restrict_
     const int chunk = (nin + kBlock - 1) / kBlock;
     const int lo = min(nin, tid * chunk), hi = min(nin, lo + chunk);
     int cnt = 0;
-    for (int i = lo; i < hi; i++) { const int sg = lps[ids_in[i]].stage; cnt += (sg != BS_DONE && sg != BS_HOST); }
+    for (int i = lo; i < hi; i++) { const int sg = lps[ids_in[i]].stage; cnt += (sg != BS_DONE && sg != BS_HOST && sg != BS_COLD); }
     s_cnt[tid] = cnt;
     __syncthreads();
     if (tid == 0) {
@@ -377,7 +452,7 @@ __global__ __launch_bounds__(kBlock) void k_b_compact(const BatchLP *__restrict_
     }
     __syncthreads();
     int at = s_cnt[tid];
-    for (int i = lo; i < hi; i++) { const int li = ids_in[i]; const int sg = lps[li].stage; if (sg != BS_DONE && sg != BS_HOST) ids[at++] = li; }
+    for (int i = lo; i < hi; i++) { const int li = ids_in[i]; const int sg = lps[li].stage; if (sg != BS_DONE && sg != BS_HOST && sg != BS_COLD) ids[at++] = li; }
 }
 __global__ void k_b_init_ids(int *__restrict__ ids, int *__restrict__ count, int nlp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -438,6 +513,18 @@ __global__ void k_b_tab_r_reduce(const BatchLP *__restrict__ lps, const int *__r
     for (int c = 0; c < nchunks; c++) acc += lp.scratch[(size_t)c * ldt + j];
     lp.R[j] = (j < nn) ? b_cost(lp, phase, lp.nonbasic[j]) - acc : 0.0;
 }
+
+// warm store: variable -> position map of a finished relaxation (>= 0: basic at that position; -1 - jp: nonbasic at jp)
+__global__ void k_b_posvar(const int32_t *__restrict__ basic, int m, const int32_t *__restrict__ nonbasic, int nn, int32_t *__restrict__ posvar) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) posvar[basic[i]] = i;
+    if (i < nn) posvar[nonbasic[i]] = -1 - i;
+}
+void launch_b_posvar(const int32_t *basic, int m, const int32_t *nonbasic, int nn, int32_t *posvar, hipStream_t s) {
+    const int n = m > nn ? m : nn;
+    hipLaunchKernelGGL(k_b_posvar, dim3((n + 255) / 256), dim3(256), 0, s, basic, m, nonbasic, nn, posvar);
+}
+void launch_b_setup_warm(BatchLP *lps, int nlp, hipStream_t s) { hipLaunchKernelGGL(k_b_setup_warm, dim3(nlp), dim3(kBlock), 0, s, lps); }
 
 // ---- launch wrappers --------------------------------------------------------------------------------------------------
 int batch_ldt(int nn) { return b_ldt(nn); }

@@ -868,6 +868,248 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a, const int nupd =
     }
 }
 
+// ---- dual-simplex block kernel (warm start, opt-in: gomilp_frontier_solve_warm; first built in round 2 against the ROOT's tableau, withdrawn in
+// round 3, back in round 4 against the PARENT's) -------------------------------------------------------------------------------------------
+// A child starts from its parent's OPTIMAL basis + the slack of its one new branch row (/root/reference/README.md TODO
+// "initiate the simplex at solution of parent?"; simplex.go:147-161 is the hook the reference has for it): that basis is
+// dual feasible (reduced costs >= 0) and primal infeasible only in the violated branch rows.  Each pivot here is the mirror
+// image of the primal one — leaving row first (first index of min x_B, stop when >= -tol), then the dual ratio test over
+// row p (first index of min r_j / -T[p][j] over T[p][j] < -1e-13; none: the child is infeasible), then column q — with the
+// same block terms, reductions and update formulas, so the rank-K update kernel and the primal kernel continue from its
+// state unchanged.  This mode does NOT follow the reference's pivot path: results agree in z and in every branching
+// decision, not bit by bit.
+template <int NT, int RI, int CJ, int KR, int VL>
+__device__ __forceinline__ void bt_inner2_dual_body(const BTArgs &a) {
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) double sh2[];
+    double *xb_s = sh2;
+    double *r_s = sh2 + RI * NT;
+    int *basic_s = reinterpret_cast<int *>(sh2 + RI * NT + CJ * NT);
+    int *nonbasic_s = basic_s + RI * NT;
+    double *vl_s = reinterpret_cast<double *>(nonbasic_s + CJ * NT);
+    constexpr int CR = CJ - VL;
+    int vhead = 0;
+    __shared__ double redMA[16], redMB[16];
+    __shared__ unsigned int redIA[16], redIB[16];
+    __shared__ double payA[16][KR + 2];  // per wave: r_q, T[p][q], v'_k[q]
+    __shared__ double payB[16][KR + 1];  // per wave: x_B[p], u_k[p]
+    DevState *st = a.st;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
+    const int done = __hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double inf = __builtin_inf();
+    const unsigned int ldt = (unsigned int)a.ldt;
+    const char *Tb = reinterpret_cast<const char *>(a.T);
+    auto ldT = [&](unsigned int elem) -> double { return *reinterpret_cast<const double *>(Tb + (elem << 3)); };
+    if (done) {
+        if (tid == 0) st->kdone = 0;
+        return;
+    }
+    double ureg[RI][KR], vreg[CR > 0 ? CR : 1][KR];
+#pragma unroll
+    for (int s = 0; s < RI; s++) {
+        const int i = tid + s * NT;
+        xb_s[i] = i < a.m ? a.xb[i] : inf;   // padding never wins the leaving-row argmin
+        basic_s[i] = i < a.m ? a.basic[i] : 0;
+#pragma unroll
+        for (int j = 0; j < KR; j++) ureg[s][j] = 0;
+    }
+#pragma unroll
+    for (int s = 0; s < CJ; s++) {
+        const int j = tid + s * NT;
+        r_s[j] = j < a.nn ? a.r[j] : inf;
+        nonbasic_s[j] = j < a.nn ? a.nonbasic[j] : 0;
+#pragma unroll
+        for (int j2 = 0; j2 < KR; j2++) {
+            if (s < CR) vreg[s < CR ? s : 0][j2] = 0;
+            else vl_s[((s - CR) * KR + j2) * NT + tid] = 0;
+        }
+    }
+    __syncthreads();
+    int kd = 0, status = ST_RUNNING;
+    long long npiv = 0;
+    if (tid == 0) npiv = st->pivots;
+
+    auto wave_first_min = [&](auto &val, auto nslots) -> BtWin {
+        constexpr int N = decltype(nslots)::value;
+        double x = val[0];
+#pragma unroll
+        for (int s = 1; s < N; s++) x = vmin_f64(x, val[s]);
+        BtWin w;
+        w.m = wave_min_f64(x);
+        w.i = 0xFFFFFFFFu;
+#pragma unroll
+        for (int s = N - 1; s >= 0; s--) {
+            const unsigned long long mask = __ballot(val[s] == w.m);
+            if (mask) w.i = (unsigned int)(s * NT + wbase + __builtin_ctzll(mask));
+        }
+        return w;
+    };
+    auto block_first_min = [&](const double *redM, const unsigned int *redI) -> BtWin {
+        const double x = lane < NW ? redM[lane] : inf;
+        const unsigned int ii = lane < NW ? redI[lane] : 0xFFFFFFFFu;
+        BtWin f;
+        f.m = readlane_f64(row_min_f64(x), 15);
+        const unsigned int key = (x == f.m) ? ii : 0xFFFFFFFFu;
+        f.i = (unsigned int)__builtin_amdgcn_readlane((int)row_min_u32(key), 15);
+        return f;
+    };
+
+    for (int k = 0; k < a.kmax; k++) {
+        // ---- leaving row: first index of min x_B; stop when the basis is primal feasible
+        BtWin fp;
+        double xbp = 0;
+        const double *up = &payB[0][1];
+        {
+            double xv[RI];
+#pragma unroll
+            for (int s = 0; s < RI; s++) xv[s] = xb_s[tid + s * NT];
+            const BtWin w = wave_first_min(xv, std::integral_constant<int, RI>());
+#pragma unroll
+            for (int s = 0; s < RI; s++)
+                if ((unsigned int)(tid + s * NT) == w.i) {
+                    payB[wv][0] = xv[s];
+#pragma unroll
+                    for (int j = 0; j < KR; j++) payB[wv][1 + j] = ureg[s][j];
+                }
+            if (lane == 0) { redMB[wv] = w.m; redIB[wv] = w.i; }
+            __syncthreads();
+            fp = block_first_min(redMB, redIB);
+            const int ww = (fp.i & (NT - 1)) >> 6;
+            xbp = payB[ww][0];
+            up = &payB[ww][1];
+        }
+        if (!(fp.m < -a.tol) || fp.i >= (unsigned int)a.m) { status = ST_OPTIMAL; break; }
+        const int p = (int)fp.i;
+        // ---- row p of the current tableau, dual ratio test
+        double vrow[CJ];
+#pragma unroll
+        for (int s = 0; s < CJ; s++) {
+            const int j = tid + s * NT;
+            double v = j < a.ldt ? ldT(tile_off((unsigned int)p, (unsigned int)j, ldt)) : 0.0;
+            if (s < CR) {
+#pragma unroll
+                for (int jj = 0; jj < KR; jj++) v = __builtin_fma(up[jj], vreg[s < CR ? s : 0][jj], v);
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < KR; jj++) v = __builtin_fma(up[jj], vl_s[((s - CR) * KR + ((vhead - jj) & (KR - 1))) * NT + tid], v);
+            }
+            vrow[s] = v;
+        }
+        BtWin fq;
+        double rq = 0, dpv = 1.0;
+        const double *vq = &payA[0][2];
+        {
+            double ratio[CJ];
+#pragma unroll
+            for (int s = 0; s < CJ; s++) {
+                const int j = tid + s * NT;
+                const double v = vrow[s];
+                ratio[s] = (j < a.nn && v < -1e-13) ? r_s[j] / (-v) : inf;
+            }
+            const BtWin w = wave_first_min(ratio, std::integral_constant<int, CJ>());
+#pragma unroll
+            for (int s = 0; s < CJ; s++)
+                if ((unsigned int)(tid + s * NT) == w.i) {
+                    payA[wv][0] = r_s[tid + s * NT];
+                    payA[wv][1] = vrow[s];
+#pragma unroll
+                    for (int j = 0; j < KR; j++)
+                        payA[wv][2 + j] = s < CR ? vreg[s < CR ? s : 0][j] : vl_s[((s - CR) * KR + ((vhead - j) & (KR - 1))) * NT + tid];
+                }
+            if (lane == 0) { redMA[wv] = w.m; redIA[wv] = w.i; }
+            __syncthreads();
+            fq = block_first_min(redMA, redIA);
+            const int ww = (fq.i & (NT - 1)) >> 6;
+            rq = payA[ww][0];
+            dpv = payA[ww][1];
+            vq = &payA[ww][2];
+        }
+        if (fq.m == inf || fq.i >= (unsigned int)a.nn) { status = ST_DUAL_INFEASIBLE; break; }   // no entry of row p can restore x_B[p] >= 0
+        const int q = (int)fq.i;
+        // ---- column q: loads first, the column-side updates run under their latency
+        double dcol[RI];
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            const int i = tid + s * NT;
+            const unsigned int ic = (unsigned int)(i < a.m ? i : a.m - 1);
+            dcol[s] = ldT(tile_off(ic, (unsigned int)q, ldt));
+        }
+        const double mult = rq / dpv;
+        const double theta = xbp / dpv;
+        const double rinv = 1.0 / dpv, nrinv = -rinv;
+        char *Vk = reinterpret_cast<char *>(a.V + (size_t)k * a.ldt);
+        char *Uk = reinterpret_cast<char *>(a.U + (size_t)k * a.ldu);
+#pragma unroll
+        for (int s = 0; s < CJ; s++) {
+            const int j = tid + s * NT;
+            if (j < a.ldt) {
+                const double v = vrow[s];
+                if (j < a.nn) r_s[j] = (j == q) ? -mult : __builtin_fma(-mult, v, r_s[j]);
+                const double vprime = (j == q) ? dpv + 1.0 : v;
+                *reinterpret_cast<double *>(Vk + ((unsigned int)j << 3)) = vprime;
+                if (s < CR) {
+#pragma unroll
+                    for (int jj = KR - 1; jj > 0; jj--) vreg[s < CR ? s : 0][jj] = vreg[s < CR ? s : 0][jj - 1];
+                    vreg[s < CR ? s : 0][0] = vprime;
+                } else {
+                    vl_s[((s - CR) * KR + ((vhead + 1) & (KR - 1))) * NT + tid] = vprime;
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < RI; s++) {
+            const int i = tid + s * NT;
+            double d = dcol[s];
+#pragma unroll
+            for (int j = 0; j < KR; j++) d = __builtin_fma(ureg[s][j], vq[j], d);   // vq: the v' terms of column q BEFORE this pivot
+            d = i < a.m ? d : 0.0;
+            if (i < a.ldu) {
+                const double u = (i == p) ? rinv - 1.0 : d * nrinv;
+                if (i < a.m) xb_s[i] = (i == p) ? theta : __builtin_fma(-theta, d, xb_s[i]);
+                *reinterpret_cast<double *>(Uk + ((unsigned int)i << 3)) = u;
+#pragma unroll
+                for (int jj = KR - 1; jj > 0; jj--) ureg[s][jj] = ureg[s][jj - 1];
+                ureg[s][0] = u;
+            }
+        }
+        vhead = (vhead + 1) & (KR - 1);
+        if (tid == 0) {
+            const int ent = nonbasic_s[q], lea = basic_s[p];
+            basic_s[p] = ent; nonbasic_s[q] = lea;
+            npiv += 1;
+        }
+        kd = k + 1;   // (two barriers per pivot are enough: every LDS slot written before barrier X of pivot k+1 was last read before barrier X' of pivot k that all waves passed)
+    }
+#pragma unroll
+    for (int s = 0; s < CJ; s++) {
+        const int j = tid + s * NT;
+        if (j < a.ldt) a.r[j] = j < a.nn ? r_s[j] : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < RI; s++) {
+        const int i = tid + s * NT;
+        if (i < a.ldu) a.xb[i] = i < a.m ? xb_s[i] : 0.0;
+    }
+    __syncthreads();
+    for (int i = tid; i < a.m; i += NT) a.basic[i] = basic_s[i];
+    for (int j = tid; j < a.nn; j += NT) a.nonbasic[j] = nonbasic_s[j];
+    if (tid == 0) {
+        st->pivots = npiv;
+        st->kdone = kd;
+        if (status != ST_RUNNING) { st->done = 1; st->status = status; }
+    }
+}
+
+template <int NT, int RI, int CJ, int KR, int VL>
+__global__ __launch_bounds__(NT) void k_bt_inner2_dual_batch(const BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count) {
+    if ((int)blockIdx.x >= *count) return;
+    const BatchLP &lp = lps[ids[blockIdx.x]];
+    if (lp.stage != BS_DUAL) return;
+    const BTArgs a = lp.bt;
+    bt_inner2_dual_body<NT, RI, CJ, KR, VL>(a);
+}
+
 template <int NT, int RI, int CJ, int KR, int VL, bool STAMP = false>
 __global__ __launch_bounds__(NT) void k_bt_inner2(BTArgs a) {
     bt_inner2_body<NT, RI, CJ, KR, VL, STAMP>(a);
@@ -879,7 +1121,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner2_batch(const BatchLP *__restric
     if ((int)blockIdx.x >= *count) return;   // the grid is sized from an older (larger) count of active relaxations
     const BatchLP &lp = lps[ids[blockIdx.x]];
     const int stage = lp.stage;
-    if (stage == BS_DONE || stage == BS_HOST) return;
+    if (stage == BS_DONE || stage == BS_HOST || stage == BS_DUAL || stage == BS_COLD) return;   // (BS_DUAL: the dual kernel's)
     const BTArgs a = lp.bt;
     bt_inner2_body<NT, RI, CJ, KR, VL, false>(a);
 }
@@ -901,7 +1143,7 @@ __global__ __launch_bounds__(NT) void k_b_loop(const BatchLP *__restrict__ lps, 
     if (slot >= *count) return;
     const BatchLP &lp = lps[ids[slot]];
     const int stage = lp.stage;
-    if (stage == BS_DONE || stage == BS_HOST) return;
+    if (stage == BS_DONE || stage == BS_HOST || stage == BS_COLD) return;
     BTArgs a = lp.bt;
     a.Tbuf[0] = lp.T[0]; a.Tbuf[1] = lp.T[1];
     a.loop = 1; a.par = par;
@@ -1090,7 +1332,7 @@ __global__ __launch_bounds__(kBlock) void k_bt_update_tiled_batch(const BatchLP 
     if ((int)li >= *count) return;
     const BatchLP &lp = lps[ids[li]];
     const int stage = lp.stage;
-    if (stage == BS_DONE || stage == BS_HOST) return;
+    if (stage == BS_DONE || stage == BS_HOST || stage == BS_COLD) return;
     const BTArgs a = lp.bt;
     const unsigned int bx = tile % (unsigned int)gx, by = tile / (unsigned int)gx;
     if (bx * kBlock >= 2u * (unsigned int)a.ldt || (int)by * tilerows_per_wg * 4 >= ((a.m + 3) & ~3)) return;
@@ -1299,6 +1541,19 @@ void launch_b_loop(const BatchLP *lps, const int *ids, const int *count, int nlp
     const unsigned int grid = 8u * (unsigned int)((nlp + 7) / 8) * (1u + kBLoopNU);
     const size_t lds = (size_t)(2 + 2) * 512 * (sizeof(double) + sizeof(int));
     hipExtLaunchKernelGGL((k_b_loop<512, 2, 4, kBLoopNU>), dim3(grid), dim3(512), lds, s, e0, e1, 0, lps, ids, count, nblocks, par);
+}
+// dual pivots of the relaxations in stage BS_DUAL (warm start); the others leave at once
+template <int NT, int RI, int VL>
+static void bt_inner_dual_batch_nt(const BatchLP *lps, const int *ids, const int *count, int nlp, hipStream_t s) {
+    const size_t lds = (size_t)(RI + RI) * NT * (sizeof(double) + sizeof(int)) + (size_t)VL * 8 * NT * sizeof(double);
+    if (lds > 64 * 1024) lds_attr_once(reinterpret_cast<const void *>(&k_bt_inner2_dual_batch<NT, RI, RI, 8, VL>), 140 * 1024);
+    hipLaunchKernelGGL((k_bt_inner2_dual_batch<NT, RI, RI, 8, VL>), dim3(nlp), dim3(NT), lds, s, lps, ids, count);
+}
+bool bt_dual_batch_supported(int m_max, int ldt_max) { return bt_batch_k(m_max, ldt_max) == 8 && bt_batch_supported(m_max, ldt_max); }
+void launch_bt_inner_dual_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s) {
+    const BtCfg c = bt_cfg(m_max, ldt_max, 0);
+    if (c.ri == 2) { if (c.nt == 512) bt_inner_dual_batch_nt<512, 2, 0>(lps, ids, count, nlp, s); else bt_inner_dual_batch_nt<1024, 2, 1>(lps, ids, count, nlp, s); }
+    else bt_inner_dual_batch_nt<512, 4, 0>(lps, ids, count, nlp, s);
 }
 const char *bt_batch_kernel_name(int m_max, int ldt_max) {
     if (bt_batch_k(m_max, ldt_max) == 16) return bt_group_cfg(m_max, ldt_max, 0).nt == 256 ? "k_bt_innerG_batch<8,256,1,16>" : "k_bt_innerG_batch<8,512,1,16>";

@@ -48,6 +48,7 @@ struct gomilp_pool {
                                 // time, each with its pivot workgroups on an XCD of its own) instead of the batched launch pairs.  Off:
                                 // measured 342 k pivots/s for 4 metric LPs against 391 k batched — four updates streaming at once
                                 // raise the latency of every chain's agent-scope reads and polls
+    gomilp::WarmStore warm;     // final states kept for warm starts (gomilp_frontier_solve_warm), shared by both schedules
     Engine::RootView view;      // of eng[0]'s root (all workers hold the same data)
     // further roots (gomilp_pool_add_root): resident in worker 0's engine only, read in place by the others
     std::vector<int64_t> extra_root;
@@ -196,6 +197,7 @@ int gomilp_pool_set_root(gomilp_pool *pool, const double *c0, const double *A0, 
     std::lock_guard<std::mutex> g(pool->call_mu);
     for (auto id : pool->extra_root) pool->eng[0]->free_problem(id);
     pool->extra_root.clear(); pool->extra_view.clear();
+    pool->warm.clear();
     for (size_t w = 0; w < pool->eng.size(); w++) {
         if (pool->root[w] >= 0) pool->eng[w]->free_problem(pool->root[w]);
         int64_t id = pool->eng[w]->upload(c0, A0, lda, b0, m0, n0);
@@ -232,9 +234,13 @@ int gomilp_pool_set_root(gomilp_pool *pool, const double *c0, const double *A0, 
     return GOMILP_OK;
 }
 
-int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t *root_of, const int64_t *koff, const int32_t *var,
-                                const double *sign, const double *rhs, double tol, double *z_out, double *x_out, int64_t ldx,
-                                int32_t *status_out, int32_t *has_x_out, gomilp_frontier_stats *stats) {
+}  // extern "C"
+
+// warm: parent / tag / keep per relaxation (each nullable), budget; null: a cold wave
+struct WarmArgs { const int64_t *parent, *tag; const int32_t *keep; int32_t budget; };
+static int frontier_solve_impl(gomilp_pool *pool, int64_t count, const int32_t *root_of, const int64_t *koff, const int32_t *var,
+                               const double *sign, const double *rhs, double tol, double *z_out, double *x_out, int64_t ldx,
+                               int32_t *status_out, int32_t *has_x_out, gomilp_frontier_stats *stats, const WarmArgs *wa) {
     if (!pool || count < 0 || !koff || !z_out || !x_out || !status_out || !has_x_out) return GOMILP_ERR_BAD_SHAPE;
     for (auto r : pool->root) if (r < 0) return GOMILP_ERR_BAD_SHAPE;
     std::lock_guard<std::mutex> call_guard(pool->call_mu);
@@ -326,8 +332,11 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
     }
     if (use_batch) {
         std::mutex agg_mu;
+        std::vector<int64_t> cold_again;   // warm starts that spent their dual-pivot budget: solved cold by this same call
         auto on_done_at = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) {
             std::lock_guard<std::mutex> lk(agg_mu);
+            if (o.warm) { agg.warm_started++; agg.pivots_dual += o.pivd; }
+            if (o.stage == gomilp::BS_COLD) { agg.warm_fallbacks++; cold_again.push_back(i); return; }
             if (o.stage != gomilp::BS_DONE) {   // a path the device schedule does not cover
                 agg.host_fallbacks++;
                 pool->submit([&full_solve, i](int w) { full_solve(w, i); });
@@ -349,8 +358,8 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
         // streams, put one half's updates under the other half's block kernels.
         int m_big = 0, nn_big = 0;
         for (int r = 0; r < nroots; r++) { m_big = std::max(m_big, views[r]->m + K_max); nn_big = std::max(nn_big, views[r]->n - views[r]->m + (any_p1 ? 1 : 0)); }
-        const bool two = pool->split_large && count >= 4 && gomilp::bt_batch_k(m_big, gomilp::batch_ldt(nn_big)) == 16;
-        int rc;
+        const bool two = pool->split_large && count >= 4 && gomilp::bt_batch_k(m_big, gomilp::batch_ldt(nn_big)) == 16 && !wa;
+        int rc = GOMILP_OK;
         auto make_batch2 = [&] {
             if (!pool->batch2) {
                 pool->batch2.reset(new BatchEngine(pool->device));
@@ -360,55 +369,98 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
                 pool->batch2->set_loop(pool->batch_loop != 0);
             }
         };
-        auto merge_stats = [&](const BatchEngine::Stats &bs2) {
-            bs.launches += bs2.launches; bs.supersteps = std::max(bs.supersteps, bs2.supersteps); bs.blocks += bs2.blocks; bs.blocks_sampled += bs2.blocks_sampled;
-            bs.seconds_inner += bs2.seconds_inner; bs.seconds_update += bs2.seconds_update; bs.seconds_total = std::max(bs.seconds_total, bs2.seconds_total);
+        auto merge_stats = [&](const BatchEngine::Stats &bs2, bool serial) {
+            bs.launches += bs2.launches; bs.blocks += bs2.blocks; bs.blocks_sampled += bs2.blocks_sampled;
+            bs.supersteps = serial ? bs.supersteps + bs2.supersteps : std::max(bs.supersteps, bs2.supersteps);
+            bs.seconds_inner += bs2.seconds_inner; bs.seconds_update += bs2.seconds_update;
+            bs.seconds_total = serial ? bs.seconds_total + bs2.seconds_total : std::max(bs.seconds_total, bs2.seconds_total);
+            bs.warm_kept += bs2.warm_kept;
         };
+        // a subset of the wave as a schedule of its own (the schedules take contiguous lists)
+        struct Group { std::vector<int32_t> root_of, var, keep; std::vector<int64_t> koff, parent, tag; std::vector<double> sign, rhs; };
+        auto gather = [&](const std::vector<int64_t> &idx, Group &g) {
+            g.koff.push_back(0);
+            for (int64_t i : idx) {
+                g.root_of.push_back(root_of ? root_of[i] : 0);
+                for (int64_t k = koff[i]; k < koff[i + 1]; k++) { g.var.push_back(var[k]); g.sign.push_back(sign[k]); g.rhs.push_back(rhs[k]); }
+                g.koff.push_back((int64_t)g.var.size());
+                g.parent.push_back(wa && wa->parent ? wa->parent[i] : -1);
+                g.tag.push_back(wa && wa->tag ? wa->tag[i] : -1);
+                g.keep.push_back(wa && wa->keep && wa->tag && wa->tag[i] >= 0 ? wa->keep[i] : 0);
+            }
+            if (g.var.empty()) { g.var.push_back(0); g.sign.push_back(0); g.rhs.push_back(0); }   // (valid pointers for K = 0 everywhere)
+        };
+        auto run_group = [&](BatchEngine &be, const std::vector<int64_t> &idx, const Group &g, bool start_warm, BatchEngine::Stats *bsx) -> int {
+            gomilp::WarmSpec ws;
+            ws.store = &pool->warm; ws.parent = g.parent.data(); ws.tag = g.tag.data(); ws.keep = g.keep.data();
+            ws.dual_budget = wa ? wa->budget : 0; ws.start_warm = start_warm;
+            auto od = [&, idxp = &idx](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) { on_done_at((*idxp)[(size_t)i], o, basic, xb); };
+            return be.run_roots(views.data(), nroots, g.root_of.data(), (int64_t)idx.size(), g.koff.data(), g.var.data(), g.sign.data(), g.rhs.data(), tol, od, bsx,
+                                wa ? &ws : nullptr);
+        };
+        // ---- warm starts first: the relaxations whose parent's final state is resident
+        std::vector<int64_t> cold_idx;
+        bool subset = false;   // the cold part is a proper subset of the call (or carries keep flags): gathered lists
+        if (wa) {
+            std::vector<int64_t> warm_idx;
+            for (int64_t i = 0; i < count; i++) {
+                const bool w = wa->parent && wa->parent[i] >= 0 && koff[i + 1] - koff[i] >= 1 && pool->warm.find(wa->parent[i]) != nullptr;
+                (w ? warm_idx : cold_idx).push_back(i);
+            }
+            subset = true;
+            if (!warm_idx.empty()) {
+                Group gw;
+                gather(warm_idx, gw);
+                rc = run_group(*pool->batch, warm_idx, gw, true, &bs);
+                if (rc != GOMILP_OK) { pool->drain(); return rc; }
+                std::lock_guard<std::mutex> lk(agg_mu);
+                for (int64_t i : cold_again) cold_idx.push_back(i);
+                cold_again.clear();
+                std::sort(cold_idx.begin(), cold_idx.end());
+            }
+        }
         // relaxations that start feasible (slack basis, b >= 0, every branch right-hand side >= 0: Phase II at once) against those that
         // need Phase I
         std::vector<int64_t> grp_f, grp_p;
-        if (pool->split_phase && !two && count >= 16) {
+        const int64_t ncold = subset ? (int64_t)cold_idx.size() : count;
+        if (pool->split_phase && !two && ncold >= 16) {
             std::vector<char> root_ok(nroots, 0);
             for (int r = 0; r < nroots; r++) {
                 bool ok = views[r]->unit_basis;
                 for (double v : views[r]->hb) if (v < -1e-13) { ok = false; break; }
                 root_ok[r] = ok ? 1 : 0;
             }
-            for (int64_t i = 0; i < count; i++) {
+            for (int64_t t = 0; t < ncold; t++) {
+                const int64_t i = subset ? cold_idx[(size_t)t] : t;
                 bool f = root_ok[root_of ? root_of[i] : 0] != 0;
                 for (int64_t k = koff[i]; k < koff[i + 1] && f; k++) if (rhs[k] < -1e-13) f = false;
                 (f ? grp_f : grp_p).push_back(i);
             }
         }
-        if (!grp_f.empty() && !grp_p.empty()) {
-            // gather each group's description (the schedules take contiguous lists)
-            struct Group { std::vector<int32_t> root_of, var; std::vector<int64_t> koff; std::vector<double> sign, rhs; };
-            auto gather = [&](const std::vector<int64_t> &idx, Group &g) {
-                g.koff.push_back(0);
-                for (int64_t i : idx) {
-                    g.root_of.push_back(root_of ? root_of[i] : 0);
-                    for (int64_t k = koff[i]; k < koff[i + 1]; k++) { g.var.push_back(var[k]); g.sign.push_back(sign[k]); g.rhs.push_back(rhs[k]); }
-                    g.koff.push_back((int64_t)g.var.size());
-                }
-                if (g.var.empty()) { g.var.push_back(0); g.sign.push_back(0); g.rhs.push_back(0); }   // (valid pointers for K = 0 everywhere)
-            };
+        BatchEngine::Stats bsc;   // the cold part
+        if (ncold == 0) {
+            // (every relaxation of the call was a warm start that stayed warm)
+        } else if (!grp_f.empty() && !grp_p.empty()) {
             Group gf, gp;
             gather(grp_f, gf); gather(grp_p, gp);
             make_batch2();
             BatchEngine::Stats bs2;
             int rc2 = GOMILP_OK;
-            auto on_done_f = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) { on_done_at(grp_f[(size_t)i], o, basic, xb); };
-            auto on_done_p = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) { on_done_at(grp_p[(size_t)i], o, basic, xb); };
             pool->batch->set_low_priority(true);   // the wide group yields to the long chains
             std::thread t2([&] {
                 hipSetDevice(pool->device);
-                rc2 = pool->batch2->run_roots(views.data(), nroots, gf.root_of.data(), (int64_t)grp_f.size(), gf.koff.data(), gf.var.data(), gf.sign.data(), gf.rhs.data(), tol, on_done_f, &bs2);
+                rc2 = run_group(*pool->batch2, grp_f, gf, false, &bs2);
             });
-            rc = pool->batch->run_roots(views.data(), nroots, gp.root_of.data(), (int64_t)grp_p.size(), gp.koff.data(), gp.var.data(), gp.sign.data(), gp.rhs.data(), tol, on_done_p, &bs);
+            rc = run_group(*pool->batch, grp_p, gp, false, &bsc);
             t2.join();
             pool->batch->set_low_priority(false);
             if (rc == GOMILP_OK) rc = rc2;
-            merge_stats(bs2);
+            merge_stats(bsc, true); merge_stats(bs2, false);
+        } else if (subset) {
+            Group gc;
+            gather(cold_idx, gc);
+            rc = run_group(*pool->batch, cold_idx, gc, false, &bsc);
+            merge_stats(bsc, true);
         } else if (two) {
             make_batch2();
             const int64_t half = count / 2;
@@ -422,10 +474,11 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
             rc = pool->batch->run_roots(views.data(), nroots, root_of, half, koff, var, sign, rhs, tol, on_done, &bs);
             t2.join();
             if (rc == GOMILP_OK) rc = rc2;
-            merge_stats(bs2);
+            merge_stats(bs2, false);
         } else {
             rc = pool->batch->run_roots(views.data(), nroots, root_of, count, koff, var, sign, rhs, tol, on_done, &bs);
         }
+        agg.warm_kept = bs.warm_kept;
         pool->drain();
         if (rc != GOMILP_OK) return rc;
     } else {
@@ -443,9 +496,33 @@ int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t 
         stats->supersteps = bs.supersteps; stats->seconds_batch = bs.seconds_total;
         stats->blocks = bs.blocks; stats->blocks_sampled = bs.blocks_sampled;
         stats->seconds_inner_kernels = bs.seconds_inner; stats->seconds_update_kernels = bs.seconds_update;
+        stats->warm_kept = bs.warm_kept;
         stats->workers = W; stats->device_id = pool->device;
         stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
+    return GOMILP_OK;
+}
+
+extern "C" {
+
+int gomilp_frontier_solve_roots(gomilp_pool *pool, int64_t count, const int32_t *root_of, const int64_t *koff, const int32_t *var,
+                                const double *sign, const double *rhs, double tol, double *z_out, double *x_out, int64_t ldx,
+                                int32_t *status_out, int32_t *has_x_out, gomilp_frontier_stats *stats) {
+    return frontier_solve_impl(pool, count, root_of, koff, var, sign, rhs, tol, z_out, x_out, ldx, status_out, has_x_out, stats, nullptr);
+}
+
+int gomilp_frontier_solve_warm(gomilp_pool *pool, int64_t count, const int64_t *koff, const int32_t *var, const double *sign,
+                               const double *rhs, const int64_t *parent, const int64_t *tag, const int32_t *keep, int32_t dual_budget,
+                               double tol, double *z_out, double *x_out, int32_t *status_out, int32_t *has_x_out,
+                               gomilp_frontier_stats *stats) {
+    if (!pool) return GOMILP_ERR_BAD_SHAPE;
+    WarmArgs wa{parent, tag, keep, dual_budget};
+    return frontier_solve_impl(pool, count, nullptr, koff, var, sign, rhs, tol, z_out, x_out, pool->n0, status_out, has_x_out, stats, &wa);
+}
+
+int gomilp_pool_release_warm(gomilp_pool *pool, int64_t tag) {
+    if (!pool) return GOMILP_ERR_BAD_SHAPE;
+    if (tag < 0) pool->warm.clear(); else pool->warm.release(tag);
     return GOMILP_OK;
 }
 

@@ -24,6 +24,7 @@ enum : int32_t {
     ST_BLAND_FAILED = 6,  // replaceBland exhausted its candidates (lp.ErrBland, simplex.go:382)
     ST_FORCED_DONE = 7,   // a set-up pivot ordered with forced_nocommit = 3 has run: later launches of the superstep are no-ops
     ST_XCHG_TIMEOUT = 9,    // multi-workgroup block kernel (btg_kernels.hip): an exchange saw no progress (a workgroup never ran)
+    ST_DUAL_INFEASIBLE = 11,   // dual simplex (warm start): a row with x_B < 0 has no entry that can restore it — the relaxation is infeasible
     ST_NEED_EXACT = 10      // the winning ratio is within BTArgs::guard of zero: the host refreshes x_B with a gonum-order solve of the
                             // current basis before the decision is taken (simplex.go:268-277 sees a fresh x_B every pivot)
 };
@@ -175,8 +176,12 @@ enum : int32_t {
     BS_P2 = 3,        // Phase-II loop running
     BS_EXCH = 6,      // the zero-level artificial is being exchanged out of the basis (one forced pivot, simplex.go:581-606)
     BS_DONE = 4,      // terminal: `status` holds the outcome (GOMILP_OK = basis + x_B ready for the final gonum-order solve)
-    BS_HOST = 5       // terminal: a path the device schedule does not cover (artificial exchange, guard band, ...): the
+    BS_HOST = 5,      // terminal: a path the device schedule does not cover (artificial exchange, guard band, ...): the
                       // host solves this relaxation through the single-relaxation engine
+    // warm start (opt-in): the relaxation starts from its parent's final tableau + the slack of its one new branch row
+    BS_DUAL_START = 7,  // reduced costs of the parent's basis are being rebuilt; then BS_DUAL (new row violated) or BS_P2 (still optimal)
+    BS_DUAL = 8,        // dual-simplex loop running (k_bt_inner2_dual_batch)
+    BS_COLD = 9         // terminal: the dual simplex spent its pivot budget — the caller solves this relaxation cold
 };
 
 struct BatchLP {
@@ -201,6 +206,13 @@ struct BatchLP {
     const int32_t *gbasic0, *gnonbasic0;   // its positional lists
     const int32_t *gposvar0; // n0: variable id -> basis position (>= 0) or -1 - nonbasic position
     int32_t gldt, gen;       // gen = 1: this relaxation starts from that basis
+    // warm start: the parent's final state (WarmStore entry, engine_batch.cpp): tableau in 4x4 tiles (wm rows, the child's own ldt),
+    // updated x_B, positional lists, variable -> position map; the child's one new branch row is the LAST of var / sign / rhs
+    const double *wT, *wxb;
+    const int32_t *wbasic, *wnonbasic, *wposvar;
+    int32_t warm, wm;        // warm = 1: start from that state (m = wm + 1)
+    int32_t dual_budget, pad1;   // dual pivots before the relaxation is handed back (BS_COLD)
+    int64_t pivd;            // dual pivots performed
     double tol_user;         // Phase-II tolerance of the call (GoMILP: 0)
     int32_t stage;           // BS_*
     int32_t tcur;            // index of the current T buffer
@@ -217,7 +229,8 @@ struct BatchLP {
 // What the host needs to see of a relaxation after every control step (one small D2H copy per superstep for the whole wave)
 struct BatchOut {
     int32_t stage, status, wrapped, phase1_used;
-    int64_t piv1, piv2, bland;
+    int64_t piv1, piv2, bland, pivd;
+    int32_t tcur, pad;   // which tableau buffer holds the final state (warm store)
 };
 
 // State of the device column search (general_kernels.hip)

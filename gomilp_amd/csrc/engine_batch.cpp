@@ -28,6 +28,58 @@ template <typename T>
 hipError_t bhost(T **p, size_t count) { return hipHostMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault); }
 }  // namespace
 
+WarmEntry::~WarmEntry() {
+    for (void *p : {(void *)T, (void *)xb, (void *)basic, (void *)nonbasic, (void *)posvar}) if (p) hipFree(p);
+}
+std::shared_ptr<WarmEntry> WarmStore::find(int64_t tag) {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = by_tag_.find(tag);
+    return it == by_tag_.end() ? nullptr : it->second;
+}
+std::shared_ptr<WarmEntry> WarmStore::acquire(int m4, int ldt, int m, int nn, int n) {
+    const size_t need_t = (size_t)m4 * ldt;
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        for (size_t i = 0; i < free_.size(); i++) {
+            WarmEntry &e = *free_[i];
+            if (e.cap_t >= need_t && e.cap_m >= (size_t)m && e.cap_nn >= (size_t)nn && e.cap_n >= (size_t)n) {
+                auto r = free_[i];
+                free_[i] = free_.back();
+                free_.pop_back();
+                return r;
+            }
+        }
+    }
+    std::shared_ptr<WarmEntry> e(new WarmEntry);
+    // head-room: the children of this node are one row taller, theirs two, ...: a recycled entry should fit a few levels deeper
+    e->cap_t = (size_t)(m4 + 32) * ldt; e->cap_m = (size_t)m + 32; e->cap_nn = (size_t)nn + 8; e->cap_n = (size_t)n + 32;
+    if (bmalloc(&e->T, e->cap_t) != hipSuccess || bmalloc(&e->xb, e->cap_m) != hipSuccess || bmalloc(&e->basic, e->cap_m) != hipSuccess ||
+        bmalloc(&e->nonbasic, e->cap_nn) != hipSuccess || bmalloc(&e->posvar, e->cap_n) != hipSuccess) return nullptr;
+    return e;
+}
+void WarmStore::put(int64_t tag, std::shared_ptr<WarmEntry> e) {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = by_tag_.find(tag);
+    if (it != by_tag_.end()) { free_.push_back(it->second); by_tag_.erase(it); }
+    by_tag_[tag] = std::move(e);
+}
+void WarmStore::release(int64_t tag) {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = by_tag_.find(tag);
+    if (it == by_tag_.end()) return;
+    if (free_.size() < 4096) free_.push_back(it->second);
+    by_tag_.erase(it);
+}
+void WarmStore::clear() {
+    std::lock_guard<std::mutex> g(mu_);
+    by_tag_.clear();
+    free_.clear();
+}
+size_t WarmStore::size() {
+    std::lock_guard<std::mutex> g(mu_);
+    return by_tag_.size();
+}
+
 struct BatchEngine::Buf {
     int cap_lp = 0, cap_m4 = 0, cap_ldt = 0, cap_ldu = 0, cap_n = 0;
     int64_t cap_k = 0;
@@ -164,7 +216,8 @@ int BatchEngine::ensure(int nlp, int m_max, int n_max, int ldt1, int64_t ktot) {
 }
 
 int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, const int32_t *root_of, int64_t count, const int64_t *koff,
-                           const int32_t *var, const double *sign, const double *rhs, double tol, const DoneFn &on_done, Stats *stats) {
+                           const int32_t *var, const double *sign, const double *rhs, double tol, const DoneFn &on_done, Stats *stats,
+                           const WarmSpec *warm) {
     const double t0 = bnow();
     Stats local;
     Stats &S = stats ? *stats : local;
@@ -219,6 +272,8 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         rho_of[r] = e.d;
     }
     // ---- per-relaxation argument blocks
+    std::vector<std::shared_ptr<WarmEntry>> warm_used;
+    int nwarm = 0;
     const size_t sT = (size_t)b.cap_m4 * b.cap_ldt;
     for (int64_t k = 0; k < ktot; k++) { b.h_var[k] = var[koff[0] + k]; b.h_sr[k] = sign[koff[0] + k]; b.h_sr[b.cap_k + k] = rhs[koff[0] + k]; }
     for (int i = 0; i < nlp; i++) {
@@ -243,6 +298,17 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         lp.basic = b.d_basic + (size_t)i * b.cap_ldu; lp.nonbasic = b.d_nonbasic + (size_t)i * b.cap_ldt; lp.srcpos = b.d_srcpos + (size_t)i * b.cap_ldt;
         lp.st = b.d_st + i;
         lp.tol_user = tol; lp.kblock = kb; lp.stage = BS_HOST;
+        if (warm && warm->store && warm->start_warm && warm->parent && warm->parent[i] >= 0 && K >= 1 && R.unit_basis && !lp.gen && kb == 8) {
+            std::shared_ptr<WarmEntry> e = warm->store->find(warm->parent[i]);
+            // the parent must be this relaxation minus its last branch row, solved on the same root data
+            if (e && e->m + 1 == lp.m && e->n + 1 == lp.n && e->K + 1 == K && e->root_serial == R.serial && e->ldt == batch_ldt(lp.n - lp.m)) {
+                lp.warm = 1; lp.wm = e->m;
+                lp.wT = e->T; lp.wxb = e->xb; lp.wbasic = e->basic; lp.wnonbasic = e->nonbasic; lp.wposvar = e->posvar;
+                lp.dual_budget = warm->dual_budget > 0 ? warm->dual_budget : 64;
+                warm_used.push_back(e);   // (alive until the wave is through, whatever the caller releases meanwhile)
+                nwarm++;
+            }
+        }
         // degenerate pivots are decided on a fresh gonum-order x_B: such a relaxation is handed to the worker path (ST_NEED_EXACT -> BS_HOST)
         lp.bt.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && (lp.m <= 256 || lp.gen || R.scale_span > 1e9))) ? 1e-9 : 0.0;
         lp.bt.xbuf = b.d_xbuf + (size_t)i * bt_xbuf_doubles();
@@ -273,7 +339,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         const int *ids = b.d_ids[(step + 1) & 1];
         const int *cnt = step == 0 ? b.d_active + (kMaxSteps - 1) : b.d_active + (step - 1);
         last_loop_par = -1;
-        if (allow_loop && loop_slots > 0 && bound <= loop_slots) {
+        if (allow_loop && loop_slots > 0 && bound <= loop_slots && nwarm == 0) {
             hipEvent_t e[2] = {nullptr, nullptr};
             if (sampling_) {
                 while (b.samp_ev.size() < (size_t)(nsamp + 1) * 4) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) break; b.samp_ev.push_back(ev); }
@@ -296,6 +362,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
                 if (b.samp_ev.size() >= (size_t)(nsamp + 1) * 4) { for (int q = 0; q < 4; q++) e[q] = b.samp_ev[(size_t)nsamp * 4 + q]; nsamp++; }
             }
             launch_bt_inner_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_, e[0], e[1]);
+            if (nwarm) { launch_bt_inner_dual_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_); S.launches += 1; }   // (stage BS_DUAL only)
             launch_bt_update_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_, e[2], e[3]);
         }
         S.launches += 2 * nb; S.blocks += nb;
@@ -311,8 +378,10 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
     };
     // ---- prologue: set-up, T, the forced Phase-I pivots, first reduced costs
     launch_b_setup(b.d_lps, nlp, stream_);
+    if (nwarm) { launch_b_setup_warm(b.d_lps, nlp, stream_); S.launches += 1; }
     launch_b_gather(b.d_lps, nlp, m_max, ldt1, stream_);
     S.launches += 2;
+    S.warm_started = nwarm;
     blocks(1, false);   // (set-up pivots: one block each, launch pair)
     control(false);
     if ((rc = snapshot(0)) != GOMILP_OK) return rc;
@@ -336,13 +405,31 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         for (int i = 0; i < nlp; i++) {
             if (reported[i]) continue;
             const BatchOut &lp = b.h_snap[slot][i];
-            if (lp.stage != BS_DONE && lp.stage != BS_HOST) continue;
+            if (lp.stage != BS_DONE && lp.stage != BS_HOST && lp.stage != BS_COLD) continue;
             const int m_i = b.h_lps[i].m;
             reported[i] = 1;
             Outcome o;
             o.stage = lp.stage; o.status = lp.status; o.wrapped = lp.wrapped; o.phase1_used = lp.phase1_used;
-            o.piv1 = lp.piv1; o.piv2 = lp.piv2; o.bland = lp.bland;
+            o.piv1 = lp.piv1; o.piv2 = lp.piv2; o.bland = lp.bland; o.pivd = lp.pivd; o.warm = b.h_lps[i].warm;
             if (lp.stage == BS_DONE && (lp.status == GOMILP_OK || lp.status == GOMILP_ERR_BLAND)) {
+                if (lp.status == GOMILP_OK && warm && warm->store && warm->keep && warm->keep[i] && warm->tag && !b.h_lps[i].gen && kb == 8) {
+                    // keep the final state for this relaxation's children: device-to-device, behind nothing (the relaxation is terminal)
+                    const BatchLP &hl = b.h_lps[i];
+                    const int nn_i = hl.n - hl.m, ldt_i = batch_ldt(nn_i), m4_i = (hl.m + 3) & ~3;
+                    std::shared_ptr<WarmEntry> e = warm->store->acquire(m4_i, ldt_i, hl.m, nn_i, hl.n);
+                    if (e) {
+                        e->m = hl.m; e->n = hl.n; e->nn = nn_i; e->ldt = ldt_i; e->K = hl.K;
+                        e->root_serial = roots[root_of ? root_of[i] : 0]->serial;
+                        const double *Tsrc = (lp.tcur & 1) ? hl.T[1] : hl.T[0];
+                        B_TRY(hipMemcpyAsync(e->T, Tsrc, (size_t)m4_i * ldt_i * sizeof(double), hipMemcpyDeviceToDevice, copy_stream_));
+                        B_TRY(hipMemcpyAsync(e->xb, hl.xb, (size_t)hl.m * sizeof(double), hipMemcpyDeviceToDevice, copy_stream_));
+                        B_TRY(hipMemcpyAsync(e->basic, hl.basic, (size_t)hl.m * sizeof(int32_t), hipMemcpyDeviceToDevice, copy_stream_));
+                        B_TRY(hipMemcpyAsync(e->nonbasic, hl.nonbasic, (size_t)nn_i * sizeof(int32_t), hipMemcpyDeviceToDevice, copy_stream_));
+                        launch_b_posvar(e->basic, hl.m, e->nonbasic, nn_i, e->posvar, copy_stream_);
+                        warm->store->put(warm->tag[i], e);
+                        S.warm_kept++;
+                    }
+                }
                 // terminal relaxations are never written again: their basis / x_B can leave on the second stream at once
                 B_TRY(hipMemcpyAsync(b.h_basic + (size_t)i * b.cap_ldu, b.d_basic + (size_t)i * b.cap_ldu, (size_t)m_i * sizeof(int32_t), hipMemcpyDeviceToHost, copy_stream_));
                 B_TRY(hipMemcpyAsync(b.h_xb + (size_t)i * b.cap_ldu, b.d_xb + (size_t)i * b.cap_ldu, (size_t)m_i * sizeof(double), hipMemcpyDeviceToHost, copy_stream_));
@@ -363,7 +450,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         // what a block step costs there); a narrow wave is a few single-workgroup chains: longer supersteps, fewer round trips
         int nb = nlp <= 16 ? (step < 2 ? 4 : 8) : (step < 2 ? 1 : (step < 4 ? 2 : (step < 8 ? 4 : 8)));
         // a loop launch has no boundary between its blocks: longer supersteps (fewer control steps on the chain) once the wave is narrow
-        if (loop_slots > 0 && bound <= loop_slots && step >= 2) nb = bound <= 8 ? (step >= 3 ? 32 : 16) : 8;
+        if (loop_slots > 0 && bound <= loop_slots && step >= 2 && nwarm == 0) nb = bound <= 8 ? (step >= 3 ? 32 : 16) : 8;
         step++;
         blocks(nb, true);
         control(true);

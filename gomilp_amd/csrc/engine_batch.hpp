@@ -4,11 +4,50 @@
 // /root/reference/tree.go:98-100,196-205 (each worker: subProblem.solve -> lp.Simplex, subproblem.go:141-159).
 #pragma once
 #include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "engine.hpp"
 
 namespace gomilp {
+
+// Warm start (opt-in; SURVEY.md §8f-1, /root/reference/README.md TODO "initiate the simplex at solution of parent", the reference's hook:
+// initialBasic, simplex.go:147-161): final states of relaxations the caller asked to keep, by caller-chosen tag (the B&B node id).  A
+// later relaxation that names such a tag as its parent and carries ONE more branch row starts from that basis (batch_kernels.hip
+// k_b_setup_warm).  Shared by the schedules of a pool; entries are recycled through a free list.
+struct WarmEntry {
+    int m = 0, n = 0, nn = 0, ldt = 0, K = 0;
+    uint64_t root_serial = 0;
+    double *T = nullptr, *xb = nullptr;                              // tableau (4x4 tiles, m4 x ldt), updated x_B
+    int32_t *basic = nullptr, *nonbasic = nullptr, *posvar = nullptr;
+    size_t cap_t = 0, cap_m = 0, cap_nn = 0, cap_n = 0;
+    ~WarmEntry();
+};
+class WarmStore {
+   public:
+    std::shared_ptr<WarmEntry> find(int64_t tag);
+    // an entry with room for the given shape (recycled or new; nullptr: out of device memory)
+    std::shared_ptr<WarmEntry> acquire(int m4, int ldt, int m, int nn, int n);
+    void put(int64_t tag, std::shared_ptr<WarmEntry> e);
+    void release(int64_t tag);
+    void clear();
+    size_t size();
+
+   private:
+    std::mutex mu_;
+    std::map<int64_t, std::shared_ptr<WarmEntry>> by_tag_;
+    std::vector<std::shared_ptr<WarmEntry>> free_;
+};
+// per-wave description of the warm start: parent[i] (tag, or < 0: none) / keep[i] / tag[i] per relaxation
+struct WarmSpec {
+    WarmStore *store = nullptr;
+    const int64_t *parent = nullptr, *tag = nullptr;
+    const int32_t *keep = nullptr;
+    int dual_budget = 0;    // dual pivots before a warm relaxation is handed back (BS_COLD)
+    bool start_warm = true; // false: keep only (every relaxation starts cold)
+};
 
 class BatchEngine {
    public:
@@ -16,10 +55,11 @@ class BatchEngine {
         int stage = BS_HOST;       // BS_DONE: `status` is final (GOMILP_OK / ERR_BLAND: basis + x_B ready for the final solve);
                                    // BS_HOST: the single-relaxation engine must solve this child
         int status = 0, wrapped = 0, phase1_used = 0;
-        int64_t piv1 = 0, piv2 = 0, bland = 0;
+        int64_t piv1 = 0, piv2 = 0, bland = 0, pivd = 0;   // (pivd: dual pivots of a warm start)
+        int warm = 0;                                      // started from its parent's basis
     };
     struct Stats {
-        int64_t launches = 0, supersteps = 0, blocks = 0, loop_launches = 0;
+        int64_t launches = 0, supersteps = 0, blocks = 0, loop_launches = 0, warm_started = 0, warm_kept = 0;
         double seconds_setup = 0, seconds_total = 0;
         double seconds_inner = 0, seconds_update = 0;   // HIP-event time of the sampled block launches (set_sampling)
         int64_t blocks_sampled = 0;
@@ -49,7 +89,8 @@ class BatchEngine {
     // relaxation i is a child (K_i >= 0 rows) of roots[root_of[i]] (root_of == nullptr: all of roots[0]); the wave is
     // ONE batch: independent LPs of similar shape are children with K = 0 of different roots
     int run_roots(const Engine::RootView *const *roots, int nroots, const int32_t *root_of, int64_t count, const int64_t *koff,
-                  const int32_t *var, const double *sign, const double *rhs, double tol, const DoneFn &on_done, Stats *stats);
+                  const int32_t *var, const double *sign, const double *rhs, double tol, const DoneFn &on_done, Stats *stats,
+                  const WarmSpec *warm = nullptr);
 
    private:
     struct Buf;

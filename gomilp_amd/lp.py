@@ -54,10 +54,12 @@ class FrontierStats(C.Structure):
                 ("workers", C.c_int32), ("device_id", C.c_int32), ("seconds_total", C.c_double),
                 ("seconds_busy_sum", C.c_double), ("batched_relaxations", C.c_int64), ("host_fallbacks", C.c_int64),
                 ("supersteps", C.c_int64), ("seconds_batch", C.c_double), ("blocks", C.c_int64), ("blocks_sampled", C.c_int64),
-                ("seconds_inner_kernels", C.c_double), ("seconds_update_kernels", C.c_double)]
+                ("seconds_inner_kernels", C.c_double), ("seconds_update_kernels", C.c_double),
+                ("warm_started", C.c_int64), ("warm_fallbacks", C.c_int64), ("warm_kept", C.c_int64), ("pivots_dual", C.c_int64)]
 
 
 EXPORTS = [
+    "gomilp_frontier_solve_warm", "gomilp_pool_release_warm",
     "gomilp_lp_upload_child", "gomilp_pool_create", "gomilp_pool_destroy", "gomilp_pool_set", "gomilp_pool_set_root", "gomilp_frontier_solve", "gomilp_pool_add_root", "gomilp_frontier_solve_roots", "gomilp_pool_solve_root", "gomilp_debug_find_independent", "gomilp_debug_find_independent_device", "gomilp_debug_cond_estimate",
     "gomilp_lp_simplex", "gomilp_ctx_create", "gomilp_ctx_destroy", "gomilp_ctx_device", "gomilp_ctx_set",
     "gomilp_lp_upload", "gomilp_lp_free", "gomilp_lp_solve_resident", "gomilp_lp_last_trace", "gomilp_version",
@@ -103,6 +105,9 @@ def lib():
     L.gomilp_pool_set_root.argtypes = [C.c_void_p, dp, dp, C.c_int64, dp, C.c_int64, C.c_int64]
     L.gomilp_frontier_solve.argtypes = [C.c_void_p, C.c_int64, ip, i32p, dp, dp, C.c_double, dp, dp, i32p, i32p,
                                         C.POINTER(FrontierStats)]
+    L.gomilp_frontier_solve_warm.argtypes = [C.c_void_p, C.c_int64, ip, i32p, dp, dp, ip, ip, i32p, C.c_int32, C.c_double, dp, dp, i32p, i32p,
+                                             C.POINTER(FrontierStats)]
+    L.gomilp_pool_release_warm.argtypes = [C.c_void_p, C.c_int64]
     L.gomilp_pool_solve_root.argtypes = [C.c_void_p, C.c_double, dp, dp, i32p, C.POINTER(Stats)]
     L.gomilp_pool_add_root.argtypes = [C.c_void_p, dp, dp, C.c_int64, dp, C.c_int64, C.c_int64]
     L.gomilp_frontier_solve_roots.argtypes = [C.c_void_p, C.c_int64, i32p, ip, i32p, dp, dp, C.c_double, dp, dp, C.c_int64, i32p, i32p,
@@ -356,6 +361,41 @@ class FrontierPool:
         if rc != OK:
             raise RuntimeError("gomilp_frontier_solve failed: %s" % STATUS_NAMES.get(rc, rc))
         return FrontierResult(status, z, x, has_x, {k: getattr(st, k) for k, _ in FrontierStats._fields_})
+
+    def solve_warm(self, children, parents=None, tags=None, keep=None, dual_budget: int = 0, tol: float = 0.0) -> FrontierResult:
+        """gomilp_frontier_solve_warm (opt-in warm start, include/gomilp_lp.h): children of the set_root problem; parents[i] = tag of a kept
+        relaxation that is child i minus its last constraint (or -1), tags[i] = the id child i is kept under when keep[i]."""
+        count = len(children)
+        koff = np.zeros(count + 1, dtype=np.int64)
+        for i, ch in enumerate(children):
+            koff[i + 1] = koff[i] + len(ch)
+        tot = int(koff[-1])
+        var = np.zeros(max(tot, 1), dtype=np.int32)
+        sign = np.zeros(max(tot, 1), dtype=np.float64)
+        rhs = np.zeros(max(tot, 1), dtype=np.float64)
+        k = 0
+        for ch in children:
+            for (v, s, r) in ch:
+                var[k], sign[k], rhs[k] = v, s, r
+                k += 1
+        par = np.full(count, -1, dtype=np.int64) if parents is None else np.ascontiguousarray(parents, dtype=np.int64)
+        tg = np.full(count, -1, dtype=np.int64) if tags is None else np.ascontiguousarray(tags, dtype=np.int64)
+        kp = np.zeros(count, dtype=np.int32) if keep is None else np.ascontiguousarray(keep, dtype=np.int32)
+        z = np.full(count, math.nan)
+        x = np.zeros((count, self.n0))
+        status = np.zeros(count, dtype=np.int32)
+        has_x = np.zeros(count, dtype=np.int32)
+        st = FrontierStats()
+        i32p = C.POINTER(C.c_int32)
+        rc = lib().gomilp_frontier_solve_warm(self._h, count, _ip(koff), var.ctypes.data_as(i32p), _dp(sign), _dp(rhs), _ip(par), _ip(tg),
+                                              kp.ctypes.data_as(i32p), int(dual_budget), float(tol), _dp(z), _dp(x),
+                                              status.ctypes.data_as(i32p), has_x.ctypes.data_as(i32p), C.byref(st))
+        if rc != OK:
+            raise RuntimeError("gomilp_frontier_solve_warm failed: %s" % STATUS_NAMES.get(rc, rc))
+        return FrontierResult(status, z, x, has_x, {k: getattr(st, k) for k, _ in FrontierStats._fields_})
+
+    def release_warm(self, tag: int = -1) -> None:
+        lib().gomilp_pool_release_warm(self._h, int(tag))
 
     def close(self) -> None:
         if self._h:

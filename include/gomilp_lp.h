@@ -167,6 +167,11 @@ typedef struct gomilp_frontier_stats {
     int64_t blocks_sampled;      /* of which timed with HIP events (pool knob "sample_batch") */
     double seconds_inner_kernels;  /* HIP-event time of the sampled batched inner launches (k_bt_inner2_batch) */
     double seconds_update_kernels; /* ... of the sampled batched update launches (k_bt_update_tiled_batch) */
+    /* warm start (gomilp_frontier_solve_warm) */
+    int64_t warm_started;        /* relaxations that started from their parent's basis */
+    int64_t warm_fallbacks;      /* of which handed back to the cold path (dual-pivot budget spent) */
+    int64_t warm_kept;           /* final states kept for children */
+    int64_t pivots_dual;         /* dual-simplex pivots of the warm starts (not counted in pivots_phase1 / 2) */
 } gomilp_frontier_stats;
 
 gomilp_pool *gomilp_pool_create(int device, int workers, int *status);
@@ -209,11 +214,27 @@ int gomilp_incumbent_allreduce(gomilp_comm *comm, double local_z, int64_t local_
 /* the host logic of the exchange (no GPU): lexicographic minimum of a table of `world` (z, index) pairs, +Inf = none */
 void gomilp_incumbent_pick(const double *table, int world, double *global_z, int64_t *global_index);
 
-/* The root relaxation (subproblem.go:172) on the pool's first worker.  (A warm start of the children from the root's optimal
- * tableau — SURVEY.md §8f-1; the reference's hook would be initialBasic, simplex.go:147-161 — was built in round 2 and withdrawn
- * in round 3: on the benchmark frontier the reference's cold Phase I proves a cut-off child infeasible in ~7 pivots where the
- * dual simplex from the root's optimum needed hundreds) */
+/* The root relaxation (subproblem.go:172) on the pool's first worker. */
 int gomilp_pool_solve_root(gomilp_pool *pool, double tol, double *opt_f, double *opt_x, int32_t *has_x, gomilp_lp_stats *stats);
+
+/* Warm start from the parent's basis — OPT-IN (/root/reference/README.md TODO "initiate the simplex at solution of
+ * parent?"; the reference's own hook would be initialBasic, simplex.go:147-161).  As gomilp_frontier_solve, plus per relaxation:
+ *   tag[i]     caller-chosen id (>= 0; the B&B node id) under which the relaxation's final state stays resident when keep[i] != 0 and it
+ *              ends GOMILP_OK inside the device-batched schedule (2-3 MB of HBM per 520-row relaxation; gomilp_pool_release_warm drops it,
+ *              gomilp_pool_set_root drops all);
+ *   parent[i]  tag of a kept relaxation that is THIS relaxation minus its last branch row, or < 0.  With a parent the relaxation starts
+ *              from the parent's final basis + the slack of the new row: dual feasible, primal infeasible at most in that row — a dual-
+ *              simplex loop on the device (k_bt_inner2_dual_batch) repairs it or proves the row infeasible; a new row the parent's
+ *              optimum already satisfies costs no pivot.  After `dual_budget` dual pivots (0: default 64) the relaxation is handed to the
+ *              cold path of this same call (the reference's Phase I), so the worst case is cold + budget.
+ * Parity in this mode (it does not follow the reference's pivot path): status, branching / pruning decisions and |z - z_ref| <= 1e-9
+ * max(1, |z_ref|); x is the gonum-order solve of the final basis, as always — the same vertex reached through another basis order can
+ * differ in the last bits.  Without parents (parent == NULL or all < 0) the call is gomilp_frontier_solve + keeping. */
+int gomilp_frontier_solve_warm(gomilp_pool *pool, int64_t count, const int64_t *koff, const int32_t *var, const double *sign,
+                               const double *rhs, const int64_t *parent, const int64_t *tag, const int32_t *keep, int32_t dual_budget,
+                               double tol, double *z_out, double *x_out, int32_t *status_out, int32_t *has_x_out,
+                               gomilp_frontier_stats *stats);
+int gomilp_pool_release_warm(gomilp_pool *pool, int64_t tag);   /* tag < 0: all */
 
 /* Several roots in one pool: relaxation i of a wave is a child (K_i >= 0 rows) of root root_of[i]; index 0 is the root of
  * gomilp_pool_set_root, gomilp_pool_add_root returns 1, 2, ... (or -(gomilp_status)).  Independent LPs of similar shape
