@@ -670,6 +670,7 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a, const int nupd =
             // (a winning pivot element below the guard too: the updated tableau drifts by ~1e-12 on nearly dependent rows, where the fresh
             // column has an exact zero that the reference's 1e-13 rounding removes from the test — pivoting there gave singular bases)
             if (a.guard > 0 && !(k == 0 && blk == 0 && a.exact_once) && (mv <= a.guard || mv2 - mv <= a.guard * fmax(1.0, fabs(mv)) || fabs(dpv) <= a.guard)) { status = ST_NEED_EXACT; break; }
+            if (a.cguard > 0 && fabs(dpv) <= a.cguard && !(k == 0 && blk == 0 && a.exact_once)) { status = ST_NEED_EXACT; break; }   // (BTArgs::cguard)
             if (mv <= 0) {
                 // ---- replaceBland (simplex.go:347-383): candidates in position order with r_i <= -1e-14 after the
                 // 1e-13 rounding of :252-256; the mat.Cond guard of :377 is replaced by |d| >= 1e-13

@@ -462,6 +462,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             const double mv = w.m;
             if (mv == inf || w.i >= (unsigned int)a.m) { status = ST_UNBOUNDED; break; }   // simplex.go:328-330
             if (a.guard > 0 && (mv <= a.guard || fabs(dpv) <= a.guard) && !(k == 0 && blk == 0 && a.exact_once)) { status = ST_NEED_EXACT; break; }   // degenerate (or nearly): decided on a fresh x_B
+            if (a.cguard > 0 && fabs(dpv) <= a.cguard && !(k == 0 && blk == 0 && a.exact_once)) { status = ST_NEED_EXACT; break; }   // (BTArgs::cguard)
             if (mv <= 0) {
                 // replaceBland (simplex.go:347-383), as in k_bt_inner2: candidates in position order
                 bland = true;

@@ -159,6 +159,11 @@ struct BTArgs {
     // are decided by it.  guard > 0: a block stops (ST_NEED_EXACT) in front of a pivot whose winning ratio is <= guard; the host
     // uploads the gonum-order x_B of the current basis and restarts with exact_once = 1 (the first pivot then decides as is).
     double guard;
+    // Pivot-element floor at ANY size (knob cond_guard): gonum leaves its loop with mat.Condition when the condition estimate of a solve
+    // exceeds 1e16 (mat/lu.go:321) — on the tableau a basis on its way there shows as a Dantzig pivot element of rounding-noise size.
+    // cguard > 0: a block stops (ST_NEED_EXACT) in front of a pivot with |d_p| <= cguard; the host measures the exact condition numbers
+    // and repeats the reference's iteration on fresh solves (Engine::exact_step); a batched relaxation goes to the worker path
+    double cguard;
     int32_t exact_once, poll_delay;   // (poll_delay: units of 64 cycles a wave waits between its post and its first poll, knob "poll_delay")
 };
 

@@ -246,6 +246,7 @@ BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int
     // there, and a pivot on their 1e-12 drift walks into a singular basis)
     // (and for inputs whose entries span more than nine decades: their updated tableau loses digits, the exact steps check and rebuild it)
     a.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && (P.m <= 256 || gen_start_ || badly_scaled_))) ? 1e-9 : 0.0;
+    a.cguard = (cond_guard_ && !gen_start_ && P.m > 64) ? 1e-9 : 0.0;   // (<= 64 rows: the per-pivot replay of Engine::solve; general starts: the guard above is on)
     if (a.tiled && !bt_old_) {
         const BtGroupCfg gc = bt_group_cfg(P.m, ldt_, groups_knob(P));
         a.groups = gc.groups; a.group_ri = gc.ri; a.group_nt = gc.nt; a.xbuf = w.xbuf;
@@ -289,7 +290,7 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
     // gonum's guards on the solves of this iteration (mat/lu.go:321: cond > 1e16 -> mat.Condition out of the duals' solve,
     // simplex.go:236-239; lp.ErrLinSolve out of computeMove, :316-318): the tableau of a slack-basis start holds B^-1, so the exact
     // kappa_1 / kappa_inf of the current basis cost three small launches (cond_check) — every exact step measures them
-    if (cond_guard_ && phase == 2 && !gen_start_ && m > 64) {
+    if (cond_guard_ && !gen_start_ && m > 64) {   // (Phase I too: the artificial column is a column of the basis like any other)
         double k1 = 0, kinf = 0;
         int rc0 = cond_check(P, nn, &k1, &kinf);
         if (rc0 != GOMILP_OK) return -rc0;
