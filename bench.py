@@ -710,6 +710,26 @@ def main() -> int:
                                               "sample": "root + the first %d nodes of the same tree in the reference's FIFO order, one oracle solve after the other "
                                                         "(LU panels threaded over the host cores), %.1f s wall" % (len(osolved) - 1, tc),
                                               "gpu_nodes_identical_on_sample": bool(same)}
+    # ---- degenerate trees: the 240 integer-data MILPs of the parity suite (duplicate rows, stacked branch rows: every node sits on a
+    # degenerate vertex, decided on fresh gonum-order solves — Engine::exact_step): what the exact steps cost
+    if args.milp_nodes > 0:
+        from gomilp_amd import bnb
+        poold = lp.FrontierPool(device=local_rank, workers=args.workers)
+        fam = [synth.degenerate_integer_milp(sd) for sd in range(240)]
+        for cd, Gd, hd, intd in fam[:8]:
+            bnb.solve_milp(cd, None, None, Gd, hd, intd, max_nodes=15, pool=poold)   # warm-up
+        td0 = time.perf_counter()
+        nrel = 0
+        for cd, Gd, hd, intd in fam:
+            rd = bnb.solve_milp(cd, None, None, Gd, hd, intd, max_nodes=15, pool=poold)
+            nrel += rd.relaxations
+        td = time.perf_counter() - td0
+        poold.close()
+        out["degenerate_trees"] = {"workload": "240 integer-data MILPs (2-5 rows + branch rows, duplicate rows; gomilp_amd/synth.py degenerate_integer_milp), FIFO B&B, 15 nodes each",
+                                   "trees": len(fam), "relaxations": int(nrel), "seconds": td, "relaxations_per_s": nrel / td,
+                                   "note": "bases of up to 64 rows: every relaxation on a worker's single-relaxation engine with the pivot-by-pivot condition replay and the "
+                                           "exact-degenerate steps (three gonum-order device LUs per degenerate pivot); tests/test_gpu_golden.py checks every node of these trees "
+                                           "bit for bit against the oracle tree"}
     emit(out)
     prob.free()
     ctx.close()

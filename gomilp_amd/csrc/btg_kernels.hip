@@ -768,7 +768,7 @@ void launch_bt_loop(const BTArgs &a, int ncu, hipStream_t s, hipEvent_t e0, hipE
     }
     if (G == 16 && a.group_nt == 128) { hipExtLaunchKernelGGL((k_bt_loop<16, 128, 1, false, 8>), dim3(std::max(grid, 136u)), dim3(128), 0, s, e0, e1, 0, a); return; }   // up to 2048 rows: 16 x 128 threads, blocks of 8
     if (G == 16 && a.kmax == 12) { hipExtLaunchKernelGGL((k_bt_loop<16, 256, 1, false, 12>), dim3(std::max(grid, 136u)), dim3(256), 0, s, e0, e1, 0, a); return; }   // knob loop_k = 12
-    if (G == 16) { hipExtLaunchKernelGGL((k_bt_loop<16, 256, 1, false, 16>), dim3(std::max(grid, 136u)), dim3(256), 0, s, e0, e1, 0, a); return; }   // 4096 rows: 16 x 256 threads, blocks of 16
+    if (G == 16) { hipExtLaunchKernelGGL((k_bt_loop<16, 256, 1, false, 16>), dim3(std::max(grid, 128u)), dim3(256), 0, s, e0, e1, 0, a); return; }   // 4096 rows: 16 x 256 threads, blocks of 16 (pivot blocks: x + 8 j, j < 16, x <= 6)
     if (G == 2) hipExtLaunchKernelGGL((k_bt_loop<2, 512, 1>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);
     else if (G == 4) hipExtLaunchKernelGGL((k_bt_loop<4, 512, 1>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);
     else if (a.kmax == 16) hipExtLaunchKernelGGL((k_bt_loop<8, 512, 1, false, 16>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);   // blocks of 16 pivots

@@ -219,6 +219,9 @@ void Engine::bt_plan(const Problem &P, int *K, bool *tiled, bool *lag) const {
         if (lag && bt_lag_ && block_k_ == 0 && max_pivots_ == 0 && (!bt_stamps_ || gc.nt == 256) && bt_loop_supported(gc)) {
             *lag = true;
             *K = (gc.nt == 512 && gc.groups == 8 && loop_k_ != 8) ? (loop_k_ == 12 && loop_g_ != 8 ? 12 : 16) : 8;
+            // knob loop_k = 16 on the 1025..2048-row class: blocks of 16 on 16 x 256 threads (the 4096-row instance) — half the update
+            // traffic per pivot, which is what several such loop kernels side by side run out of (gomilp_frontier_solve_roots, large_loop)
+            if (gc.nt == 256 && gc.groups == 8 && loop_k_ == 16 && loop_g_ != 8 && !bt_stamps_) *K = 16;
         }
         return;
     }
@@ -429,7 +432,8 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
         ~LoopSlot() { if (slot >= 0) Engine::loop_release(dev, weight, slot); }
     };
     // (weight: the 128-thread shape shares the device with up to three others, every other shape runs alone — engine.cpp)
-    const bool small_loop = lag && K == 8 && loop_g_ != 8 && !bt_stamps_ && bt_group_cfg(P.m, ldt_, groups_knob(P)).nt == 256;
+    // (the 2048-row class in blocks of 16 — knob loop_k — shares the device too: 256-thread workgroups, two per CU, grid of half the CUs)
+    const bool small_loop = lag && (K == 8 || K == 16) && loop_g_ != 8 && !bt_stamps_ && bt_group_cfg(P.m, ldt_, groups_knob(P)).nt == 256;
     LoopSlot loop_slot(device_, small_loop ? 1 : 4, lag);
     const int loop_xcd = (small_loop && loop_slot.slot > 0) ? 2 * loop_slot.slot : 0;
     bt_layout(P, tiled_plan);
@@ -482,6 +486,8 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
             // 2049..4096 rows: 16 pivot workgroups of 256 threads (one wave per SIMD: the per-pivot chain of the 2048-row shape)
             // instead of 8 of 512 — inside the loop kernel only; set-up pivots and the batched schedule keep bt_group_cfg's shape
             if (ai.groups == 8 && ai.group_nt == 512 && ai.group_ri == 1 && loop_g_ != 8 && (K == 16 || K == 12)) { ai.groups = 16; ai.group_nt = 256; }
+            const bool k16_small = ai.groups == 8 && ai.group_nt == 256 && ai.group_ri == 1 && loop_g_ != 8 && K == 16;
+            if (k16_small) ai.groups = 16;   // (16 x 256 threads, blocks of 16: the instance of the 4096-row class)
             // 1025..2048 rows: 16 x 128 threads (two waves per workgroup: a cheaper workgroup stage in front of every exchange; measured
             // 11.47 ms against 11.85 ms per solve of the metric LP for 8 x 256)
             if (ai.groups == 8 && ai.group_nt == 256 && ai.group_ri == 1 && loop_g_ != 8 && K == 8 && !bt_stamps_) {
@@ -493,7 +499,7 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
             // stream a block at the full HBM rate in 51 of its 84 us and the pivot workgroups' dependent tableau reads queue behind
             // them; 112 spread the same bytes over ~60 us (measured per solve of C4: 240: 50.3 ms, 170: 49.0, 140: 47.8, 110: 47.0, 90: 48.9,
             // 70: 57.9 — update-bound from there)
-            if (ai.upd_cap == 0 && ai.groups == 16 && ai.group_nt == 256) ai.upd_cap = 112;
+            if (ai.upd_cap == 0 && ai.groups == 16 && ai.group_nt == 256 && !k16_small) ai.upd_cap = 112;
             ai.exact_once = exact_pending ? 1 : 0; exact_pending = false;
             ai.forced_q = forced_q_pending; ai.forced_p = forced_p_pending; forced_q_pending = forced_p_pending = -1;
             hipEvent_t e0 = nullptr, e1 = nullptr;

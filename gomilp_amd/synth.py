@@ -76,3 +76,21 @@ def frontier_children(root_x, integrality, nvars: int = 8):
                 cons.append((j, 1, fl))
         children.append(cons)
     return children
+
+
+def degenerate_integer_milp(seed):
+    """Small integer-data MILP in inequality form (x = 0 feasible, every column bounded): duplicate rows, integer right-hand
+    sides and the reference's habit of branching on the same variable again and again stack identical rows — vertices
+    where several basic variables sit at level zero, the place where the rounding noise of the reference's fresh x_B decides."""
+    rng = np.random.default_rng(7000 + seed)
+    nv, m = int(rng.integers(3, 8)), int(rng.integers(2, 6))
+    G = rng.integers(0, 4, (m, nv)).astype(float)
+    G[int(rng.integers(0, m))] = np.maximum(G[int(rng.integers(0, m))], 1.0)
+    G[0] = np.maximum(G[0], 1.0)                      # every variable bounded by row 0
+    h = rng.integers(1, 9, m).astype(float)
+    if m >= 3 and rng.random() < 0.6:
+        G[m - 1], h[m - 1] = G[1], h[1]                # a duplicate row
+    c = -rng.integers(0, 5, nv).astype(float)
+    integ = [bool(v) for v in rng.integers(0, 2, nv)]
+    integ[int(rng.integers(0, nv))] = True
+    return c, G, h, integ

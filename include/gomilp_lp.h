@@ -114,10 +114,14 @@ int gomilp_ctx_device(const gomilp_ctx *ctx);
  * single-workgroup block kernel), "bt_groups" (-1: single-workgroup block kernels only, 0: by shape, 2 / 4 / 8: that many
  * workgroups), "bt_old", "bt_stamps", "sample_events"; of the persistent loop kernel: "bt_lag" (0: the launch pairs of round 2),
  * "loop_chunk" (pivots per launch), "loop_g" (8 / 16 pivot workgroups), "loop_k" (8 / 12 / 16 pivots per block), "loop_upd"
- * (update workgroups that take part), "loop_grid", "poll_delay".  Knobs that DO change what is decided, and how faithfully:
+ * (update workgroups that take part), "loop_grid", "poll_delay"; of the bit-exact final solve: "lu_blocked" (3 default: compressed rounds
+ * with the slot panel, 2: with the sorted register panel, 1: blocked panels, 0: one launch per column — all bit-identical).  The
+ * diagnostic flavour of the library (libgomilp_hip_debug.so, GOMILP_DEBUG_BUILD=1) adds "bt_fault" and the GOMILP_DEBUG_* / GOMILP_LUC_*
+ * environment hooks; the product library has none of them.  Knobs that DO change what is decided, and how faithfully:
  * "exact_degenerate" (0 never, 1 default: bases of up to 256 rows, non-slack starts and badly scaled inputs, 2 always — degenerate,
  * tied and tiny pivots are decided on fresh gonum-order solves), "cond_guard" (1 default: gonum's
- * mat.Condition guard, from a pivot-by-pivot replay up to 64 rows and from the tableau's exact condition numbers beyond).
+ * mat.Condition guard, from a pivot-by-pivot replay up to 64 rows and from the tableau's exact condition numbers beyond — at every exact
+ * step (Phase I too), on the final basis, and in front of any pivot whose element is of rounding-noise size).
  * Returns GOMILP_OK or GOMILP_ERR_BAD_SHAPE. */
 int gomilp_ctx_set(gomilp_ctx *ctx, const char *key, int64_t value);
 
@@ -176,7 +180,10 @@ typedef struct gomilp_frontier_stats {
 
 gomilp_pool *gomilp_pool_create(int device, int workers, int *status);
 void gomilp_pool_destroy(gomilp_pool *pool);
-/* knobs: "split_large" (default 1: a wave of >= 4 relaxations beyond 1024 rows runs as two interleaved schedules), "sample_batch" (1: time every batched block launch with HIP events), "batched" (default 1: the pivot loops of a wave run device-batched — grid.x = relaxation, O(1) host round trips per
+/* knobs: "split_phase" (default 1: in a wave of >= 16 the relaxations that start feasible — the long Phase-II chains — and those that need
+ * Phase I run as two schedules side by side, the long chains on the higher-priority stream), "batch_loop" (default 1: whenever the active
+ * relaxations of a schedule fit one launch their block steps run in the persistent kernel k_b_loop — per relaxation one pivot workgroup and
+ * seven update workgroups, the rank-4 update of block t beside block t + 1), "split_large" (default 1: a wave of >= 4 relaxations beyond 1024 rows runs as two interleaved schedules), "sample_batch" (1: time every batched block launch with HIP events), "batched" (default 1: the pivot loops of a wave run device-batched — grid.x = relaxation, O(1) host round trips per
  * superstep for the whole wave; 0: one host thread + stream per relaxation); any gomilp_ctx_set key is forwarded to the
  * worker contexts. */
 int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value);

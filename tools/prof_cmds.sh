@@ -1,6 +1,6 @@
 # rocprofv3 evidence of a round (run on the GPU box through gpurun: bash tools/prof_cmds.sh <tag>)
 set -x
-TAG=${1:-r2}
+TAG=${1:-r4}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 R=$GRAFT_REPO_ROOT
