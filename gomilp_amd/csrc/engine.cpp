@@ -78,7 +78,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "max_pivots") max_pivots_ = v < 0 ? 0 : v;
     else if (key == "sample_events") sample_events_ = v < 0 ? 0 : v;
     else if (key == "fused") fused_ = v ? 1 : 0;
-    else if (key == "lu_blocked") lu_blocked_ = v < 0 ? 0 : (v > 3 ? 3 : v);  // 0 per column, 1 blocked panels, 2 compressed rounds (sorted register panel), 3 compressed rounds (slot panel)
+    else if (key == "lu_blocked") lu_blocked_ = v < 0 ? 0 : (v > 2 ? 3 : v);  // 0 per column, 1 blocked panels, 2 / 3 compressed rounds (slot panel; the sorted register panel of rounds 1-3 is retired)
     else if (key == "tableau") tableau_ = v ? 1 : 0;
     else if (key == "blocked") blocked_ = v ? 1 : 0;
     else if (key == "bt_nt") { if (v != 0 && v != 256 && v != 512 && v != 1024) return GOMILP_ERR_BAD_SHAPE; bt_nt_ = v; }
@@ -786,7 +786,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     const bool blocked = compressed || (lu_blocked_ && lu_blocked_supported(m));
     a.dense_flag = blocked ? w.denseflag : nullptr;
     a.ctl = w.luctl; a.Lp = w.luLp; a.Up = w.luUp;
-    a.slots = lu_blocked_ >= 3 ? 1 : 0; a.pad = 0;
+    a.slots = 1; a.pad = 0;
     w.st_host->lu_singular = 0;
     sync_state_to_device();
     lu_rounds_ = 0;

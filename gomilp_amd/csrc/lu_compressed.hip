@@ -8,12 +8,13 @@
 // row yet makes its elimination step pure bookkeeping (pivot exactly 1, multipliers exactly 0, one row interchange);
 // only the other steps ("dense" steps) do arithmetic.  The blocked schedule of lu_kernels.hip still spends one
 // register column and two workgroup barriers on every step.  Here a ROUND is
-//   k_luc_panel   ONE workgroup: registers hold the next NB columns that are KNOWN to be dense (non-unit, or unit with
-//                 a used row), wherever they are; between two of them a single thread replays the run of bookkeeping
-//                 steps on LDS-resident index maps (lpos / rowat / active).  A unit column that BECOMES dense inside
-//                 the round (a dense step took its row: the column is -l of that step) is inserted into the register
-//                 list at its sorted position; when the list is full its last column is dropped un-eliminated (W
-//                 still holds its original; LUCtl records for which retired rows the panel already wrote it).
+//   k_luc_panel_slots
+//                 ONE workgroup: registers hold the next NB columns that are KNOWN to be dense (non-unit, or unit with
+//                 a used row), wherever they are, each in a fixed slot; between two of them wave 0 replays the run of
+//                 bookkeeping steps on LDS-resident index maps (lpos / rowat / active).  A unit column that BECOMES dense
+//                 inside the round (a dense step took its row: the column is -l of that step) takes the slot the step's own
+//                 column leaves.  (Rounds 1-3 kept the columns sorted in registers and shifted them every step: retired in
+//                 round 4, see the comment at the kernel.)
 //   k_luc_usolve  finishes the dense pivot rows right of the round (columns >= k1),
 //   k_luc_trail   applies the round's dense steps to every other row right of the round: all of them for rows that
 //                 are still active, the steps before its own for a row retired by a bookkeeping step of the round.
@@ -31,286 +32,8 @@
 
 namespace gomilp {
 
-template <int NB>
-struct CPanelRow {
-    typedef double vec __attribute__((ext_vector_type(NB)));
-    vec v;
-    int R, lp;
-    bool act;
-};
-
-// Storage of this schedule: W is COLUMN-major (Wc[k*ldw + R] = element (R, k)): the panel's column loads and its
-// per-step multiplier stores are contiguous over the threads' rows (row-major W made both m-line scatters through
-// one CU), and the basis gather is a plain copy of rows of At.  The round's multipliers and finished U rows also
-// go to two compact panels, Lp[s][R] = -l and Up[s][j] = u, which is all the trailing update reads.
-template <int T, int RPT, int NB>
-__global__ __launch_bounds__(T) void k_luc_panel(LUArgs a, int32_t *__restrict__ pivrow) {
-    constexpr int NW = T / 64;
-    constexpr int MAXM = T * RPT;
-    typedef unsigned short idx_t;            // m <= 4096
-    constexpr idx_t NONE = 0xFFFF;
-    __shared__ idx_t s_lpos[MAXM];    // logical position of physical row R
-    __shared__ idx_t s_rowat[MAXM];   // physical row at logical position
-    __shared__ idx_t s_unit[MAXM];    // unit_row per column (NONE: not a unit column)
-    __shared__ idx_t s_ucol[MAXM];    // inverse: the unit column of a row (NONE: none)
-    __shared__ unsigned char s_active[MAXM];
-    __shared__ double prow[2][NB];
-    __shared__ double s_rinv[2];      // 1 / pivot of the running step, computed once by the pivot row's owner
-    __shared__ double redM[2][16];
-    __shared__ unsigned int redL[2][16];
-    __shared__ int s_cols[2][NB];     // register columns, ascending; double buffered across insertions
-    __shared__ int s_in[2][NB];       // thread 0 only: dense step after which a column joined the list (-1: round start)
-    __shared__ int s_ncols, s_stop, s_limit, s_ins;
-    LUCtl *ctl = a.ctl;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int m = a.m;
-    const size_t ldw = (size_t)a.ldw;
-    const int k0 = ctl->k_next;
-    if (k0 >= m) {
-        if (tid == 0) ctl->nsteps = 0;
-        return;
-    }
-    for (int R = tid; R < MAXM; R += T) {
-        const bool in = R < m;
-        s_lpos[R] = (idx_t)(in ? a.lpos[R] : R);
-        s_active[R] = (in && a.rowstep[R] < 0) ? 1 : 0;
-        const int ur = (in && a.unit_row) ? a.unit_row[R] : -1;
-        s_unit[R] = ur < 0 ? NONE : (idx_t)ur;
-        s_ucol[R] = NONE;
-    }
-    __syncthreads();
-    for (int R = tid; R < m; R += T) {
-        s_rowat[s_lpos[R]] = (idx_t)R;
-        if (s_unit[R] != NONE) s_ucol[s_unit[R]] = (idx_t)R;   // column R is the unit vector of row s_unit[R]
-    }
-    if (w == 0) {
-        // the first NB columns >= k0 that are dense for sure
-        int n = 0;
-        for (int base = k0; base < m && n < NB; base += 64) {
-            const int k = base + lane;
-            bool dense = false;
-            if (k < m) {
-                const idx_t ur = s_unit[k];
-                dense = ur == NONE || !s_active[ur];
-            }
-            const unsigned long long mask = __ballot(dense);
-            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-            if (dense && n + rank < NB) s_cols[0][n + rank] = k;
-            n += __popcll(mask);
-        }
-        if (lane == 0) s_ncols = n < NB ? n : NB;
-        if (lane < NB) s_in[0][lane] = -1;
-    }
-    __syncthreads();
-    int ncols = s_ncols;
-    int lsel = 0;   // which copy of s_cols is current (uniform)
-    CPanelRow<NB> rows[RPT];
-#define GOMILP_FOR_ROWS(F)                              \
-    do {                                                \
-        _Pragma("unroll") for (int rr_ = 0; rr_ < RPT; rr_++) F(rows[rr_], rr_); \
-    } while (0)
-    auto load_row = [&](CPanelRow<NB> &row, int r) {
-        row.R = tid + r * T;
-        row.act = (row.R < m) && s_active[row.R < m ? row.R : 0];
-        row.lp = 0;
-        const double *src = a.W + (row.act ? row.R : 0);
-#pragma unroll
-        for (int c = 0; c < NB; c++) row.v[c] = (row.act && c < ncols) ? src[(size_t)s_cols[0][c < ncols ? c : 0] * ldw] : 0.0;
-    };
-    GOMILP_FOR_ROWS(load_row);
-    __syncthreads();   // every thread has taken its rows' `act` from s_active before thread 0's first run clears entries
-    int kcur = k0, s = 0, k1 = m, ndrop = 0;
-#pragma unroll 1
-    for (;;) {
-        if (w == 0) {
-            // run of bookkeeping steps [kcur, limit): Idamax finds the 1 in row ur, dlaswp exchanges logical
-            // positions k and lpos[ur]; nothing else happens (the step's multipliers are exactly 0).  Wave 0 classifies
-            // 64 columns at a time (a bookkeeping step only retires its own unit row, so the test of one column does
-            // not depend on the steps before it); lane 0 then replays the interchanges, which do depend on each other,
-            // with the unit rows handed over by v_readlane instead of dependent LDS reads.
-            const int limit = (s < ncols) ? s_cols[lsel][s] : m;
-            int k = kcur;
-            for (;;) {
-                const int kk = k + lane;
-                const idx_t ur = kk < limit ? s_unit[kk] : NONE;
-                const bool triv = ur != NONE && s_active[ur];
-                const unsigned long long nt = __ballot(!triv);
-                const int cnt = nt ? (int)__builtin_ctzll(nt) : 64;
-                for (int j = 0; j < cnt; j++) {
-                    const int urj = __builtin_amdgcn_readlane((int)ur, j);
-                    if (lane == 0) {
-                        const idx_t jp = s_lpos[urj], Q = s_rowat[k + j];
-                        s_lpos[Q] = jp; s_rowat[jp] = Q;
-                        s_lpos[urj] = (idx_t)(k + j); s_rowat[k + j] = (idx_t)urj;
-                        s_active[urj] = 0;
-                    }
-                }
-                k += cnt;
-                if (cnt < 64) break;   // the limit or a step that needs arithmetic
-            }
-            if (lane == 0) { s_stop = k; s_limit = limit; }
-        }
-        __syncthreads();
-        const int kstop = s_stop, limit = s_limit;
-        const int *cols = s_cols[lsel];
-        // rows retired by the run become U rows: their entries in the register columns are final
-        auto retire = [&](CPanelRow<NB> &row, int) {
-            if (!row.act || s_active[row.R]) return;
-            const int kt = s_lpos[row.R];
-            a.rowstep[row.R] = kt; pivrow[kt] = row.R;
-            double *dst = a.W + row.R;
-#pragma unroll
-            for (int c = 0; c < NB; c++)
-                if (s + c < ncols) dst[(size_t)cols[s + c] * ldw] = row.v[c];
-            row.act = false;
-        };
-        GOMILP_FOR_ROWS(retire);
-        if (kstop < limit || s >= ncols) { k1 = kstop; break; }
-        const int k = limit;
-        // ---- dense step k.  idamax without (key, index) candidates: the minimum of -|a_ik| by v_min_f64 over DPP row
-        // shifts, then the smallest logical position among the rows that attain it (u32 min): first maximum in
-        // LAPACK row order
-        double xm = __builtin_inf();
-        auto cand = [&](CPanelRow<NB> &row, int) {
-            if (!row.act) return;
-            row.lp = s_lpos[row.R];
-            xm = vmin_f64(xm, -fabs(row.v[0]));
-        };
-        GOMILP_FOR_ROWS(cand);
-        const double wm = wave_min_f64(xm);
-        unsigned int lk = 0xFFFFFFFFu;
-        auto cand2 = [&](CPanelRow<NB> &row, int) {
-            if (row.act && -fabs(row.v[0]) == wm) lk = min(lk, (unsigned int)row.lp);
-        };
-        GOMILP_FOR_ROWS(cand2);
-        lk = row_min_u32(lk);
-        lk = min(min((unsigned int)__builtin_amdgcn_readlane((int)lk, 15), (unsigned int)__builtin_amdgcn_readlane((int)lk, 31)),
-                 min((unsigned int)__builtin_amdgcn_readlane((int)lk, 47), (unsigned int)__builtin_amdgcn_readlane((int)lk, 63)));
-        double *rm = redM[s & 1];
-        unsigned int *rl = redL[s & 1];
-        if (lane == 0) { rm[w] = wm; rl[w] = lk; }
-        __syncthreads();
-        const double bx = lane < NW ? rm[lane] : __builtin_inf();
-        const double bm = readlane_f64(row_min_f64(bx), 15);
-        const unsigned int bk = (lane < NW && bx == bm) ? rl[lane] : 0xFFFFFFFFu;
-        const int jp = (int)(unsigned int)__builtin_amdgcn_readlane((int)row_min_u32(bk), 15);
-        double *pr = prow[s & 1];
-        auto publish = [&](CPanelRow<NB> &row, int) {
-            if (!row.act || row.lp != jp) return;
-            const int P = row.R;
-#pragma unroll
-            for (int cc = 0; cc < NB; cc++) pr[cc] = row.v[cc];
-            s_rinv[s & 1] = 1.0 / row.v[0];   // dgetf2.go:54-56 scales by the reciprocal
-            row.act = false;
-            row.lp = -2 - P;   // marks the owner: its U entries go to W after the barrier, off everybody's critical path
-            s_active[P] = 0;
-            a.rowstep[P] = k; pivrow[k] = P;
-            if (a.dense_flag) a.dense_flag[k] = 1;
-            ctl->steps[s] = k; ctl->prow[s] = P;
-            const idx_t Q = s_rowat[k];   // dlaswp.go: the row at logical k moves to jp
-            s_lpos[Q] = (idx_t)jp; s_rowat[jp] = Q;
-            s_lpos[P] = (idx_t)k; s_rowat[k] = (idx_t)P;
-            // taking row P makes the unit column of P (if it is still to come) dense from this step on
-            const idx_t uc = s_ucol[P];
-            s_ins = (uc != NONE && (int)uc > k) ? (int)uc : -1;
-        };
-        GOMILP_FOR_ROWS(publish);
-        __syncthreads();
-        auto publish_w = [&](CPanelRow<NB> &row, int) {
-            if (row.act || row.lp != -2 - row.R) return;
-            row.lp = 0;
-            double *dst = a.W + row.R;
-#pragma unroll
-            for (int cc = 0; cc < NB; cc++)
-                if (s + cc < ncols) dst[(size_t)cols[s + cc] * ldw] = row.v[cc];
-        };
-        GOMILP_FOR_ROWS(publish_w);
-        const double piv = pr[0];
-        const bool singular = (piv == 0);  // dgetf2.go:48-49: no scaling, the rank-1 update is a no-op
-        if (singular && tid == 0) a.st->lu_singular = 1;
-        const double rinv = s_rinv[s & 1];
-        // ---- the column that just became dense joins the register list (sorted position `pos` behind the columns
-        // still to come) instead of ending the round in front of it; with a full list the last column is dropped
-        // (W still holds its original: the trailing kernels redo it, except for the rows retired while it was listed)
-        const int k2 = s_ins;
-        const int rest = ncols - (s + 1);   // columns behind the current one
-        bool doins = false;
-        int pos = 0;
-        if (k2 >= 0) {
-            // one LDS read per lane + a ballot instead of a serial scan of the list
-            const int cv = (lane < rest) ? cols[s + 1 + lane] : 0x7fffffff;   // NB <= 32 < 64 lanes
-            const unsigned long long below = __ballot(cv < k2);
-            const int lastv = rest > 0 ? cols[ncols - 1] : -1;
-            doins = (ncols < NB) || (k2 < lastv);
-            pos = doins ? __popcll(below) : 0;
-        }
-        const bool dropping = doins && ncols == NB;
-        double *wcol = a.W + (size_t)k * ldw;      // column k of L\U
-        double *lcol = a.Lp + (size_t)s * ldw;     // compact panel: -l (0 for rows that are not active)
-        auto elim = [&](CPanelRow<NB> &row, int) {
-            if (!row.act) {
-                if (row.R < a.ldw) lcol[row.R] = 0.0;
-                return;
-            }
-            const double l = singular ? row.v[0] : __dmul_rn(row.v[0], rinv);
-            wcol[row.R] = l;
-            const double nl = -l;
-            lcol[row.R] = singular ? 0.0 : nl;
-            const bool skip = singular;   // Dger (dgetf2.go:60-66) does not skip zero multipliers
-            // only the columns still listed behind the current one carry data (uniform tests: scalar branches)
-            if (!doins) {   // plain shift (uniform branch)
-#pragma unroll
-                for (int cc = 1; cc < NB; cc++) row.v[cc - 1] = (skip || cc > rest) ? row.v[cc] : __dadd_rn(__dmul_rn(nl, pr[cc]), row.v[cc]);
-                row.v[NB - 1] = 0.0;
-                return;
-            }
-            typename CPanelRow<NB>::vec old = row.v;   // old[c], c >= 1: column c after this step's update
-#pragma unroll
-            for (int cc = 1; cc < NB; cc++) old[cc] = (skip || cc > rest) ? row.v[cc] : __dadd_rn(__dmul_rn(nl, pr[cc]), row.v[cc]);
-            // e_P column: 0 + (-l)*1 for the active rows
-            const double vnew = skip ? 0.0 : __dadd_rn(__dmul_rn(nl, 1.0), 0.0);
-#pragma unroll
-            for (int cc = 0; cc < NB; cc++) {
-                const double shifted = cc + 1 < NB ? old[cc + 1 < NB ? cc + 1 : 0] : 0.0;
-                const double stay = cc >= 1 ? old[cc >= 1 ? cc : 1] : 0.0;
-                row.v[cc] = (cc > pos) ? stay : ((cc == pos) ? vnew : shifted);
-            }
-        };
-        GOMILP_FOR_ROWS(elim);
-        if (doins) {
-            if (tid == 0) {
-                // new list in the other copy: entries up to and including s unchanged, then the rest with k2 at s+1+pos
-                int *nc = s_cols[lsel ^ 1], *ni = s_in[lsel ^ 1];
-                const int *oi = s_in[lsel];
-                for (int c = 0; c <= s; c++) { nc[c] = cols[c]; ni[c] = oi[c]; }
-                int src = s + 1;
-                for (int c = s + 1; c < NB; c++) {
-                    if (c == s + 1 + pos) { nc[c] = k2; ni[c] = k; }
-                    else if (src < ncols) { nc[c] = cols[src]; ni[c] = oi[src]; src++; }
-                }
-                if (dropping) {
-                    ctl->dropcol[ndrop] = cols[ncols - 1];
-                    ctl->dropin[ndrop] = oi[ncols - 1];
-                    ctl->dropout[ndrop] = k + 1;
-                }
-            }
-            if (dropping) ndrop++;
-            else ncols++;
-            lsel ^= 1;
-        }
-        s++;
-        kcur = k + 1;
-    }
-    for (int R = tid; R < m; R += T) a.lpos[R] = s_lpos[R];
-    if (tid == 0) {
-        ctl->k0 = k0; ctl->k1 = k1; ctl->k_next = k1; ctl->nsteps = s; ctl->ndrop = ndrop;
-        ctl->rounds += 1;
-    }
-#undef GOMILP_FOR_ROWS
-}
-
 // ---- slot form of the panel (round 4; default) -------------------------------------------------------------------------------
-// Same arithmetic, same step order, another register discipline.  k_luc_panel above keeps its NB columns SORTED in registers: every
+// Same arithmetic, same step order as the panel of rounds 1-3, another register discipline.  That panel kept its NB columns SORTED in registers: every
 // dense step shifts all of them by one (the update folded into the shift behind 64-bit selects), and a column that becomes dense
 // inside the round is inserted at its sorted position through a select chain over all NB registers — ~390 VALU instructions per
 // wave and step, 4 waves per SIMD: the panel was issue-bound on ONE CU (4.7 us per dense step at 2048 rows, 20 % of the metric
@@ -879,15 +602,6 @@ __global__ __launch_bounds__(256) void k_luc_solve_rows(LUArgs a, const int32_t 
     x[i] = __dmul_rn(acc, tinv);
 }
 
-template <int T, int RPT, int NB>
-static void luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t s) {
-    const int m = a.m;
-    for (int r = 0; r < nrounds; r++) {
-        hipLaunchKernelGGL((k_luc_panel<T, RPT, NB>), dim3(1), dim3(T), 0, s, a, pivrow);
-        hipLaunchKernelGGL((k_luc_usolve<NB>), dim3((m + 63) / 64), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((k_luc_trail<NB>), dim3((m + 63) / 64, (m + 63) / 64), dim3(256), 0, s, a);
-    }
-}
 // slot form: up to kLucSlotSteps dense steps per round whatever the number of register slots
 constexpr int kLucSlotSteps = 32;
 template <int T, int RPT, int NB>
@@ -901,19 +615,8 @@ static void luc_rounds_slots(const LUArgs &a, int32_t *pivrow, int nrounds, hipS
 }
 
 bool lu_compressed_supported(int m) { return m <= 4096; }
-static int luc_cfg(int m) {
-#ifdef GOMILP_DEBUG
-    static const int forced = [] { const char *e = getenv("GOMILP_LUC_CFG"); return e ? atoi(e) : -1; }();   // developer knob (diagnostic flavour), read once
-    if (forced >= 0) return forced;
-#endif
-    return m <= 512 ? 0 : (m <= 1024 ? 1 : (m <= 2048 ? 2 : 3));
-}
 // dense steps a round can take (the host sizes its batches of rounds with it)
-int lu_compressed_nb(int m, bool slots) {
-    if (slots) return kLucSlotSteps;
-    const int c = luc_cfg(m);
-    return c <= 1 ? 32 : ((c == 2 || c == 4) ? 16 : 8);
-}
+int lu_compressed_nb(int, bool) { return kLucSlotSteps; }
 
 void launch_luc_init(const LUArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(k_luc_init, dim3((a.m + 255) / 256), dim3(256), 0, s, a);
@@ -937,7 +640,7 @@ void launch_luc_pack(const LUArgs &a, const int32_t *dlist, int nd, double *Wd, 
 // enqueue `nrounds` rounds; returns the number of kernel launches
 int launch_luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t s) {
     const int m = a.m;
-    if (a.slots) {
+    {
         // (threads x rows per thread x register slots: 128 VGPRs per thread at 1024 threads hold 2 x 16 or 4 x 8 columns)
 #ifdef GOMILP_DEBUG
         static const int forced = [] { const char *e = getenv("GOMILP_LUC_SLOTS"); return e ? atoi(e) : -1; }();   // developer knob (diagnostic flavour): panel shape
@@ -966,13 +669,7 @@ int launch_luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t
         else luc_rounds_slots<1024, 4, 8>(a, pivrow, nrounds, s);
         return 3 * nrounds;
     }
-    const int c = luc_cfg(m);
-    if (c == 0) luc_rounds<512, 1, 32>(a, pivrow, nrounds, s);
-    else if (c == 1) luc_rounds<1024, 1, 32>(a, pivrow, nrounds, s);
-    else if (c == 2) luc_rounds<1024, 2, 16>(a, pivrow, nrounds, s);
-    else if (c == 4) luc_rounds<512, 4, 16>(a, pivrow, nrounds, s);   // developer knob only (GOMILP_LUC_CFG=4): measured below
-    else luc_rounds<1024, 4, 8>(a, pivrow, nrounds, s);
-    return 3 * nrounds;
+    return 0;
 }
 
 #ifdef GOMILP_DEBUG
