@@ -1,6 +1,6 @@
 # developer tool: final-solve time by panel shape (diagnostic flavour of the library: GOMILP_LUC_SLOTS)
 set -x
-OUT=gpurun_out/r4c
+OUT=gpurun_out/r4n
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 export GOMILP_DEBUG_BUILD=1
@@ -10,5 +10,3 @@ for cfg in 20 21 22 23; do GOMILP_LUC_SLOTS=$cfg python tools/final_cfg.py C2 >>
 for cfg in 20 21 22 23; do echo "heavy cfg $cfg" >> $OUT/sweep.log; GOMILP_LUC_SLOTS=$cfg python tools/heavy_child.py 3 2>&1 | grep "sample 0" | tail -1 >> $OUT/sweep.log || exit 1; grep -q "Memory access fault" $OUT/sweep.log && exit 3; done
 for cfg in 99 30 31 32; do GOMILP_LUC_SLOTS=$cfg python tools/final_cfg.py C3 >> $OUT/sweep.log 2>&1 || exit 1; grep -q "Memory access fault" $OUT/sweep.log && exit 3; done
 cat $OUT/sweep.log
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_M -- python3 tools/final_cfg.py M > $OUT/prof_M.log 2>&1
