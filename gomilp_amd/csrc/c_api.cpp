@@ -447,11 +447,12 @@ static int frontier_solve_impl(gomilp_pool *pool, int64_t count, const int32_t *
             BatchEngine::Stats bs2;
             int rc2 = GOMILP_OK;
             pool->batch->set_low_priority(true);   // the wide group yields to the long chains
+            // (the long chains on the calling thread: they are the critical path of the wave and start without waiting for a thread to come up)
             std::thread t2([&] {
                 hipSetDevice(pool->device);
-                rc2 = run_group(*pool->batch2, grp_f, gf, false, &bs2);
+                rc = run_group(*pool->batch, grp_p, gp, false, &bsc);
             });
-            rc = run_group(*pool->batch, grp_p, gp, false, &bsc);
+            rc2 = run_group(*pool->batch2, grp_f, gf, false, &bs2);
             t2.join();
             pool->batch->set_low_priority(false);
             if (rc == GOMILP_OK) rc = rc2;
