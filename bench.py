@@ -255,9 +255,15 @@ def main() -> int:
         wave_dist = dist if comm is None else None   # rehearsal only: the table travels over gloo
         holder = {}
 
+        packed = {}
+
         def solve_shard(chs):
             ts = time.perf_counter()
-            r = pool.solve(chs)
+            pk = packed.get(id(chs))
+            if pk is None or pk[0] is not chs:   # the shard's flat description (koff / var / sign / rhs) is an INPUT of the wave: built once
+                pk = (chs, lp.pack_children(chs))
+                packed[id(chs)] = pk
+            r = pool.solve(pk[1])
             holder["stats"] = r.stats
             holder["solve_s"] = time.perf_counter() - ts
             return r.status, r.z, r.x, r.has_x

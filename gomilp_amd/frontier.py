@@ -10,12 +10,14 @@ like /root/reference/tree.go:228-230 uses it â€” after the solves, for pruning â
 """
 from __future__ import annotations
 
+import functools
 import math
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
 BIG_INDEX = 1 << 52   # == GOMILP_NO_INCUMBENT (include/gomilp_lp.h): exact in a double
+_SHARD_CACHE: dict = {}
 
 
 def _mix(i: int) -> int:
@@ -26,14 +28,19 @@ def _mix(i: int) -> int:
     return x ^ (x >> 13)
 
 
+@functools.lru_cache(maxsize=64)
+def _shard_indices_cached(count: int, rank: int, world: int) -> tuple:
+    order = sorted(range(count), key=lambda i: (_mix(i), i))
+    return tuple(sorted(order[rank::world]))
+
+
 def shard_indices(count: int, rank: int, world: int) -> List[int]:
     """Children owned by `rank`: round-robin over a fixed pseudo-random order of the wave.
 
     Plain `i % world` piles up the expensive children of a sign-pattern frontier (the few feasible ones are the
     patterns 0, 1, 2, 4, 8, ... â€” mostly multiples of the GPU count) on rank 0; a fixed shuffle spreads them.  The
     per-child results do not depend on the assignment, and incumbent ties are resolved by the child index."""
-    order = sorted(range(count), key=lambda i: (_mix(i), i))
-    return sorted(order[rank::world])
+    return list(_shard_indices_cached(count, rank, world))
 
 
 def is_all_integer(v: float) -> bool:
@@ -46,8 +53,13 @@ def is_all_integer(v: float) -> bool:
 
 
 def feasible_for_ip(integrality: Sequence[bool], x: Sequence[float]) -> bool:
-    """tree.go:276-288."""
-    return all(is_all_integer(float(x[j])) for j in range(len(integrality)) if integrality[j])
+    """tree.go:276-288 (vectorised: k == math.Trunc(k) for every integer-constrained coordinate; +-Inf passes, NaN does not)."""
+    mask = np.asarray(integrality, dtype=bool)
+    v = np.asarray(x, dtype=np.float64)[: len(mask)][mask]
+    if v.size == 0:
+        return True
+    with np.errstate(invalid="ignore"):
+        return bool(np.all((v == np.trunc(v)) | np.isinf(v)))
 
 
 def local_incumbent(indices: Sequence[int], status, z, x, has_x, integrality) -> Tuple[float, int]:
@@ -94,7 +106,14 @@ def solve_wave(solve_shard: Callable[[List[list]], tuple], children: List[list],
     `solve_shard(list_of_children)` returns (status, z, x, has_x) arrays for that list (FrontierPool.solve on
     the GPU box; a stub in the gloo tests)."""
     mine = shard_indices(len(children), rank, world)
-    status, z, x, has_x = solve_shard([children[i] for i in mine])
+    key = (id(children), len(children), rank, world)
+    shard = _SHARD_CACHE.get(key)
+    if shard is None or shard[0] is not children:   # the same frontier list, wave after wave (benches): its shard is built once
+        if len(_SHARD_CACHE) > 16:
+            _SHARD_CACHE.clear()
+        shard = (children, [children[i] for i in mine])
+        _SHARD_CACHE[key] = shard
+    status, z, x, has_x = solve_shard(shard[1])
     zl, il = local_incumbent(mine, status, z, x, has_x, integrality)
     zg, ig = allreduce_incumbent(zl, il, dist, device, comm)
     return {"indices": mine, "status": status, "z": z, "x": x, "has_x": has_x, "incumbent_z": zg, "incumbent_index": ig,

@@ -280,6 +280,31 @@ class FrontierResult:
     stats: dict
 
 
+class PackedChildren:
+    """Children of a wave in the flat form the C-ABI takes (koff / var / sign / rhs): built once per child list — a host that keeps its
+    frontier in this form (a Go host would) pays nothing per wave."""
+
+    def __init__(self, children):
+        count = len(children)
+        self.count = count
+        self.koff = np.zeros(count + 1, dtype=np.int64)
+        for i, ch in enumerate(children):
+            self.koff[i + 1] = self.koff[i] + len(ch)
+        tot = int(self.koff[-1])
+        self.var = np.zeros(max(tot, 1), dtype=np.int32)
+        self.sign = np.zeros(max(tot, 1), dtype=np.float64)
+        self.rhs = np.zeros(max(tot, 1), dtype=np.float64)
+        k = 0
+        for ch in children:
+            for (v, s, r) in ch:
+                self.var[k], self.sign[k], self.rhs[k] = v, s, r
+                k += 1
+
+
+def pack_children(children) -> PackedChildren:
+    return children if isinstance(children, PackedChildren) else PackedChildren(children)
+
+
 class FrontierPool:
     """`workers` engine contexts on one GPU solving independent child relaxations of one root concurrently
     (the solveWorker pool of /root/reference/tree.go:98-100,196-205 for one FIFO level)."""
@@ -334,19 +359,8 @@ class FrontierPool:
     def solve(self, children, tol: float = 0.0, roots=None) -> FrontierResult:
         """children: list of constraint lists [(var, sign, rhs), ...]; roots: per child the index of its root
         (default: all children of the set_root problem).  Independent LPs: children [] of different roots."""
-        count = len(children)
-        koff = np.zeros(count + 1, dtype=np.int64)
-        for i, ch in enumerate(children):
-            koff[i + 1] = koff[i] + len(ch)
-        tot = int(koff[-1])
-        var = np.zeros(max(tot, 1), dtype=np.int32)
-        sign = np.zeros(max(tot, 1), dtype=np.float64)
-        rhs = np.zeros(max(tot, 1), dtype=np.float64)
-        k = 0
-        for ch in children:
-            for (v, s, r) in ch:
-                var[k], sign[k], rhs[k] = v, s, r
-                k += 1
+        pk = pack_children(children)   # (a PackedChildren is taken as is)
+        count, koff, var, sign, rhs = pk.count, pk.koff, pk.var, pk.sign, pk.rhs
         z = np.full(count, math.nan)
         ldx = max(getattr(self, "_widths", [self.n0]))
         x = np.zeros((count, ldx))
