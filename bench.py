@@ -324,18 +324,21 @@ def main() -> int:
             "bland_steps_per_wave": int(tot[2] / steps), "host_fallbacks_per_wave": tot[3] / steps, "device_batched_per_wave": tot[4] / steps,
             "feasible_children": int(tot[5]), "incumbent_z": wave["incumbent_z"], "incumbent_child": wave["incumbent_index"],
             "collective": "gomilp_incumbent_allreduce: 1 x ncclAllReduce(min) of %d doubles per wave over %d rank(s) (RCCL, C-ABI)" % (2 * world, world),
-            "schedule": "device-batched: one launch per kernel type per block step for the whole shard (grid.x = relaxation), "
-                        "%d block steps and %.1f host round trips per wave on rank 0" % (acc["blocks"] // max(steps, 1), holder["stats"]["supersteps"]),
-            "kernels_rank0": {"inner": "k_bt_inner2_batch<512,2,2,8,0>", "inner_us_per_launch": inner_us, "update_us_per_launch": upd_us,
+            "schedule": "device-batched, two schedules side by side (relaxations that start feasible: the long chains, on the higher-priority stream | relaxations that need "
+                        "Phase I): one launch per kernel type per block step for a whole schedule while it is wide (grid.x = relaxation), ONE persistent launch per superstep "
+                        "(k_b_loop: per relaxation a pivot workgroup + 7 update workgroups, update of block t beside block t + 1) once <= 24 relaxations are active; "
+                        "%d block steps (of 8 pivots) and %.1f host looks per wave on rank 0" % (acc["blocks"] // max(steps, 1), holder["stats"]["supersteps"]),
+            "kernels_rank0": {"inner": "k_b_loop<512,2,4,7> (narrow) / k_bt_inner2_batch<512,2,2,8,0> (wide)", "inner_us_per_launch": inner_us, "update_us_per_launch": upd_us,
                               "time_share_inner": acc["inner"] / max(acc["inner"] + acc["update"], 1e-30),
-                              "algorithmic_bytes_per_pivot": alg_bytes},
+                              "algorithmic_bytes_per_pivot": alg_bytes,
+                              "note": "HIP events of the sampled waves: a k_b_loop launch (up to 32 blocks of 8 pivots for every active relaxation, updates inside) counts as ONE inner launch"},
         }
         if solo is not None:
             out["scaling_bound"] = {"heaviest_child": solo, "note": "a wave cannot finish before its heaviest child: relaxations/s at any GPU count "
                                     "<= %d / %.2f ms; more GPUs only remove what the other children add to that" % (len(children), 1e3 * solo["seconds_alone"]),
                                     "max_relaxations_per_s": len(children) / solo["seconds_alone"]}
         roof = {"bound": "hbm", "bound_kind": "latency", "limited_by": "latency: one workgroup per relaxation, two workgroup-wide argmins and two dependent tableau reads per pivot",
-                "kernel": "k_bt_inner2_batch<512,2,2,8,0>", "achieved": acc["pivots"] * alg_bytes / max(acc["inner"], 1e-30) / 1e9 if acc["inner"] > 0 else 0.0,
+                "kernel": "k_b_loop<512,2,4,7> + k_bt_inner2_batch<512,2,2,8,0>", "achieved": acc["pivots"] * alg_bytes / max(acc["inner"], 1e-30) / 1e9 if acc["inner"] > 0 else 0.0,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "note": "one workgroup per relaxation, two workgroup-wide argmins and two dependent tableau reads per pivot: bound by "
                         "latency, not bandwidth; achieved = rank 0's pivots x algorithmic bytes per pivot / HIP-event time of its batched inner launches"}
