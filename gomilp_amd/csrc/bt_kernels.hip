@@ -1501,7 +1501,7 @@ bool bt_tiled(int m, int ldt, int kmax, int nt_force, bool old_only) {
 // ---- batched launches (device-batched frontier, engine_batch.cpp): one configuration for the whole wave, chosen from
 // the largest relaxation; the register-resident kernel on the tiled layout only
 BtGroupCfg bt_group_cfg(int m, int ldt, int knob);   // btg_kernels.hip
-void launch_bt_inner_groups_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, const BtGroupCfg &c, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+void launch_bt_inner_groups_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, const BtGroupCfg &c, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int xcd_off);
 // pivots per block of the batched schedule for a wave of this shape class: 16 where the 8-workgroup kernel runs, else 8
 int bt_batch_k(int m_max, int ldt_max) {
     const BtGroupCfg g = bt_group_cfg(m_max, ldt_max, 0);
@@ -1520,8 +1520,8 @@ static void bt_inner_batch_nt(const BatchLP *lps, const int *ids, const int *cou
     hipExtLaunchKernelGGL((k_bt_inner2_batch<NT, RI, RI, 8, VL>), dim3(nlp), dim3(NT), lds, s, e0, e1, 0, lps, ids, count);
 }
 // ids / count: the active list of the previous control step (device); nlp: an upper bound of *count the host knows
-void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    if (bt_batch_k(m_max, ldt_max) == 16) { launch_bt_inner_groups_batch(lps, ids, count, nlp, bt_group_cfg(m_max, ldt_max, 0), s, e0, e1); return; }
+void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int xcd_off) {
+    if (bt_batch_k(m_max, ldt_max) == 16) { launch_bt_inner_groups_batch(lps, ids, count, nlp, bt_group_cfg(m_max, ldt_max, 0), s, e0, e1, xcd_off); return; }
     const BtCfg c = bt_cfg(m_max, ldt_max, 0);
     if (c.ri == 2) { if (c.nt == 512) bt_inner_batch_nt<512, 2, 0>(lps, ids, count, nlp, s, e0, e1); else bt_inner_batch_nt<1024, 2, 1>(lps, ids, count, nlp, s, e0, e1); }
     else bt_inner_batch_nt<512, 4, 0>(lps, ids, count, nlp, s, e0, e1);

@@ -691,8 +691,9 @@ __global__ __launch_bounds__(NT) void k_bt_loop(BTArgs a) {
 // advance at once, each inside one L2.  Blocks are dispatched in index order and all G workgroups of a relaxation lie in one
 // run of 8 G blocks, so a relaxation whose first workgroup is resident gets the others as soon as slots free up.
 template <int G, int NT, int RI, int KR>
-__global__ __launch_bounds__(NT) void k_bt_innerG_batch(const BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count) {
-    const unsigned int x8 = blockIdx.x & 7u, j = blockIdx.x >> 3;
+__global__ __launch_bounds__(NT) void k_bt_innerG_batch(const BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count, int xcd_off) {
+    // (xcd_off: list position 0 runs on that XCD — several schedules side by side keep their block kernels apart)
+    const unsigned int x8 = ((blockIdx.x & 7u) + 8u - (unsigned int)xcd_off) & 7u, j = blockIdx.x >> 3;
     const int lpos = (int)((j / G) * 8u + x8);
     if (lpos >= *count) return;
     const BatchLP &lp = lps[ids[lpos]];
@@ -775,10 +776,10 @@ void launch_bt_loop(const BTArgs &a, int ncu, hipStream_t s, hipEvent_t e0, hipE
     else hipExtLaunchKernelGGL((k_bt_loop<8, 512, 1>), dim3(grid), dim3(512), 0, s, e0, e1, 0, a);
 }
 // batched launch: the whole wave has the shape class of its largest relaxation (8 workgroups; 256 or 512 threads)
-void launch_bt_inner_groups_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, const BtGroupCfg &c, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+void launch_bt_inner_groups_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, const BtGroupCfg &c, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int xcd_off) {
     const unsigned int grid = 64u * (unsigned int)((nlp + 7) / 8);
-    if (c.nt == 256) hipExtLaunchKernelGGL((k_bt_innerG_batch<8, 256, 1, 16>), dim3(grid), dim3(256), 0, s, e0, e1, 0, lps, ids, count);
-    else hipExtLaunchKernelGGL((k_bt_innerG_batch<8, 512, 1, 16>), dim3(grid), dim3(512), 0, s, e0, e1, 0, lps, ids, count);
+    if (c.nt == 256) hipExtLaunchKernelGGL((k_bt_innerG_batch<8, 256, 1, 16>), dim3(grid), dim3(256), 0, s, e0, e1, 0, lps, ids, count, xcd_off);
+    else hipExtLaunchKernelGGL((k_bt_innerG_batch<8, 512, 1, 16>), dim3(grid), dim3(512), 0, s, e0, e1, 0, lps, ids, count, xcd_off);
 }
 const char *bt_group_kernel_name(int G, int ri) {   // (512-thread instances)
     static const char *names[3][2] = {{"k_bt_innerG<2,512,1,16>", "k_bt_innerG<2,512,2,16>"}, {"k_bt_innerG<4,512,1,16>", "k_bt_innerG<4,512,2,16>"},

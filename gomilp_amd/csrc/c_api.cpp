@@ -37,7 +37,8 @@ struct gomilp_pool {
     int64_t m0 = 0, n0 = 0;
     int batched = 1;            // knob: 0 = every relaxation through a worker's single-relaxation engine (round-1 path)
     std::unique_ptr<BatchEngine> batch;
-    std::unique_ptr<BatchEngine> batch2;   // second schedule for waves of large relaxations (created on first use)
+    std::unique_ptr<BatchEngine> batch2;   // second schedule (split waves, waves of large relaxations; created on first use)
+    std::unique_ptr<BatchEngine> batchx[2];   // third and fourth schedule for waves of large relaxations (split_large)
     int cond_guard = 1, exact_degenerate = 1, sample_batch = 0, batch_loop = 1;   // knob values kept for batch2: both halves of a split wave decide alike
     int split_large = 1;        // knob: waves of >= 4 large relaxations run as two interleaved schedules
     int split_phase = 1;        // knob: relaxations that start feasible (Phase II from the slack basis: the long pivot chains of a wave) and
@@ -167,6 +168,7 @@ int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value) {
         pool->batch_loop = value ? 1 : 0;
         pool->batch->set_loop(value != 0);
         if (pool->batch2) pool->batch2->set_loop(value != 0);
+        for (auto &bx : pool->batchx) if (bx) bx->set_loop(value != 0);
         return GOMILP_OK;
     }
     if (std::string(key) == "large_loop") { pool->large_loop = value ? 1 : 0; return GOMILP_OK; }
@@ -174,17 +176,20 @@ int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value) {
         pool->sample_batch = value != 0;
         pool->batch->set_sampling(value != 0);
         if (pool->batch2) pool->batch2->set_sampling(value != 0);
+        for (auto &bx : pool->batchx) if (bx) bx->set_sampling(value != 0);
         return GOMILP_OK;
     }
     if (std::string(key) == "cond_guard") {
         pool->cond_guard = (int)value;
         pool->batch->set_cond_guard((int)value);
         if (pool->batch2) pool->batch2->set_cond_guard((int)value);
+        for (auto &bx : pool->batchx) if (bx) bx->set_cond_guard((int)value);
     }
     if (std::string(key) == "exact_degenerate") {   // (and the workers' engines below)
         pool->exact_degenerate = (int)value;
         pool->batch->set_exact_degenerate((int)value);
         if (pool->batch2) pool->batch2->set_exact_degenerate((int)value);
+        for (auto &bx : pool->batchx) if (bx) bx->set_exact_degenerate((int)value);
     }
     int rc = GOMILP_OK;
     for (auto &e : pool->eng) { const int r = e->set(key, value); if (r != GOMILP_OK) rc = r; }
@@ -463,19 +468,39 @@ static int frontier_solve_impl(gomilp_pool *pool, int64_t count, const int32_t *
             rc = run_group(*pool->batch, cold_idx, gc, false, &bsc);
             merge_stats(bsc, true);
         } else if (two) {
+            // up to four schedules, each with a contiguous quarter of the wave, each on its own stream and host thread, their block kernels on
+            // XCDs of their own (BatchEngine::set_xcd_offset): one schedule's updates and control steps run under the other schedules' blocks
             make_batch2();
-            const int64_t half = count / 2;
-            BatchEngine::Stats bs2;
-            int rc2 = GOMILP_OK;
-            auto on_done2 = [&](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) { on_done_at(i + half, o, basic, xb); };
-            std::thread t2([&] {
+            const int nsched = (int)std::min<int64_t>(2, count);   // (four schedules — one per LP of a wave of four — measured 363 k pivots / s against 408-440 k for one or two: the chains slow each other through the memory system)
+            BatchEngine *be[4] = {pool->batch.get(), pool->batch2.get(), nullptr, nullptr};
+            for (int t = 2; t < nsched; t++) {
+                if (!pool->batchx[t - 2]) {
+                    pool->batchx[t - 2].reset(new BatchEngine(pool->device));
+                    pool->batchx[t - 2]->set_cond_guard(pool->cond_guard);
+                    pool->batchx[t - 2]->set_exact_degenerate(pool->exact_degenerate);
+                    pool->batchx[t - 2]->set_sampling(pool->sample_batch != 0);
+                    pool->batchx[t - 2]->set_loop(pool->batch_loop != 0);
+                }
+                be[t] = pool->batchx[t - 2].get();
+            }
+            int64_t lo[5];
+            for (int t = 0; t <= nsched; t++) lo[t] = count * t / nsched;
+            BatchEngine::Stats bsx[4];
+            int rcx[4] = {GOMILP_OK, GOMILP_OK, GOMILP_OK, GOMILP_OK};
+            auto run_part = [&](int t) {
                 hipSetDevice(pool->device);
-                rc2 = pool->batch2->run_roots(views.data(), nroots, root_of ? root_of + half : nullptr, count - half, koff + half, var, sign, rhs, tol, on_done2, &bs2);
-            });
-            rc = pool->batch->run_roots(views.data(), nroots, root_of, half, koff, var, sign, rhs, tol, on_done, &bs);
-            t2.join();
-            if (rc == GOMILP_OK) rc = rc2;
-            merge_stats(bs2, false);
+                const int64_t off = lo[t];
+                auto od = [&, off](int64_t i, const BatchEngine::Outcome &o, const int32_t *basic, const double *xb) { on_done_at(i + off, o, basic, xb); };
+                be[t]->set_xcd_offset((int)((2 * t) & 7));
+                rcx[t] = be[t]->run_roots(views.data(), nroots, root_of ? root_of + off : nullptr, lo[t + 1] - off, koff + off, var, sign, rhs, tol, od, &bsx[t]);
+                be[t]->set_xcd_offset(0);
+            };
+            std::vector<std::thread> ths;
+            for (int t = 1; t < nsched; t++) ths.emplace_back(run_part, t);
+            run_part(0);
+            for (auto &th : ths) th.join();
+            bs = bsx[0];
+            for (int t = 0; t < nsched; t++) { if (rc == GOMILP_OK) rc = rcx[t]; if (t) merge_stats(bsx[t], false); }
         } else {
             rc = pool->batch->run_roots(views.data(), nroots, root_of, count, koff, var, sign, rhs, tol, on_done, &bs);
         }

@@ -256,7 +256,7 @@ bool bt_loop_supported(const BtGroupCfg &c);
 void launch_bt_loop(const BTArgs &a, int ncu, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 bool bt_batch_supported(int m_max, int ldt_max);
 int bt_batch_k(int m_max, int ldt_max);
-void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int xcd_off = 0);
 void launch_bt_update_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 const char *bt_batch_kernel_name(int m_max, int ldt_max);
 // batched persistent loop kernel (bt_kernels.hip k_b_loop): relaxations per launch on a device with ncu CUs; shapes it takes

@@ -362,7 +362,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
                 while (b.samp_ev.size() < (size_t)(nsamp + 1) * 4) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) break; b.samp_ev.push_back(ev); }
                 if (b.samp_ev.size() >= (size_t)(nsamp + 1) * 4) { for (int q = 0; q < 4; q++) e[q] = b.samp_ev[(size_t)nsamp * 4 + q]; nsamp++; }
             }
-            launch_bt_inner_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_, e[0], e[1]);
+            launch_bt_inner_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_, e[0], e[1], xcd_off_);
             if (nwarm) { launch_bt_inner_dual_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_); S.launches += 1; }   // (stage BS_DUAL only)
             launch_bt_update_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_, e[2], e[3]);
         }
