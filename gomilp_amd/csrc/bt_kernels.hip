@@ -1151,6 +1151,9 @@ __global__ __launch_bounds__(NT) void k_b_loop(const BatchLP *__restrict__ lps, 
     // (the host counts blocks of 8 pivots: a launch with shorter blocks runs more of them)
     if (a.kmax >= KB) { a.kmax = KB; a.nblocks = nblocks * (8 / KB); }
     else a.nblocks = 1;
+#ifdef GOMILP_DEBUG
+    if (a.fault && role == 1) return;   // test hook (diagnostic flavour only): an update workgroup that never takes part -> the pivot workgroup gives up (ST_XCHG_TIMEOUT)
+#endif
     if (role == 0) bt_inner2_body<NT, RI, RI, 2 * KB, 0, false, true>(a, NU);
     else bt_loop_update_role<NT, KB, true>(a, role - 1, NU, 1);
 }

@@ -179,6 +179,9 @@ int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value) {
         for (auto &bx : pool->batchx) if (bx) bx->set_sampling(value != 0);
         return GOMILP_OK;
     }
+#ifdef GOMILP_DEBUG
+    if (std::string(key) == "bt_fault") { pool->batch->set_fault((int)value); if (pool->batch2) pool->batch2->set_fault((int)value); }   // (and the workers' engines below)
+#endif
     if (std::string(key) == "cond_guard") {
         pool->cond_guard = (int)value;
         pool->batch->set_cond_guard((int)value);

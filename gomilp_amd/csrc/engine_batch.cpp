@@ -311,6 +311,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         }
         // degenerate pivots are decided on a fresh gonum-order x_B: such a relaxation is handed to the worker path (ST_NEED_EXACT -> BS_HOST)
         lp.bt.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && (lp.m <= 256 || lp.gen || R.scale_span > 1e9))) ? 1e-9 : 0.0;
+        lp.bt.fault = fault_;
         lp.bt.cguard = (cond_guard_ && !lp.gen) ? 1e-9 : 0.0;   // a pivot element of rounding-noise size: ST_NEED_EXACT -> BS_HOST, the worker path measures the condition numbers
         lp.bt.xbuf = b.d_xbuf + (size_t)i * bt_xbuf_doubles();
         if (kb == 16) { lp.bt.groups = grp.groups; lp.bt.group_ri = grp.ri; lp.bt.group_nt = grp.nt; }
