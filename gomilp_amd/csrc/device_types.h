@@ -259,12 +259,18 @@ struct LUCtl {
     int32_t nsteps;     // how many of them did arithmetic ("dense" steps)
     int32_t ndrop;      // register columns the panel dropped un-eliminated (a newly dense column took their slot)
     int32_t rounds;     // rounds that did work
-    int32_t pad[2];
+    int32_t nnext;      // look-ahead schedule: the columns the NEXT round's panel loads (the first dense columns >= k1, as the panel's own scan finds them)
+    int32_t pad;
     int32_t steps[32];  // step (= column) index of each dense step, ascending
     int32_t prow[32];   // its pivot row
     // dropped column d was in the register list for the rows that left the active set at steps [dropin, dropout):
     // those rows hold final values in it (the panel wrote them), every other row still holds the original
     int32_t dropcol[32], dropin[32], dropout[32];
+    int32_t next[32];
+    // look-ahead schedule, control block 0 only: arrival counters of the workgroups that run beside the panel (monotonic over the rounds of
+    // a factorization: the update of the next panel's columns / the U-solve tiles), and the flag a wait that ran out of patience raises
+    uint32_t cnt_x, cnt_u, cnt_s;   // (cnt_x: the U-solve of the next panel's columns, one workgroup per round)
+    int32_t fault;
 };
 
 // Arguments of the gonum-order LU kernels (final basis solve).
@@ -281,7 +287,15 @@ struct LUArgs {
     int32_t *dense_flag;        // per step: 1 when the step did arithmetic (0 = unit-column fast path); nullable
     LUCtl *ctl;                 // compressed schedule only
     double *Lp, *Up;            // compressed schedule only: compact panels of the running round (32 x ldw each)
-    int32_t slots, pad;         // compressed schedule: the slot form of the panel (lu_compressed.hip k_luc_panel_slots; knob lu_blocked = 3, default)
+    int32_t slots, look;        // compressed schedule: the slot form of the panel (lu_compressed.hip k_luc_panel_slots); look: the look-ahead schedule (knob lu_blocked = 3, default; 2: the trailing update of a round in one launch behind it)
+    // look-ahead schedule: control block / panels / row snapshot of the round before (by round parity), read by the update workgroups that
+    // run beside this round's panel; ctl_prev == ctl, ... without look-ahead
+    const LUCtl *ctl_prev;
+    const double *Lp_prev, *Up_prev;
+    int32_t *rowsnap;           // rowstep as this round leaves it (the panel of the next round changes rowstep while this round's update still reads it)
+    const int32_t *rowsnap_prev;
+    LUCtl *ctl_base;            // control block 0 (counters, fault flag)
+    int32_t round, pad3;        // rounds launched for this factorization before this one
 };
 
 }  // namespace gomilp

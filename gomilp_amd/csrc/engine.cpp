@@ -78,7 +78,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "max_pivots") max_pivots_ = v < 0 ? 0 : v;
     else if (key == "sample_events") sample_events_ = v < 0 ? 0 : v;
     else if (key == "fused") fused_ = v ? 1 : 0;
-    else if (key == "lu_blocked") lu_blocked_ = v < 0 ? 0 : (v > 2 ? 3 : v);  // 0 per column, 1 blocked panels, 2 / 3 compressed rounds (slot panel; the sorted register panel of rounds 1-3 is retired)
+    else if (key == "lu_blocked") lu_blocked_ = v < 0 ? 0 : (v > 2 ? 3 : v);  // 0 per column, 1 blocked panels, 2 compressed rounds (slot panel), 3 the same with the look-ahead schedule (default; lu_compressed.hip)
     else if (key == "tableau") tableau_ = v ? 1 : 0;
     else if (key == "blocked") blocked_ = v ? 1 : 0;
     else if (key == "bt_nt") { if (v != 0 && v != 256 && v != 512 && v != 1024) return GOMILP_ERR_BAD_SHAPE; bt_nt_ = v; }
@@ -119,8 +119,8 @@ int Engine::ensure_work(int m, int ncols) {
         }
         HIP_TRY(dmalloc(&w.st, 1));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.st_host), sizeof(DevState), hipHostMallocDefault));
-        HIP_TRY(dmalloc(&w.luctl, 1));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.luctl_host), sizeof(LUCtl), hipHostMallocDefault));
+        HIP_TRY(dmalloc(&w.luctl, 2));   // (by round parity: lu_compressed.hip, look-ahead schedule)
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.luctl_host), 2 * sizeof(LUCtl), hipHostMallocDefault));
         w.trace_cap = 1 << 18;
         HIP_TRY(dmalloc(&w.trace, (size_t)w.trace_cap));
         HIP_TRY(hipEventCreate(&w.ev[0])); HIP_TRY(hipEventCreate(&w.ev[1]));
@@ -139,10 +139,11 @@ int Engine::ensure_work(int m, int ncols) {
     HIP_TRY(dmalloc(&w.move, (size_t)nld)); HIP_TRY(dmalloc(&w.rvec, (size_t)nc));
     HIP_TRY(dmalloc(&w.yscratch, (size_t)64 * nld));
     HIP_TRY(dmalloc(&w.basic, (size_t)nm + (size_t)nc)); w.nonbasic = w.basic + nm;   // one block: both lists go up in one copy
-    HIP_TRY(dmalloc(&w.lpos, (size_t)nm)); HIP_TRY(dmalloc(&w.rowstep, (size_t)nm)); HIP_TRY(dmalloc(&w.rho, (size_t)nm));
+    // (rowstep: + two snapshots, by round parity, for the look-ahead schedule of the compressed LU)
+    HIP_TRY(dmalloc(&w.lpos, (size_t)nm)); HIP_TRY(dmalloc(&w.rowstep, (size_t)3 * nm)); HIP_TRY(dmalloc(&w.rho, (size_t)nm));
     HIP_TRY(dmalloc(&w.unitrow, (size_t)nm)); HIP_TRY(dmalloc(&w.denseflag, (size_t)nm)); HIP_TRY(dmalloc(&w.dlist, (size_t)nm));
     HIP_TRY(dmalloc(&w.ludiag, (size_t)nm)); HIP_TRY(dmalloc(&w.Wd, (size_t)nm * nld));
-    HIP_TRY(dmalloc(&w.luLp, (size_t)32 * nld)); HIP_TRY(dmalloc(&w.luUp, (size_t)32 * nld));
+    HIP_TRY(dmalloc(&w.luLp, (size_t)64 * nld)); HIP_TRY(dmalloc(&w.luUp, (size_t)64 * nld));   // (2 x 32 rows: by round parity)
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_W), (size_t)nm * nld * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_vec), (size_t)std::max(nld, nc) * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_chk), (size_t)nld * sizeof(double), hipHostMallocDefault));
@@ -786,31 +787,53 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     const bool blocked = compressed || (lu_blocked_ && lu_blocked_supported(m));
     a.dense_flag = blocked ? w.denseflag : nullptr;
     a.ctl = w.luctl; a.Lp = w.luLp; a.Up = w.luUp;
-    a.slots = 1; a.pad = 0;
+    // look-ahead schedule: where a factorization takes many rounds (measured: 2048 rows 23 rounds 2.20 -> 2.05 ms, 1000 rows 12 rounds
+    // 1.10 -> 1.03 ms on the device; 520-row children, 4 rounds: 0.63 -> 0.65 ms, and a wave runs dozens of them side by side)
+    a.slots = 1; a.look = (lu_blocked_ >= 3 && m > 768) ? 1 : 0;
+    a.ctl_prev = a.ctl; a.Lp_prev = a.Lp; a.Up_prev = a.Up;
+    a.rowsnap = w.rowstep + w.cap_m; a.rowsnap_prev = a.rowsnap;   // (launch_luc_rounds sets the round's parity)
+    a.ctl_base = a.ctl; a.round = 0; a.pad3 = 0;
     w.st_host->lu_singular = 0;
     sync_state_to_device();
     lu_rounds_ = 0;
     if (compressed) {
         // rounds are data dependent (lu_compressed.hip): enqueue a batch, read the control block, repeat.  The first
         // batch is sized from the number of columns that are dense for sure.
-        launch_luc_init(a, stream_);
-        launches_++;
         const int nb = lu_compressed_nb(m, a.slots != 0);
-        // measured: steps that do arithmetic ~ 3 x the non-unit columns (each of them usually turns a unit column dense)
-        // (the slot panel takes up to nb steps per round whatever the order of the columns; a wrong guess costs one more look at the
-        // control block, a generous one a run of empty rounds of three launches each)
-        int batch = a.slots ? std::max(1, (std::min(m, (5 * nonunit) / 2) + nb - 1) / nb) : std::max(1, (3 * nonunit + nb - 1) / nb + 1);
-        for (;;) {
-            launches_ += launch_luc_rounds(a, w.rho, batch, stream_);
-            HIP_TRY(hipMemcpyAsync(w.luctl_host, w.luctl, sizeof(LUCtl), hipMemcpyDeviceToHost, stream_));
-            // the dense-step flags ride along (final once k_next == m): no separate round trip for them
-            HIP_TRY(hipMemcpyAsync(w.h_idx, w.denseflag, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-            HIP_TRY(sync_stream());
-            if (w.luctl_host->k_next >= m) break;
-            batch = std::max(4, (int)(((int64_t)(m - w.luctl_host->k_next) * w.luctl_host->rounds) / std::max(1, w.luctl_host->k_next)) + 2);
-            if (batch > 64) batch = 64;
+        for (int attempt = 0;; attempt++) {
+            launch_luc_init(a, stream_);
+            launches_++;
+            // measured: steps that do arithmetic ~ 3 x the non-unit columns (each of them usually turns a unit column dense)
+            // (the slot panel takes up to nb steps per round whatever the order of the columns; a wrong guess costs one more look at the
+            // control block, a generous one a run of empty rounds)
+            int batch = a.slots ? std::max(1, (std::min(m, (5 * nonunit) / 2) + nb - 1) / nb) : std::max(1, (3 * nonunit + nb - 1) / nb + 1);
+            int enq = 0;   // rounds enqueued so far: the look-ahead schedule keeps two control blocks, by round parity
+            const LUCtl *last = w.luctl_host;
+            for (;;) {
+                launches_ += launch_luc_rounds(a, w.rho, batch, enq, stream_);
+                enq += batch;
+                HIP_TRY(hipMemcpyAsync(w.luctl_host, w.luctl, 2 * sizeof(LUCtl), hipMemcpyDeviceToHost, stream_));
+                // the dense-step flags ride along (final once k_next == m): no separate round trip for them
+                HIP_TRY(hipMemcpyAsync(w.h_idx, w.denseflag, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+                HIP_TRY(sync_stream());
+                last = w.luctl_host + (a.look ? ((enq - 1) & 1) : 0);
+                if (w.luctl_host[0].fault || last->k_next >= m) break;
+                batch = std::max(4, (int)(((int64_t)(m - last->k_next) * last->rounds) / std::max(1, last->k_next)) + 2);
+                if (batch > 64) batch = 64;
+            }
+            lu_rounds_ = last->rounds;
+            if (!w.luctl_host[0].fault) break;
+            // a wait inside a look-ahead launch ran out of patience (its workgroups never became resident together): once more, from the
+            // basis, with the whole update behind each panel
+            if (attempt > 0 || !a.look) return GOMILP_ERR_DEVICE;
+            a.look = 0;
+            lu_look_faults_++;
+            if (compressed != transpose) launch_luc_gather(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
+            else {
+                if (transpose) HIP_TRY(hipMemsetAsync(w.W, 0, (size_t)m * ldw * sizeof(double), stream_));
+                launch_gather_w(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
+            }
         }
-        lu_rounds_ = w.luctl_host->rounds;
     } else if (blocked) launches_ += launch_lu_blocked(a, w.rho, stream_) + 1;
     else { launch_lu(a, stream_); launches_ += m + 2; }
     // Only the columns whose elimination step did arithmetic carry non-zero L / off-diagonal U entries (a unit-column
@@ -854,9 +877,23 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     std::vector<int32_t> phys(m);
     for (int R = 0; R < m; R++) phys[w.h_idx[R]] = R;
     const double *diag = w.h_vec;
-    // LU.Det() == 0 (mat/lu.go:301, :118-135): exp(sum log|u_ii|) == 0
+    // LU.Det() == 0 (mat/lu.go:301, :118-135): exp(sum log|u_ii|) == 0.  The sum of the binary exponents brackets it ( |u| in
+    // [2^(e-1), 2^e) ): only a product that could underflow (or a zero / NaN on the diagonal) pays for the m logarithms in gonum's order.
     double logdet = 0;
-    for (int i = 0; i < m; i++) logdet += log(fabs(diag[phys[i]]));
+    {
+        long long esum = 0;
+        bool plain = true;
+        for (int i = 0; i < m; i++) {
+            int e = 0;
+            const double d = diag[i];
+            if (!(fabs(d) > 0) || !std::isfinite(d)) { plain = false; break; }
+            (void)frexp(d, &e);
+            esum += e;
+        }
+        // sum log|u_ii| >= (esum - m) ln 2, minus rounding of m additions; exp() is zero below -745.14
+        if (plain && (double)(esum - m) * 0.6931471805599453 > -700.0) logdet = 0;   // (exp(logdet) != 0 for sure; the value itself is not used)
+        else for (int i = 0; i < m; i++) logdet += log(fabs(diag[phys[i]]));
+    }
     *singular = w.st_host->lu_singular != 0 || exp(logdet) == 0;
     if (*singular && GOMILP_DBG_ENV("GOMILP_DEBUG_LOOP")) {
         int nz = 0; double dmin = 1e300;
@@ -870,7 +907,22 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     if (split) {
         // coupled part on the host: row s of h_W is dense position dl[s] restricted to the dense columns
         std::vector<double> xdl(nd), xdu(nd);
-        for (int s2 = 0; s2 < nd; s2++) {   // Dtrsm(Left, Lower, NoTrans, Unit)
+        // Dtrsm(Left, Lower, NoTrans, Unit): a row is one chain of dependent rounded additions in ascending t; four rows run side by
+        // side over the part of the solution that is known before the first of them, then finish one after the other
+        int s2 = 0;
+        for (; s2 + 4 <= nd; s2 += 4) {
+            const double *r0 = w.h_W + (size_t)s2 * nd, *r1 = r0 + nd, *r2 = r1 + nd, *r3 = r2 + nd;
+            double b0 = rhs[phys[dl[s2]]], b1 = rhs[phys[dl[s2 + 1]]], b2 = rhs[phys[dl[s2 + 2]]], b3 = rhs[phys[dl[s2 + 3]]];
+            for (int t = 0; t < s2; t++) {
+                const double xk = xdl[t];
+                b0 = term(b0, r0[t], xk); b1 = term(b1, r1[t], xk); b2 = term(b2, r2[t], xk); b3 = term(b3, r3[t], xk);
+            }
+            xdl[s2] = b0;
+            b1 = term(b1, r1[s2], b0); xdl[s2 + 1] = b1;
+            b2 = term(b2, r2[s2], b0); b2 = term(b2, r2[s2 + 1], b1); xdl[s2 + 2] = b2;
+            b3 = term(b3, r3[s2], b0); b3 = term(b3, r3[s2 + 1], b1); b3 = term(b3, r3[s2 + 2], b2); xdl[s2 + 3] = b3;
+        }
+        for (; s2 < nd; s2++) {
             const double *row = w.h_W + (size_t)s2 * nd;
             double bi = rhs[phys[dl[s2]]];
             for (int t = 0; t < s2; t++) bi = term(bi, row[t], xdl[t]);

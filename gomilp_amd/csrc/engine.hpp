@@ -157,6 +157,7 @@ class Engine {
     int32_t *up_stats_ = nullptr; size_t up_stats_cap_ = 0;
     std::unique_ptr<Work> w_;
     // knobs
+    int64_t lu_look_faults_ = 0;   // final solves repeated with the plain schedule after a look-ahead launch gave up a wait
     int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 3, tableau_ = 1, blocked_ = 1, block_k_ = 0,  // block_k_ 0 = auto
             bt_nt_ = 0, bt_old_ = 0, bt_stamps_ = 0, bt_upd_valu_ = 0, bt_fault_ = 0, general_device_ = 1, bt_groups_ = 0,   // bt_groups_: -1 never, 0 by shape, 2 / 4 / 8 forced
             bt_lag_ = 1,       // persistent loop kernel where the multi-workgroup block kernel runs (0: block kernel + update launches)
@@ -295,7 +296,7 @@ int launch_lu_blocked(const LUArgs &a, int32_t *pivrow, hipStream_t s);
 bool lu_compressed_supported(int m);
 int lu_compressed_nb(int m, bool slots);
 void launch_luc_init(const LUArgs &a, hipStream_t s);
-int launch_luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t s);
+int launch_luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, int round_base, hipStream_t s);
 void launch_luc_gather(const double *At, int ld, int m, const int32_t *basic, double *W, int ldw, hipStream_t s);
 void launch_luc_pack_dense(const LUArgs &a, const int32_t *dlist, int nd, const int32_t *pivrow, double *Wdd, double *diag, hipStream_t s);
 void launch_luc_solve_rows(const LUArgs &a, const int32_t *dlist, int nd, const double *b, const double *xdL, const double *xdU,

@@ -18,11 +18,23 @@ double now_s() {
     return duration<double>(steady_clock::now().time_since_epoch()).count();
 }
 
+#ifdef GOMILP_DEBUG
+// diagnostic flavour: say which call failed
+#define HIP_TRY(expr)                                                                                                   \
+    do {                                                                                                                \
+        hipError_t _e = (expr);                                                                                         \
+        if (_e != hipSuccess) {                                                                                         \
+            fprintf(stderr, "gomilp: %s:%d: %s -> %s\n", __FILE__, __LINE__, #expr, hipGetErrorString(_e));              \
+            return GOMILP_ERR_DEVICE;                                                                                   \
+        }                                                                                                               \
+    } while (0)
+#else
 #define HIP_TRY(expr)                                   \
     do {                                                \
         hipError_t _e = (expr);                         \
         if (_e != hipSuccess) return GOMILP_ERR_DEVICE; \
     } while (0)
+#endif
 
 // floats.MinIdx (floats/floats.go:458-474)
 int64_t min_idx(const double *s, int64_t n) {

@@ -63,7 +63,336 @@ __device__ unsigned long long g_luc_stamps[4 * 16];
 #else
 #define LUC_STAMP(S) do { } while (0)
 #endif
-template <int T, int RPT, int NB, int SMAX>
+constexpr int kLucSpinLimit = 600000;   // polls (~1.5 us each)
+__device__ __forceinline__ bool luc_spin(const uint32_t *p, uint32_t target) {
+    for (int it = 0; it < kLucSpinLimit; it++) {
+        const uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(v - target) >= 0) return true;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return false;
+}
+__device__ __forceinline__ double luc_ld_agent(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void luc_st_agent(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- the trailing update of a round, cell by cell (look-ahead schedule) ------------------------------------------------------------
+// a[R][j] += sum_s Lp[s][R] * Up[s][j] in ascending s, zero multipliers skipped — the arithmetic of k_luc_trail below, with the
+// round's panels read straight from L2 (no staging, no barrier): the body of every 256-thread group of the workgroups that run
+// BESIDE the next round's panel (luc_role, phase T) — hidden behind the panel's steps, so the efficiency of these loads does not matter.
+// 4 x 4 cells per thread: rows R0 + 4 tx .. (consecutive lanes walk down a column), columns by `colj`.
+template <int NB, int UNR>
+__device__ __forceinline__ void luc_trail_cells(const LUArgs &a, const LUCtl *__restrict__ c, const double *__restrict__ Lp,
+                                                const double *__restrict__ Up, const int32_t *__restrict__ rowstep, int ns, int k0,
+                                                const int (&colj)[4], int R0, int tx) {
+    const int m = a.m;
+    const size_t ldw = (size_t)a.ldw;
+    const int Rb = R0 + tx * 4;
+    int rs[4], cls[4];
+    bool anyrow = false;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+        const int R = Rb + rr;
+        rs[rr] = R < m ? rowstep[R] : 0;
+        cls[rr] = R < m ? (rs[rr] < 0 ? 1 : (rs[rr] >= k0 ? 2 : 0)) : 0;   // 1 active, 2 left during the round, 0 finished earlier
+        anyrow = anyrow || cls[rr] > 0;
+    }
+    bool anycol = false;
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) anycol = anycol || colj[cc] >= 0;
+    if (!anyrow || !anycol) return;
+    int din[4] = {0, 0, 0, 0}, dout[4] = {0, 0, 0, 0};   // rows that left at steps [din, dout) are final in the column
+    const int nd = c->ndrop;
+    for (int t = 0; t < nd; t++) {
+        const int dc = c->dropcol[t], di = c->dropin[t], dq = c->dropout[t];
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++)
+            if (dc == colj[cc]) { din[cc] = di; dout[cc] = dq; }
+    }
+    double acc[4][4];   // [cc][rr]
+    bool live[4][4];
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            live[cc][rr] = cls[rr] > 0 && colj[cc] >= 0 && !(cls[rr] == 2 && rs[rr] >= din[cc] && rs[rr] < dout[cc]);
+            acc[cc][rr] = live[cc][rr] ? a.W[(size_t)colj[cc] * ldw + Rb + rr] : 0.0;
+        }
+    }
+#pragma unroll UNR
+    for (int s = 0; s < ns; s++) {   // (UNR steps' loads in flight: 4 where the registers are there, 2 beside a 1024-thread panel)
+        double l[4], u[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) l[rr] = (Rb + rr) < m ? Lp[(size_t)s * ldw + Rb + rr] : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) u[cc] = colj[cc] >= 0 ? luc_ld_agent(&Up[(size_t)s * ldw + colj[cc]]) : 0.0;   // (written by phase S of this launch)
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const bool nz = l[rr] != 0;
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) acc[cc][rr] = nz ? __dadd_rn(__dmul_rn(l[rr], u[cc]), acc[cc][rr]) : acc[cc][rr];
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+            if (live[cc][rr]) a.W[(size_t)colj[cc] * ldw + Rb + rr] = acc[cc][rr];
+    }
+}
+
+// ---- look-ahead schedule: ONE launch per round -----------------------------------------------------------------------------------
+// Workgroup 0 is the panel of round r.  The other workgroups finish round r-1 beside it, from the record round r-1 left (control block,
+// multiplier panel, rowstep snapshot: all by round parity, the running panel writes the other parity):
+//   phase U  (workgroups 1 .. nrt, 64 rows each): U-solve + update of the columns panel r LOADS (ctl_prev->next) — the only part of
+//            the update on the critical path; the panel sets up its index maps meanwhile and waits for cnt_u before it loads.
+//   phase S  (the same workgroups): the U-solve of one 64-column tile of all other columns -> Up_prev, then cnt_s.
+//   phase T  (every workgroup, behind cnt_s): the update of all other columns, hidden behind the panel's steps.  Not touched: the
+//            columns of phase U, and the unit columns of rows that were still active when round r-1 ended — the running panel may take
+//            such a row, build the column in registers and write it, while the round's U rows are exactly zero in it (the update
+//            would add l * 0 to every cell).
+// What crosses workgroups INSIDE the launch (the cells of phase U -> the panel's loads, Up_prev -> phase T) moves with agent-scope
+// stores / loads and an arrival counter, as in the loop kernels (bt_loop.h); everything else crossed a launch boundary.  Waits are
+// bounded: a workgroup that runs out of patience raises ctl_base->fault, every later launch returns at once, and the host repeats the
+// factorization with the plain schedule.
+template <int T, int NB>
+__device__ void luc_role(const LUArgs &a) {
+    static_assert(T % 256 == 0 && NB == 32, "groups of 256 threads; 32 steps per round");
+    const LUCtl *__restrict__ c = a.ctl_prev;
+    LUCtl *base = a.ctl_base;
+    const int b = (int)blockIdx.x - 1;
+    const int tid = threadIdx.x;
+    const int m = a.m, nrt = (m + 63) / 64;
+    const size_t ldw = (size_t)a.ldw;
+    const int ns = c->nsteps, k0 = c->k0, k1 = c->k1, nn = c->nnext, nd = c->ndrop;
+    const bool work = ns > 0 && k1 < m;
+    // phases U and S share the staging area (S starts behind U's last barrier)
+    __shared__ double s_ln[NB][NB + 1];
+    __shared__ double s_xa[2 * NB * 33];      // U: X[s][33] (pivot rows x listed columns) + Us[s][33]; S: X[s][65]
+    static_assert(2 * NB * 33 >= NB * 65, "staging area of phase S");
+    __shared__ double s_ls[NB][64];
+    __shared__ int Ps[NB], Ss[NB], Dc[NB], Di[NB], Do[NB], Nx[NB];
+    __shared__ int s_go;
+    const double *__restrict__ Lp = a.Lp_prev;
+    if (b < nrt) {
+        if (work) {
+            if (tid < NB) {
+                Ps[tid] = tid < ns ? c->prow[tid] : 0;
+                Ss[tid] = tid < ns ? c->steps[tid] : 0x7fffffff;
+                Dc[tid] = tid < nd ? c->dropcol[tid] : -1;
+                Di[tid] = tid < nd ? c->dropin[tid] : 0;
+                Do[tid] = tid < nd ? c->dropout[tid] : 0;
+                Nx[tid] = tid < nn ? c->next[tid] : -1;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < NB * NB; idx += T) {
+                const int s2 = idx / NB, t = idx % NB;
+                s_ln[s2][t] = (s2 < ns && t < s2) ? Lp[(size_t)t * ldw + Ps[s2]] : 0.0;
+            }
+        }
+        // ---- phase U
+        // The U-solve of the listed columns reads the round's pivot rows in them, and the update WRITES those cells (a pivot row's
+        // update is its U-solve): ONE workgroup solves, before anybody writes, and hands the U rows over through Up_prev (otherwise
+        // unused in these columns) and cnt_x; a workgroup that starts late — other kernels on the device — finds everything it needs.
+        bool ok = true;
+        if (work && nn > 0) {
+            double (*X)[33] = reinterpret_cast<double (*)[33]>(s_xa);
+            double (*Us)[33] = reinterpret_cast<double (*)[33]>(s_xa + NB * 33);
+            double *Upw = const_cast<double *>(a.Up_prev);
+            const int R0 = b * 64;
+            for (int idx = tid; idx < NB * 64; idx += T) {
+                const int s2 = idx / 64, r = idx % 64;
+                s_ls[s2][r] = (s2 < ns && R0 + r < m) ? Lp[(size_t)s2 * ldw + R0 + r] : 0.0;
+            }
+            if (b == 0) {
+                for (int idx = tid; idx < NB * 32; idx += T) {
+                    const int s2 = idx / 32, ci = idx % 32;
+                    X[s2][ci] = (s2 < ns && ci < nn) ? a.W[(size_t)Nx[ci] * ldw + Ps[s2]] : 0.0;
+                }
+                __syncthreads();
+                if (tid < nn) {   // the U-solve of k_luc_usolve, one listed column per thread
+                    const int j = Nx[tid];
+                    int din = 0, dout = 0;
+                    for (int t = 0; t < nd; t++)
+                        if (Dc[t] == j) { din = Di[t]; dout = Do[t]; }
+                    double u[NB];
+#pragma unroll
+                    for (int s2 = 0; s2 < NB; s2++) {
+                        double x = 0;
+                        if (s2 < ns) {
+                            x = X[s2][tid];
+                            if (!(Ss[s2] >= din && Ss[s2] < dout)) {
+#pragma unroll
+                                for (int t = 0; t < s2; t++) {
+                                    const double l = s_ln[s2][t];
+                                    x = (l != 0) ? __dadd_rn(__dmul_rn(l, u[t]), x) : x;
+                                }
+                            }
+                            luc_st_agent(Upw + (size_t)s2 * ldw + j, x);
+                        }
+                        u[s2] = x;
+                        Us[s2][tid] = x;
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(&base->cnt_x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (tid == 0) s_go = luc_spin(&base->cnt_x, (uint32_t)(a.round + 1)) ? 1 : 0;
+                __syncthreads();
+                ok = s_go != 0;
+                if (ok) {
+                    for (int idx = tid; idx < NB * 32; idx += T) {
+                        const int s2 = idx / 32, ci = idx % 32;
+                        Us[s2][ci] = (s2 < ns && ci < nn) ? luc_ld_agent(Upw + (size_t)s2 * ldw + Nx[ci]) : 0.0;
+                    }
+                } else if (tid == 0) base->fault = 1;
+                __syncthreads();
+            }
+            if (ok && tid < 128) {   // 64 rows x 32 listed columns, 4 x 4 cells per thread
+                const int tx = tid & 15, ty = tid >> 4;
+                const int Rb = R0 + tx * 4;
+                int rs[4], cls[4], colj[4], din[4] = {0, 0, 0, 0}, dout[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int R = Rb + rr;
+                    rs[rr] = R < m ? a.rowsnap_prev[R] : 0;
+                    cls[rr] = R < m ? (rs[rr] < 0 ? 1 : (rs[rr] >= k0 ? 2 : 0)) : 0;
+                }
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) colj[cc] = Nx[ty * 4 + cc];
+                for (int t = 0; t < nd; t++) {
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++)
+                        if (Dc[t] == colj[cc]) { din[cc] = Di[t]; dout[cc] = Do[t]; }
+                }
+                double acc[4][4];
+                bool live[4][4];
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        live[cc][rr] = cls[rr] > 0 && colj[cc] >= 0 && !(cls[rr] == 2 && rs[rr] >= din[cc] && rs[rr] < dout[cc]);
+                        acc[cc][rr] = live[cc][rr] ? a.W[(size_t)colj[cc] * ldw + Rb + rr] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < NB; s2++) {
+                    if (s2 < ns) {
+                        double l[4], u[4];
+#pragma unroll
+                        for (int rr = 0; rr < 4; rr++) l[rr] = s_ls[s2][tx * 4 + rr];
+#pragma unroll
+                        for (int cc = 0; cc < 4; cc++) u[cc] = Us[s2][ty * 4 + cc];
+#pragma unroll
+                        for (int rr = 0; rr < 4; rr++) {
+                            const bool nz = l[rr] != 0;
+#pragma unroll
+                            for (int cc = 0; cc < 4; cc++) acc[cc][rr] = nz ? __dadd_rn(__dmul_rn(l[rr], u[cc]), acc[cc][rr]) : acc[cc][rr];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++)
+                        if (live[cc][rr]) luc_st_agent(&a.W[(size_t)colj[cc] * ldw + Rb + rr], acc[cc][rr]);
+                }
+            }
+        } else if (b == 0) {
+            if (tid == 0) __hip_atomic_fetch_add(&base->cnt_x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (one arrival per launch, work or not)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's cells have landed
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(&base->cnt_u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- phase S: column tile b of the columns behind the round
+        const int j0 = k1 + b * 64;
+        if (work && j0 < m) {
+            double (*X)[65] = reinterpret_cast<double (*)[65]>(s_xa);
+            for (int idx = tid; idx < NB * 64; idx += T) {
+                const int s2 = idx / 64, ci = idx % 64;
+                const int j = j0 + ci;
+                bool listed = false;   // (phase U's columns: not needed, and their cells are being written)
+                for (int t = 0; t < nn; t++) listed = listed || Nx[t] == j;
+                X[s2][ci] = (s2 < ns && j < m && !listed) ? a.W[(size_t)j * ldw + Ps[s2]] : 0.0;
+            }
+            __syncthreads();
+            const int j = j0 + tid;
+            bool mine = tid < 64 && j < m;
+            if (mine)
+                for (int t = 0; t < nn; t++) mine = mine && Nx[t] != j;   // (phase U's columns: their U rows in Up_prev are phase U's)
+            if (mine) {
+                int din = 0, dout = 0;
+                for (int t = 0; t < nd; t++)
+                    if (Dc[t] == j) { din = Di[t]; dout = Do[t]; }
+                double u[NB];
+#pragma unroll
+                for (int s2 = 0; s2 < NB; s2++) {
+                    if (s2 < ns) {
+                        double x = X[s2][tid];
+                        if (!(Ss[s2] >= din && Ss[s2] < dout)) {
+#pragma unroll
+                            for (int t = 0; t < s2; t++) {
+                                const double l = s_ln[s2][t];
+                                x = (l != 0) ? __dadd_rn(__dmul_rn(l, u[t]), x) : x;
+                            }
+                        }
+                        u[s2] = x;
+                        luc_st_agent(const_cast<double *>(a.Up_prev) + (size_t)s2 * ldw + j, x);
+                    } else u[s2] = 0;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(&base->cnt_s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!work) return;
+    // ---- phase T
+    if (tid == 0) s_go = luc_spin(&base->cnt_s, (uint32_t)(a.round + 1) * (uint32_t)nrt) ? 1 : 0;
+    __syncthreads();
+    if (!s_go) {
+        if (tid == 0) base->fault = 1;
+        return;
+    }
+    constexpr int G = T / 256;
+    const int g = tid >> 8, t256 = tid & 255;
+    const int tx = t256 & 15, ty = t256 >> 4;
+    const int nct = (m - k1 + 63) / 64;
+    const int ngroups = ((int)gridDim.x - 1) * G;
+    for (int tile = b * G + g; tile < nct * nrt; tile += ngroups) {
+        const int ct = tile / nrt, rt = tile % nrt;   // neighbouring groups: the row tiles of one column tile
+        int colj[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) {
+            int j = k1 + ct * 64 + ty * 4 + cc;
+            if (j >= m) j = -1;
+            if (j >= 0) {
+                const int ur = a.unit_row ? a.unit_row[j] : -1;
+                if (ur >= 0 && a.rowsnap_prev[ur] < 0) j = -1;
+            }
+            colj[cc] = j;
+        }
+        for (int t = 0; t < nn; t++) {
+            const int nj = c->next[t];
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++)
+                if (colj[cc] == nj) colj[cc] = -1;
+        }
+        luc_trail_cells<NB, (T > 512 ? 2 : 4)>(a, c, a.Lp_prev, a.Up_prev, a.rowsnap_prev, ns, k0, colj, rt * 64, tx);
+    }
+}
+
+// panel shapes that carry the look-ahead schedule: groups of 256 threads for the update role, and not the 4-rows-per-thread shape of
+// 1024 threads (bases beyond 2048 rows: its 128 registers per lane are all taken, the additions spilled inside the step loop)
+template <int T, int RPT>
+constexpr bool luc_look_ok() { return T % 256 == 0 && !(T == 1024 && RPT == 4); }
+// LK: the instance that carries the look-ahead schedule (the update role beside the panel: more registers, 42 KB of LDS); the plain
+// instance serves the small bases, dozens of which factor side by side in a wave
+template <int T, int RPT, int NB, int SMAX, bool LK>
 __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__restrict__ pivrow) {
     constexpr int NW = T / 64;
     constexpr int MAXM = T * RPT;
@@ -85,13 +414,18 @@ __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__rest
     __shared__ unsigned int redL[2][16];
     __shared__ int s_slotcol[NB];     // columns listed at the start of the round (afterwards the slot tables live in registers)
     __shared__ int s_nload, s_stop, s_limit, s_sigma, s_ins;
+    if (LK && a.look && a.ctl_base->fault) return;   // (a wait of an earlier launch gave up: the host repeats the factorization)
+    if (blockIdx.x > 0) {   // look-ahead schedule: the previous round's update beside this round's panel
+        if constexpr (LK) luc_role<T, SMAX>(a);
+        return;
+    }
     LUCtl *ctl = a.ctl;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m = a.m;
     const size_t ldw = (size_t)a.ldw;
-    const int k0 = ctl->k_next;
+    const int k0 = a.ctl_prev->k_next;
     if (k0 >= m) {
-        if (tid == 0) { ctl->nsteps = 0; ctl->ndrop = 0; }
+        if (tid == 0) { ctl->nsteps = 0; ctl->ndrop = 0; ctl->nnext = 0; ctl->k_next = k0; ctl->k0 = k0; ctl->k1 = k0; ctl->rounds = a.ctl_prev->rounds; }
         return;
     }
     for (int R = tid; R < MAXM; R += T) {
@@ -130,6 +464,19 @@ __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__rest
     int myslotcol = (lane < NB && lane < nload) ? s_slotcol[lane < NB ? lane : 0] : 0x7FFFFFFF;
     int myslotin = -1;
     unsigned int live = nload >= 32 ? 0xFFFFFFFFu : ((1u << nload) - 1u);   // uniform: every thread keeps the same copy
+    const bool lk = LK && a.look;
+    if (lk) {
+        // the columns this panel loads are brought up to date by phase U of this launch (luc_role): wait for its workgroups
+        if (tid == 0) s_stop = luc_spin(&a.ctl_base->cnt_u, (uint32_t)(a.round + 1) * (uint32_t)((m + 63) / 64)) ? 1 : 0;
+        __syncthreads();
+        if (!s_stop) {
+            if (tid == 0) {
+                a.ctl_base->fault = 1;
+                ctl->nsteps = 0; ctl->ndrop = 0; ctl->nnext = 0; ctl->k_next = k0; ctl->k0 = k0; ctl->k1 = k0; ctl->rounds = a.ctl_prev->rounds;
+            }
+            return;
+        }
+    }
     vec v[RPT][NH];
     int Rr[RPT];
     bool act[RPT];
@@ -138,8 +485,13 @@ __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__rest
         Rr[r] = tid + r * T;
         act[r] = (Rr[r] < m) && s_active[Rr[r] < m ? Rr[r] : 0];
         const double *src = a.W + (act[r] ? Rr[r] : 0);
+        if (lk) {   // (uniform) the cells come from phase U of this launch: agent scope
 #pragma unroll
-        for (int c = 0; c < NB; c++) v[r][c / VW][c % VW] = (act[r] && c < nload) ? src[(size_t)__builtin_amdgcn_readlane(myslotcol, c) * ldw] : 0.0;
+            for (int c = 0; c < NB; c++) v[r][c / VW][c % VW] = (act[r] && c < nload) ? luc_ld_agent(&src[(size_t)__builtin_amdgcn_readlane(myslotcol, c) * ldw]) : 0.0;
+        } else {
+#pragma unroll
+            for (int c = 0; c < NB; c++) v[r][c / VW][c % VW] = (act[r] && c < nload) ? src[(size_t)__builtin_amdgcn_readlane(myslotcol, c) * ldw] : 0.0;
+        }
     }
     __syncthreads();   // every thread has taken its rows' `act` from s_active before wave 0's first run clears entries
     // The column loads above are the only global loads of this kernel.  Retire them HERE, with an instruction the compiler's wait
@@ -335,9 +687,31 @@ __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__rest
     }
 #endif
     for (int R = tid; R < m; R += T) a.lpos[R] = s_lpos[R];
+    if (LK && a.look) {
+        // rowstep as this round leaves it (the last writes to it are behind the loop's closing barrier), for the update workgroups that
+        // run beside the next panel
+        for (int R = tid; R < m; R += T) a.rowsnap[R] = s_active[R] ? -1 : a.rowstep[R];
+    }
     // columns still listed: rows that left at steps [joined, k1) hold final values in them (retire / the pivot rows' stores)
     int ndl = 0;
     if (w == 0) {
+        if (LK && a.look) {
+            // the columns the next round's panel will load: its own scan (above), run on the state this round leaves
+            int n = 0;
+            for (int base = k1; base < m && n < NB; base += 64) {
+                const int k = base + lane;
+                bool dense = false;
+                if (k < m) {
+                    const idx_t ur = s_unit[k];
+                    dense = ur == NONE || !s_active[ur];
+                }
+                const unsigned long long mask = __ballot(dense);
+                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                if (dense && n + rank < NB) ctl->next[n + rank] = k;
+                n += __popcll(mask);
+            }
+            if (lane == 0) ctl->nnext = n < NB ? n : NB;
+        } else if (lane == 0) ctl->nnext = 0;
         const bool on = lane < NB && ((live >> lane) & 1u);
         const unsigned long long msk = __ballot(on);
         ndl = __popcll(msk);
@@ -350,7 +724,7 @@ __global__ __launch_bounds__(T) void k_luc_panel_slots(LUArgs a, int32_t *__rest
         const int nd = ndl;
         // (table above): rows that left at steps [joined, k1) hold final values in them (retire / the pivot rows' stores)
         ctl->k0 = k0; ctl->k1 = k1; ctl->k_next = k1; ctl->nsteps = s; ctl->ndrop = nd;
-        ctl->rounds += 1;
+        ctl->rounds = a.ctl_prev->rounds + 1;
     }
 }
 
@@ -516,8 +890,11 @@ __global__ void k_luc_init(LUArgs a) {
         if (a.dense_flag) a.dense_flag[R] = 0;
     }
     if (R == 0) {
-        LUCtl *c = a.ctl;
-        c->k_next = 0; c->k0 = 0; c->k1 = 0; c->nsteps = 0; c->ndrop = 0; c->rounds = 0;
+        for (int t = 0; t < 2; t++) {   // (two: by round parity)
+            LUCtl *c = a.ctl + t;
+            c->k_next = 0; c->k0 = 0; c->k1 = 0; c->nsteps = 0; c->ndrop = 0; c->rounds = 0; c->nnext = 0;
+            c->cnt_x = 0; c->cnt_u = 0; c->cnt_s = 0; c->fault = 0;
+        }
     }
 }
 
@@ -604,13 +981,41 @@ __global__ __launch_bounds__(256) void k_luc_solve_rows(LUArgs a, const int32_t 
 
 // slot form: up to kLucSlotSteps dense steps per round whatever the number of register slots
 constexpr int kLucSlotSteps = 32;
+// `base`: a.ctl / a.Lp / a.Up / a.rowsnap of parity 0 (the other parity behind it); round_base: rounds enqueued for this
+// factorization so far (the parity goes on across the host's batches)
 template <int T, int RPT, int NB>
-static void luc_rounds_slots(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t s) {
-    const int m = a.m;
+static void luc_rounds_slots(const LUArgs &base, int32_t *pivrow, int nrounds, int round_base, hipStream_t s) {
+    const int m = base.m;
+    const int nt = (m + 63) / 64;
+    if (!base.look) {
+        LUArgs a = base;
+        a.ctl_prev = a.ctl; a.Lp_prev = a.Lp; a.Up_prev = a.Up; a.rowsnap_prev = a.rowsnap;
+        for (int r = 0; r < nrounds; r++) {
+            hipLaunchKernelGGL((k_luc_panel_slots<T, RPT, NB, kLucSlotSteps, false>), dim3(1), dim3(T), 0, s, a, pivrow);
+            hipLaunchKernelGGL((k_luc_usolve<kLucSlotSteps>), dim3(nt), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((k_luc_trail<kLucSlotSteps>), dim3(nt, nt), dim3(256), 0, s, a);
+        }
+        return;
+    }
+    // look-ahead: one launch per round = { panel r | U-solve and update of round r-1 } (luc_role)
+    const size_t pstride = (size_t)kLucSlotSteps * (size_t)base.ldw;
+    const int rest = std::max(nt, std::min(255, (nt * nt + std::max(1, T / 256) - 1) / std::max(1, T / 256)));   // (at least the nt workgroups of phases U / S)
     for (int r = 0; r < nrounds; r++) {
-        hipLaunchKernelGGL((k_luc_panel_slots<T, RPT, NB, kLucSlotSteps>), dim3(1), dim3(T), 0, s, a, pivrow);
-        hipLaunchKernelGGL((k_luc_usolve<kLucSlotSteps>), dim3((m + 63) / 64), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((k_luc_trail<kLucSlotSteps>), dim3((m + 63) / 64, (m + 63) / 64), dim3(256), 0, s, a);
+        const int p = (round_base + r) & 1;
+        LUArgs a = base;
+        a.ctl = base.ctl + p; a.ctl_prev = base.ctl + (p ^ 1);
+        a.Lp = base.Lp + p * pstride; a.Lp_prev = base.Lp + (p ^ 1) * pstride;
+        a.Up = base.Up + p * pstride; a.Up_prev = base.Up + (p ^ 1) * pstride;
+        a.rowsnap = base.rowsnap + (size_t)p * m; a.rowsnap_prev = base.rowsnap + (size_t)(p ^ 1) * m;
+        if (!luc_look_ok<T, RPT>()) {   // a panel shape without the update role: the control blocks still alternate (the host reads by parity)
+            a.look = 0;
+            hipLaunchKernelGGL((k_luc_panel_slots<T, RPT, NB, kLucSlotSteps, false>), dim3(1), dim3(T), 0, s, a, pivrow);
+            hipLaunchKernelGGL((k_luc_usolve<kLucSlotSteps>), dim3(nt), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((k_luc_trail<kLucSlotSteps>), dim3(nt, nt), dim3(256), 0, s, a);
+            continue;
+        }
+        a.ctl_base = base.ctl; a.round = round_base + r;
+        if constexpr (luc_look_ok<T, RPT>()) hipLaunchKernelGGL((k_luc_panel_slots<T, RPT, NB, kLucSlotSteps, true>), dim3(1 + rest), dim3(T), 0, s, a, pivrow);
     }
 }
 
@@ -638,7 +1043,7 @@ void launch_luc_pack(const LUArgs &a, const int32_t *dlist, int nd, double *Wd, 
 }
 
 // enqueue `nrounds` rounds; returns the number of kernel launches
-int launch_luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t s) {
+int launch_luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, int round_base, hipStream_t s) {
     const int m = a.m;
     {
         // (threads x rows per thread x register slots: 128 VGPRs per thread at 1024 threads hold 2 x 16 or 4 x 8 columns)
@@ -647,26 +1052,26 @@ int launch_luc_rounds(const LUArgs &a, int32_t *pivrow, int nrounds, hipStream_t
         if (forced >= 0) {
             bool done = true;
             switch (forced) {
-                case 10: if (m <= 2048) luc_rounds_slots<256, 8, 8>(a, pivrow, nrounds, s); else done = false; break;
-                case 11: if (m <= 2048) luc_rounds_slots<512, 4, 16>(a, pivrow, nrounds, s); else done = false; break;
-                case 12: if (m <= 2048) luc_rounds_slots<1024, 2, 16>(a, pivrow, nrounds, s); else done = false; break;
-                case 13: if (m <= 2048) luc_rounds_slots<512, 4, 8>(a, pivrow, nrounds, s); else done = false; break;
-                case 20: if (m <= 1024) luc_rounds_slots<512, 2, 32>(a, pivrow, nrounds, s); else done = false; break;
-                case 21: if (m <= 1024) luc_rounds_slots<256, 4, 16>(a, pivrow, nrounds, s); else done = false; break;
-                case 22: if (m <= 1024) luc_rounds_slots<512, 2, 16>(a, pivrow, nrounds, s); else done = false; break;
-                case 23: if (m <= 1024) luc_rounds_slots<1024, 1, 32>(a, pivrow, nrounds, s); else done = false; break;
-                case 30: if (m <= 512) luc_rounds_slots<256, 2, 32>(a, pivrow, nrounds, s); else done = false; break;
-                case 31: if (m <= 512) luc_rounds_slots<256, 2, 16>(a, pivrow, nrounds, s); else done = false; break;
-                case 32: if (m <= 512) luc_rounds_slots<128, 4, 16>(a, pivrow, nrounds, s); else done = false; break;
+                case 10: if (m <= 2048) luc_rounds_slots<256, 8, 8>(a, pivrow, nrounds, round_base, s); else done = false; break;
+                case 11: if (m <= 2048) luc_rounds_slots<512, 4, 16>(a, pivrow, nrounds, round_base, s); else done = false; break;
+                case 12: if (m <= 2048) luc_rounds_slots<1024, 2, 16>(a, pivrow, nrounds, round_base, s); else done = false; break;
+                case 13: if (m <= 2048) luc_rounds_slots<512, 4, 8>(a, pivrow, nrounds, round_base, s); else done = false; break;
+                case 20: if (m <= 1024) luc_rounds_slots<512, 2, 32>(a, pivrow, nrounds, round_base, s); else done = false; break;
+                case 21: if (m <= 1024) luc_rounds_slots<256, 4, 16>(a, pivrow, nrounds, round_base, s); else done = false; break;
+                case 22: if (m <= 1024) luc_rounds_slots<512, 2, 16>(a, pivrow, nrounds, round_base, s); else done = false; break;
+                case 23: if (m <= 1024) luc_rounds_slots<1024, 1, 32>(a, pivrow, nrounds, round_base, s); else done = false; break;
+                case 30: if (m <= 512) luc_rounds_slots<256, 2, 32>(a, pivrow, nrounds, round_base, s); else done = false; break;
+                case 31: if (m <= 512) luc_rounds_slots<256, 2, 16>(a, pivrow, nrounds, round_base, s); else done = false; break;
+                case 32: if (m <= 512) luc_rounds_slots<128, 4, 16>(a, pivrow, nrounds, round_base, s); else done = false; break;
                 default: done = false;
             }
             if (done) return 3 * nrounds;
         }
 #endif
-        if (m <= 512) luc_rounds_slots<512, 1, 32>(a, pivrow, nrounds, s);
-        else if (m <= 1024) luc_rounds_slots<512, 2, 16>(a, pivrow, nrounds, s);   // (16 slots: C2 1.20 ms / 12 rounds against 1.34 ms / 7 rounds with 32: the branch-free slot loop costs per slot)
-        else if (m <= 2048) luc_rounds_slots<1024, 2, 16>(a, pivrow, nrounds, s);
-        else luc_rounds_slots<1024, 4, 8>(a, pivrow, nrounds, s);
+        if (m <= 512) luc_rounds_slots<512, 1, 32>(a, pivrow, nrounds, round_base, s);
+        else if (m <= 1024) luc_rounds_slots<512, 2, 16>(a, pivrow, nrounds, round_base, s);   // (16 slots: C2 1.20 ms / 12 rounds against 1.34 ms / 7 rounds with 32: the branch-free slot loop costs per slot)
+        else if (m <= 2048) luc_rounds_slots<1024, 2, 16>(a, pivrow, nrounds, round_base, s);
+        else luc_rounds_slots<1024, 4, 8>(a, pivrow, nrounds, round_base, s);
         return 3 * nrounds;
     }
     return 0;

@@ -175,7 +175,7 @@ def test_blocked_lu_equals_per_column_lu_bitwise(m, seed):
     as the one-launch-per-column schedule (simplex_kernels.hip k_lu_step), which the small cases pin to the oracle."""
     c, A, b = synth.dense_lp_standard_form(m, seed)
     res = []
-    for blocked in (3, 1, 1, 0):   # compressed rounds with the slot panel (default), blocked panels (twice: the slot of the retired sorted panel), one launch per column
+    for blocked in (3, 2, 1, 0):   # compressed rounds with the look-ahead schedule (default), the same with the whole update behind each panel, blocked panels, one launch per column
         cx = lp.Context(lu_blocked=blocked)
         try:
             rl = cx.upload(c, A, b)
@@ -187,7 +187,7 @@ def test_blocked_lu_equals_per_column_lu_bitwise(m, seed):
         assert r.status == lp.OK == res[3].status
         assert np.array_equal(r.basis, res[3].basis)
         assert np.array_equal(r.x, res[3].x) and r.z == res[3].z
-    assert res[0].stats["lu_rounds"] > 0 and res[1].stats["lu_rounds"] == 0 == res[3].stats["lu_rounds"]   # (rounds: the compressed schedule only)
+    assert res[0].stats["lu_rounds"] == res[1].stats["lu_rounds"] > 0 and res[2].stats["lu_rounds"] == 0 == res[3].stats["lu_rounds"]   # (rounds: the compressed schedules only; the look-ahead changes when an update runs, not what a round is)
     assert res[0].stats["lu_dense_steps"] == res[1].stats["lu_dense_steps"] == res[2].stats["lu_dense_steps"]
     # the unit-column fast path of the panel kernel must be deterministic (it once raced: repeat the solve)
     cx = lp.Context()
