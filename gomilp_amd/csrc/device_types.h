@@ -295,7 +295,7 @@ struct LUArgs {
     int32_t *rowsnap;           // rowstep as this round leaves it (the panel of the next round changes rowstep while this round's update still reads it)
     const int32_t *rowsnap_prev;
     LUCtl *ctl_base;            // control block 0 (counters, fault flag)
-    int32_t round, pad3;        // rounds launched for this factorization before this one
+    int32_t round, pad3;        // rounds launched for this factorization before this one; pad3: diagnostic flavour, fault injection (the U-solve workgroup never arrives)
 };
 
 }  // namespace gomilp

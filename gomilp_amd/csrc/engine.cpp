@@ -85,7 +85,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "bt_old") bt_old_ = v ? 1 : 0;
     else if (key == "bt_upd_valu") bt_upd_valu_ = v ? 1 : 0;
 #ifdef GOMILP_DEBUG
-    else if (key == "bt_fault") bt_fault_ = v ? 1 : 0;   // fault injection: diagnostic flavour only
+    else if (key == "bt_fault") bt_fault_ = v;   // fault injection, diagnostic flavour only: 1 a workgroup of the block / loop kernels, 2 the U-solve workgroup of the look-ahead LU
 #endif
     else if (key == "general_device") general_device_ = v ? 1 : 0;
     else if (key == "bt_groups") { if (v != -1 && v != 0 && v != 2 && v != 4 && v != 8 && v != 16) return GOMILP_ERR_BAD_SHAPE; bt_groups_ = v; }
@@ -792,7 +792,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     a.slots = 1; a.look = (lu_blocked_ >= 3 && m > 768) ? 1 : 0;
     a.ctl_prev = a.ctl; a.Lp_prev = a.Lp; a.Up_prev = a.Up;
     a.rowsnap = w.rowstep + w.cap_m; a.rowsnap_prev = a.rowsnap;   // (launch_luc_rounds sets the round's parity)
-    a.ctl_base = a.ctl; a.round = 0; a.pad3 = 0;
+    a.ctl_base = a.ctl; a.round = 0; a.pad3 = bt_fault_ == 2 ? 1 : 0;
     w.st_host->lu_singular = 0;
     sync_state_to_device();
     lu_rounds_ = 0;
@@ -827,7 +827,7 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
             // basis, with the whole update behind each panel
             if (attempt > 0 || !a.look) return GOMILP_ERR_DEVICE;
             a.look = 0;
-            lu_look_faults_++;
+            lu_look_faults_++; lu_look_fault_ = true;
             if (compressed != transpose) launch_luc_gather(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
             else {
                 if (transpose) HIP_TRY(hipMemsetAsync(w.W, 0, (size_t)m * ldw * sizeof(double), stream_));
@@ -1091,10 +1091,11 @@ int Engine::solve_locked(int64_t id, double tol, const int64_t *initial_basic, d
         st->seconds_total = now_s() - t0; st->kernel_launches = launches_;
         st->seconds_final_device = fs_device_; st->seconds_final_host = fs_host_;
         st->lu_dense_steps = lu_dense_; st->lu_rounds = lu_rounds_;
+        if (lu_look_fault_) st->device_retries = 1;   // (the final solve was repeated with the plain LU schedule)
         return code;
     };
     launches_ = 0;
-    fs_device_ = fs_host_ = 0;
+    fs_device_ = fs_host_ = 0; lu_look_fault_ = false;
     last_trace_.clear();
     last_trace_total_ = 0;
     if (P.verify_status != GOMILP_OK) {  // simplex.go:94-100
@@ -1504,7 +1505,7 @@ int Engine::finish_from_basis(int64_t id, const int32_t *basic_in, const double 
     if (opt_f) *opt_f = std::numeric_limits<double>::quiet_NaN();
     if (id < 0 || (size_t)id >= problems_.size() || !problems_[id] || !opt_f || !opt_x || !has_x || !basic_in || !xb_updated) return GOMILP_ERR_BAD_SHAPE;
     const Problem &P = *problems_[id];
-    launches_ = 0; fs_device_ = fs_host_ = 0;
+    launches_ = 0; fs_device_ = fs_host_ = 0; lu_look_fault_ = false;
     int rc = ensure_work(P.m, P.n + 1);
     if (rc != GOMILP_OK) return rc;
     std::vector<int32_t> basic(basic_in, basic_in + P.m);
@@ -1514,6 +1515,7 @@ int Engine::finish_from_basis(int64_t id, const int32_t *basic_in, const double 
     st->seconds_total = now_s() - t0; st->kernel_launches = launches_;
     st->seconds_final_device = fs_device_; st->seconds_final_host = fs_host_;
     st->lu_dense_steps = lu_dense_; st->lu_rounds = lu_rounds_;
+    if (lu_look_fault_) st->device_retries = 1;
     return rc;
 }
 

@@ -158,6 +158,7 @@ class Engine {
     std::unique_ptr<Work> w_;
     // knobs
     int64_t lu_look_faults_ = 0;   // final solves repeated with the plain schedule after a look-ahead launch gave up a wait
+    bool lu_look_fault_ = false;   // ... in the running solve (stats.device_retries)
     int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 3, tableau_ = 1, blocked_ = 1, block_k_ = 0,  // block_k_ 0 = auto
             bt_nt_ = 0, bt_old_ = 0, bt_stamps_ = 0, bt_upd_valu_ = 0, bt_fault_ = 0, general_device_ = 1, bt_groups_ = 0,   // bt_groups_: -1 never, 0 by shape, 2 / 4 / 8 forced
             bt_lag_ = 1,       // persistent loop kernel where the multi-workgroup block kernel runs (0: block kernel + update launches)

@@ -243,7 +243,7 @@ BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int
     a.nt_force = (int)bt_nt_; a.old_only = bt_old_ ? 1 : 0;
     a.stamps = bt_stamps_ ? w.stamps : nullptr;
     a.upd_valu = bt_upd_valu_ ? 1 : 0;
-    a.fault = bt_fault_ ? 1 : 0;
+    a.fault = bt_fault_ == 1 ? 1 : 0;
     // degenerate vertices decided on a fresh gonum-order x_B: by default for bases of up to 256 rows, and for
     // every start that is not a slack basis (equality rows: a tree's repeated branch rows make nearly dependent tableau rows
     // there, and a pivot on their 1e-12 drift walks into a singular basis)

@@ -63,7 +63,7 @@ __device__ unsigned long long g_luc_stamps[4 * 16];
 #else
 #define LUC_STAMP(S) do { } while (0)
 #endif
-constexpr int kLucSpinLimit = 600000;   // polls (~1.5 us each)
+constexpr int kLucSpinLimit = 200000;   // polls (1.5 us each and more: seconds, against the milliseconds another kernel can hold the device)
 __device__ __forceinline__ bool luc_spin(const uint32_t *p, uint32_t target) {
     for (int it = 0; it < kLucSpinLimit; it++) {
         const uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -239,6 +239,10 @@ __device__ void luc_role(const LUArgs &a) {
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+#ifdef GOMILP_DEBUG
+                if (a.pad3) ok = false;   // fault injection: this workgroup never arrives, the others run out of patience
+                else
+#endif
                 if (tid == 0) __hip_atomic_fetch_add(&base->cnt_x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 if (tid == 0) s_go = luc_spin(&base->cnt_x, (uint32_t)(a.round + 1)) ? 1 : 0;
