@@ -150,7 +150,13 @@ gomilp_pool *gomilp_pool_create(int device, int workers, int *status) {
     if (device >= n || workers < 1 || workers > 64) { if (status) *status = device >= n ? GOMILP_ERR_DEVICE : GOMILP_ERR_BAD_SHAPE; return nullptr; }
     gomilp_pool *p = new gomilp_pool;
     p->device = device;
-    for (int w = 0; w < workers; w++) { p->eng.emplace_back(new Engine(device)); p->root.push_back(-1); }
+    for (int w = 0; w < workers; w++) {
+        p->eng.emplace_back(new Engine(device));
+        p->root.push_back(-1);
+        // the workers finish the relaxations of a wave side by side, next to the batched schedule's own persistent launches: their final
+        // solves keep the LU schedule that waits for nobody (lu_compressed.hip: look-ahead launches wait for their own workgroups)
+        p->eng.back()->set("lu_look", 0);
+    }
     p->batch.reset(new BatchEngine(device));
     for (int w = 0; w < workers; w++) p->threads.emplace_back([p, w] { p->worker(w); });
     if (status) *status = GOMILP_OK;

@@ -60,6 +60,14 @@ int Engine::loop_acquire(int dev, int weight) {
     for (int i = 0; i < 4; i++) if (!L.busy[i]) { L.busy[i] = true; return i; }
     return 0;
 }
+bool Engine::loop_try_acquire_all(int dev) {
+    LoopSlots &L = loop_slots(dev);
+    std::lock_guard<std::mutex> lk(L.mu);
+    if (L.used != 0 || L.big_waiting != 0) return false;
+    L.used = 4;
+    for (bool &b2 : L.busy) b2 = true;
+    return true;
+}
 void Engine::loop_release(int dev, int weight, int slot) {
     LoopSlots &L = loop_slots(dev);
     {
@@ -78,6 +86,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "max_pivots") max_pivots_ = v < 0 ? 0 : v;
     else if (key == "sample_events") sample_events_ = v < 0 ? 0 : v;
     else if (key == "fused") fused_ = v ? 1 : 0;
+    else if (key == "lu_look") lu_look_ = v ? 1 : 0;
     else if (key == "lu_blocked") lu_blocked_ = v < 0 ? 0 : (v > 2 ? 3 : v);  // 0 per column, 1 blocked panels, 2 compressed rounds (slot panel), 3 the same with the look-ahead schedule (default; lu_compressed.hip)
     else if (key == "tableau") tableau_ = v ? 1 : 0;
     else if (key == "blocked") blocked_ = v ? 1 : 0;
@@ -789,7 +798,18 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     a.ctl = w.luctl; a.Lp = w.luLp; a.Up = w.luUp;
     // look-ahead schedule: where a factorization takes many rounds (measured: 2048 rows 23 rounds 2.20 -> 2.05 ms, 1000 rows 12 rounds
     // 1.10 -> 1.03 ms on the device; 520-row children, 4 rounds: 0.63 -> 0.65 ms, and a wave runs dozens of them side by side)
-    a.slots = 1; a.look = (lu_blocked_ >= 3 && m > 768) ? 1 : 0;
+    // Its launches wait for their own workgroups (bounded), like the loop kernels: two such launches side by side, or one beside a loop
+    // kernel, can hold each other's workgroups off the CUs until a wait gives up (measured: four metric LPs finishing together, two of
+    // four factorizations fell back after ~50 ms).  So it runs only while this engine holds the device's loop slots, all of them, and
+    // only if they are free right now; a pool's workers never ask (knob lu_look).
+    a.slots = 1; a.look = (lu_blocked_ >= 3 && lu_look_ && m > 768 && compressed) ? 1 : 0;
+    struct LookSlot {
+        int dev; bool held;
+        LookSlot(int d, bool want) : dev(d), held(want && Engine::loop_try_acquire_all(d)) {}
+        ~LookSlot() { drop(); }
+        void drop() { if (held) Engine::loop_release(dev, 4, 0); held = false; }
+    } look_slot(device_, a.look != 0);
+    if (!look_slot.held) a.look = 0;
     a.ctl_prev = a.ctl; a.Lp_prev = a.Lp; a.Up_prev = a.Up;
     a.rowsnap = w.rowstep + w.cap_m; a.rowsnap_prev = a.rowsnap;   // (launch_luc_rounds sets the round's parity)
     a.ctl_base = a.ctl; a.round = 0; a.pad3 = bt_fault_ == 2 ? 1 : 0;
@@ -822,12 +842,14 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
                 if (batch > 64) batch = 64;
             }
             lu_rounds_ = last->rounds;
+            look_slot.drop();   // (the rounds are behind the last sync)
             if (!w.luctl_host[0].fault) break;
             // a wait inside a look-ahead launch ran out of patience (its workgroups never became resident together): once more, from the
             // basis, with the whole update behind each panel
             if (attempt > 0 || !a.look) return GOMILP_ERR_DEVICE;
             a.look = 0;
             lu_look_faults_++; lu_look_fault_ = true;
+            if (GOMILP_DBG_ENV("GOMILP_DEBUG_LOOP")) fprintf(stderr, "final_solve: a look-ahead launch gave up a wait (m %d, rounds enqueued %d, cnt_x %u cnt_u %u cnt_s %u): plain schedule\n", m, enq, w.luctl_host[0].cnt_x, w.luctl_host[0].cnt_u, w.luctl_host[0].cnt_s);
             if (compressed != transpose) launch_luc_gather(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
             else {
                 if (transpose) HIP_TRY(hipMemsetAsync(w.W, 0, (size_t)m * ldw * sizeof(double), stream_));

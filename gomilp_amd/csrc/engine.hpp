@@ -51,6 +51,7 @@ class Engine {
     int device() const { return device_; }
     static int loop_acquire(int dev, int weight);          // slots for persistent loop kernels on a device (engine.cpp): returns the slot
     static void loop_release(int dev, int weight, int slot);
+    static bool loop_try_acquire_all(int dev);             // the whole device, if nobody holds a slot right now (no waiting); release: loop_release(dev, 4, 0)
     int set(const std::string &key, int64_t v);
 
     // lazy_host: do not keep a host copy of a large A at upload (the flat call: the context is the caller's alone, and the copy is
@@ -159,6 +160,7 @@ class Engine {
     // knobs
     int64_t lu_look_faults_ = 0;   // final solves repeated with the plain schedule after a look-ahead launch gave up a wait
     bool lu_look_fault_ = false;   // ... in the running solve (stats.device_retries)
+    int64_t lu_look_ = 1;          // knob lu_look: 0 = never the look-ahead schedule (the workers of a pool)
     int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 3, tableau_ = 1, blocked_ = 1, block_k_ = 0,  // block_k_ 0 = auto
             bt_nt_ = 0, bt_old_ = 0, bt_stamps_ = 0, bt_upd_valu_ = 0, bt_fault_ = 0, general_device_ = 1, bt_groups_ = 0,   // bt_groups_: -1 never, 0 by shape, 2 / 4 / 8 forced
             bt_lag_ = 1,       // persistent loop kernel where the multi-workgroup block kernel runs (0: block kernel + update launches)
