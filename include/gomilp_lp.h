@@ -65,8 +65,9 @@ typedef struct gomilp_lp_stats {
     int64_t lu_rounds;           /* panel rounds of the compressed LU schedule (0 for the other schedules) */
     int64_t art_exchanges;       /* 1 when a zero-level artificial was exchanged out of the basis after Phase I (simplex.go:581-606) */
     int64_t cond_fallbacks;      /* exact condition-number evaluations made because a cheap guard was near a threshold */
-    int64_t device_retries;      /* 1 when a transient device condition (a workgroup of the multi-workgroup block kernel was not
-                                    resident in time) made the engine repeat the solve on the single-workgroup kernels */
+    int64_t device_retries;      /* 1 when a transient device condition (a workgroup of the multi-workgroup block kernel, or of a look-ahead
+                                    launch of the final solve's LU, was not resident in time) made the engine repeat the solve on the
+                                    single-workgroup kernels, resp. the factorization with the plain LU schedule */
     double cond1_final;          /* exact kappa_1 / kappa_inf of the basis the Phase-II loop ended with, from the resident tableau (slack-basis */
     double condinf_final;        /* starts beyond 64 rows; 0: not evaluated): kappa_1 > 1e16 -> GOMILP_ERR_CONDITION like mat/lu.go:321 */
 } gomilp_lp_stats;
@@ -115,7 +116,9 @@ int gomilp_ctx_device(const gomilp_ctx *ctx);
  * workgroups), "bt_old", "bt_stamps", "sample_events"; of the persistent loop kernel: "bt_lag" (0: the launch pairs of round 2),
  * "loop_chunk" (pivots per launch), "loop_g" (8 / 16 pivot workgroups), "loop_k" (8 / 12 / 16 pivots per block), "loop_upd"
  * (update workgroups that take part), "loop_grid", "poll_delay"; of the bit-exact final solve: "lu_blocked" (3 default: compressed rounds
- * with the slot panel, 2: with the sorted register panel, 1: blocked panels, 0: one launch per column — all bit-identical).  The
+ * in the look-ahead schedule — one launch per round, the panel beside the previous round's update — for bases beyond 768 rows while the
+ * engine holds the device's loop slots, 2: compressed rounds with the whole update behind each panel, 1: blocked panels, 0: one launch per
+ * column — all bit-identical), "lu_look" (0: never the look-ahead schedule; a pool sets it on its workers).  The
  * diagnostic flavour of the library (libgomilp_hip_debug.so, GOMILP_DEBUG_BUILD=1) adds "bt_fault" and the GOMILP_DEBUG_* / GOMILP_LUC_*
  * environment hooks; the product library has none of them.  Knobs that DO change what is decided, and how faithfully:
  * "exact_degenerate" (0 never, 1 default: bases of up to 256 rows, non-slack starts and badly scaled inputs, 2 always — degenerate,
