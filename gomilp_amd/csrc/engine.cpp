@@ -760,12 +760,22 @@ int Engine::run_loop_fused(const Problem &P, int phase, double tol, int nn, cons
 // to be a unit vector.  rhs_host (m entries, by basis position; default b): the right-hand side.
 int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *singular, const int32_t *basic_host, bool transpose,
                         const double *rhs_host) {
+    int rc = lu_factor(P, singular, basic_host, transpose);
+    if (rc != GOMILP_OK) return rc;
+    return lu_solve(P, x, rhs_host);
+}
+
+// The factorization half of the final solve: gather, gonum-order LU on the device, the packed factors on the host (and, for the large
+// bases, what the row kernel needs on the device).  Everything lu_solve needs stays in lu_cache_ / the work buffers until the next
+// factorization: an exact step solves for x_B, for the entering column and for every Bland candidate from ONE factorization of ab
+// (the reference factors again each time, simplex.go:289,315,356 — same matrix, same bits).
+int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_host, bool transpose) {
     Work &w = *w_;
     const double tf0 = now_s();
     const int m = P.m, ldw = P.ld;
     int nonunit = 0;
     const bool compressed = lu_blocked_ >= 2 && lu_compressed_supported(m);
-    const double *rhs = rhs_host ? rhs_host : P.hb.data();
+    lu_cache_.valid = false;
     // the compressed schedule keeps L/U column-major (lu_compressed.hip), the other two row-major
     if (compressed != transpose) launch_luc_gather(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
     else {
@@ -878,12 +888,6 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
     // large bases: only the nd x nd part that couples the dense positions goes to the host (lu_compressed.hip,
     // k_luc_pack_dense / k_luc_solve_rows); small ones take one host pass over all rows (one round trip fewer)
     const bool split = compressed && m >= 1024 && nd > 0;
-    const double *rhs_dev = P.db;
-    if (split && rhs_host) {   // the row kernel reads the right-hand side on the device
-        int rcr = stage_upload(w.move, rhs_host, (size_t)m * sizeof(double));
-        if (rcr != GOMILP_OK) return rcr;
-        rhs_dev = w.move;
-    }
     if (split) launch_luc_pack_dense(a, w.dlist, nd, w.rho, Wd, w.ludiag, stream_);
     else if (compressed) launch_luc_pack(a, w.dlist, nd, Wd, w.ludiag, stream_);
     else launch_lu_pack(a, w.dlist, nd, Wd, w.ludiag, stream_);
@@ -923,10 +927,37 @@ int Engine::final_solve(const Problem &P, int, std::vector<double> &x, bool *sin
         fprintf(stderr, "final_solve: singular (transpose %d, m %d, nd %d, rounds %lld, lu_singular flag %d, logdet %g, zero diagonals %d, min |u_ii| %g, compressed %d)\n",
                 (int)transpose, m, nd, (long long)lu_rounds_, (int)w.st_host->lu_singular, logdet, nz, dmin, (int)compressed);
     }
+    lu_cache_.m = m; lu_cache_.nd = nd; lu_cache_.split = split; lu_cache_.singular = *singular;
+    lu_cache_.phys = phys; lu_cache_.dl = dl;
+    lu_cache_.diag.assign(diag, diag + m);   // (h_vec is everybody's landing buffer)
+    lu_cache_.args = a;
+    lu_cache_.valid = true;
+    fs_host_ += now_s() - tf1;
+    return GOMILP_OK;
+}
+
+// The solve half (Dgetrs, lapack/gonum/dgetrs.go:37-45) from the factors lu_factor left: rhs_host (m entries, by basis position;
+// default b).  A singular factorization gives zeros (the caller has the flag).
+int Engine::lu_solve(const Problem &P, std::vector<double> &x, const double *rhs_host) {
+    Work &w = *w_;
+    if (!lu_cache_.valid || lu_cache_.m != P.m) return GOMILP_ERR_DEVICE;
+    const double tf1 = now_s();
+    const int m = P.m, nd = lu_cache_.nd;
+    const bool split = lu_cache_.split;
+    const std::vector<int32_t> &phys = lu_cache_.phys, &dl = lu_cache_.dl;
+    const double *diag = lu_cache_.diag.data();
+    const LUArgs &a = lu_cache_.args;
+    const double *rhs = rhs_host ? rhs_host : P.hb.data();
     x.assign(m, 0.0);
-    if (*singular) return GOMILP_OK;
+    if (lu_cache_.singular) return GOMILP_OK;
     auto term = [](double bi, double va, double xk) { return va != 0 ? (-va) * xk + bi : bi; };
     if (split) {
+        const double *rhs_dev = P.db;
+        if (rhs_host) {   // the row kernel reads the right-hand side on the device
+            int rcr = stage_upload(w.move, rhs_host, (size_t)m * sizeof(double));
+            if (rcr != GOMILP_OK) return rcr;
+            rhs_dev = w.move;
+        }
         // coupled part on the host: row s of h_W is dense position dl[s] restricted to the dense columns
         std::vector<double> xdl(nd), xdu(nd);
         // Dtrsm(Left, Lower, NoTrans, Unit): a row is one chain of dependent rounded additions in ascending t; four rows run side by

@@ -132,6 +132,16 @@ class Engine {
                  int32_t *has_x, int64_t *basis_out, gomilp_lp_stats *st);
     int final_solve(const Problem &P, int ncols_rows, std::vector<double> &xb_exact, bool *singular, const int32_t *basic_host = nullptr,
                     bool transpose = false, const double *rhs_host = nullptr);
+    // its two halves (engine.cpp): one factorization, any number of right-hand sides
+    int lu_factor(const Problem &P, bool *singular, const int32_t *basic_host = nullptr, bool transpose = false);
+    int lu_solve(const Problem &P, std::vector<double> &x, const double *rhs_host = nullptr);
+    struct LuCache {
+        bool valid = false, split = false, singular = false;
+        int m = 0, nd = 0;
+        std::vector<int32_t> phys, dl;   // physical row at a logical position; the positions whose step did arithmetic
+        std::vector<double> diag;        // u_ii by physical row
+        LUArgs args;
+    } lu_cache_;
     // one iteration of the reference on fresh solves (engine_tableau.cpp): the decision a degenerate or tied pivot needs
     int exact_step(const Problem &P, int phase, double tol, int nn, int *q_out, int *p_out, gomilp_lp_stats *st);
     int cond_check(const Problem &P, int nn, double *k1, double *kinf);

@@ -320,8 +320,11 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
     HIP_TRY(sync_stream());
     for (int j = 0; j < nn; j++) r[j] = w.h_vec[j];
     // x_B of this iteration (simplex.go:289 of the previous one): resident from here on
-    if ((rc = final_solve(P, n, xb, &sing, basic.data())) != GOMILP_OK) return -rc;
+    // (ONE factorization of ab serves x_B, the entering column and every Bland candidate below: the reference factors the same matrix
+    // again each time, simplex.go:289 / :315 / :356 — same bits; Engine::lu_factor / lu_solve)
+    if ((rc = lu_factor(P, &sing, basic.data())) != GOMILP_OK) return -rc;
     if (sing) { if (GOMILP_DBG_ENV("GOMILP_DEBUG_LOOP")) fprintf(stderr, "exact_step: ab singular for x_B (phase %d, m %d)\n", phase, m); return -GOMILP_ERR_LINSOLVE; }
+    if ((rc = lu_solve(P, xb)) != GOMILP_OK) return -rc;
     {
         std::vector<double> xpad(P.ld, 0.0);
         std::copy(xb.begin(), xb.begin() + m, xpad.begin());
@@ -334,8 +337,7 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
     HIP_TRY(hipMemcpyAsync(w.h_vec, P.dAt + (size_t)nonbasic[q] * P.ld, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(sync_stream());
     for (int i = 0; i < m; i++) col[i] = w.h_vec[i];
-    if ((rc = final_solve(P, n, dsol, &sing, basic.data(), false, col.data())) != GOMILP_OK) return -rc;
-    if (sing) return -GOMILP_ERR_LINSOLVE;
+    if ((rc = lu_solve(P, dsol, col.data())) != GOMILP_OK) return -rc;
     // Accuracy of the resident tableau: its column q against the fresh one.  On badly scaled LPs (entries over 1e19) the updated
     // tableau loses digits within a few hundred pivots, its ratio tests then leave the reference's path and may never end; beyond
     // 1e-6 of the column's size the tableau is rebuilt from a fresh inverse of the basis (B^-1 on the host, T = B^-1 A_N as one
@@ -393,8 +395,7 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
         if (r[i] > -1e-14) continue;            // blandNegTol, :352
         const int var = nonbasic[i];
         for (int t = 0; t < m; t++) col[t] = var < n ? P.hA[(size_t)t * n + var] : art[t];
-        if ((rc = final_solve(P, n, dsol, &sing, basic.data(), false, col.data())) != GOMILP_OK) return -rc;
-        if (sing) return -GOMILP_ERR_LINSOLVE;
+        if ((rc = lu_solve(P, dsol, col.data())) != GOMILP_OK) return -rc;
         bool neg = false;
         for (int t = 0; t < m; t++) {
             double d = -dsol[t];
