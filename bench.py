@@ -738,7 +738,7 @@ def main() -> int:
         out["degenerate_trees"] = {"workload": "240 integer-data MILPs (2-5 rows + branch rows, duplicate rows; gomilp_amd/synth.py degenerate_integer_milp), FIFO B&B, 15 nodes each",
                                    "trees": len(fam), "relaxations": int(nrel), "seconds": td, "relaxations_per_s": nrel / td,
                                    "note": "bases of up to 64 rows: every relaxation on a worker's single-relaxation engine with the pivot-by-pivot condition replay and the "
-                                           "exact-degenerate steps (three gonum-order device LUs per degenerate pivot); tests/test_gpu_golden.py checks every node of these trees "
+                                           "exact-degenerate steps (two gonum-order device LUs per degenerate pivot: ab^T, and ab once for x_B / the entering column / the Bland candidates); tests/test_gpu_golden.py checks every node of these trees "
                                            "bit for bit against the oracle tree"}
     emit(out)
     prob.free()
