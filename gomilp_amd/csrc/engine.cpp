@@ -826,6 +826,27 @@ int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_hos
     w.st_host->lu_singular = 0;
     sync_state_to_device();
     lu_rounds_ = 0;
+    int32_t *h_dense = w.h_idx + w.cap_m;   // landing place of the dense-step flags (h_idx holds nm + nc entries; lpos lands in front)
+    // Small bases: the packed factors are asked for together with the control block, in ONE host round trip — all m columns (the
+    // compact list of dense columns would need the flags first; a unit-column step has zero multipliers and zero off-diagonal U
+    // entries, which the solves skip like gonum's do: same bits, m*m instead of m*nd doubles over PCIe).  An exact step factors
+    // twice and small trees are made of round trips.  Should the batch of rounds turn out too short, the pack is simply repeated.
+    bool oneshot = compressed && m <= 128;
+    std::vector<int32_t> dl;
+    auto enqueue_pack = [&](int nd2) -> int {
+        int rcd = stage_upload(w.dlist, dl.data(), (size_t)nd2 * sizeof(int32_t));
+        if (rcd != GOMILP_OK) return rcd;
+        const bool split2 = compressed && m >= 1024 && nd2 > 0;
+        if (split2) launch_luc_pack_dense(a, w.dlist, nd2, w.rho, w.Wd, w.ludiag, stream_);
+        else if (compressed) launch_luc_pack(a, w.dlist, nd2, w.Wd, w.ludiag, stream_);
+        else launch_lu_pack(a, w.dlist, nd2, w.Wd, w.ludiag, stream_);
+        launches_++;
+        if (nd2) HIP_TRY(hipMemcpyAsync(w.h_W, w.Wd, (size_t)(split2 ? nd2 : m) * nd2 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipMemcpyAsync(w.h_vec, w.ludiag, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipMemcpyAsync(w.h_idx, w.lpos, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+        return GOMILP_OK;
+    };
     if (compressed) {
         // rounds are data dependent (lu_compressed.hip): enqueue a batch, read the control block, repeat.  The first
         // batch is sized from the number of columns that are dense for sure.
@@ -844,10 +865,17 @@ int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_hos
                 enq += batch;
                 HIP_TRY(hipMemcpyAsync(w.luctl_host, w.luctl, 2 * sizeof(LUCtl), hipMemcpyDeviceToHost, stream_));
                 // the dense-step flags ride along (final once k_next == m): no separate round trip for them
-                HIP_TRY(hipMemcpyAsync(w.h_idx, w.denseflag, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+                HIP_TRY(hipMemcpyAsync(h_dense, w.denseflag, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+                if (oneshot) {
+                    dl.resize(m);
+                    for (int k = 0; k < m; k++) dl[k] = k;
+                    int rcp = enqueue_pack(m);
+                    if (rcp != GOMILP_OK) return rcp;
+                }
                 HIP_TRY(sync_stream());
                 last = w.luctl_host + (a.look ? ((enq - 1) & 1) : 0);
                 if (w.luctl_host[0].fault || last->k_next >= m) break;
+                oneshot = false;   // (the batch was too short: that pack came too early)
                 batch = std::max(4, (int)(((int64_t)(m - last->k_next) * last->rounds) / std::max(1, last->k_next)) + 2);
                 if (batch > 64) batch = 64;
             }
@@ -857,7 +885,7 @@ int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_hos
             // a wait inside a look-ahead launch ran out of patience (its workgroups never became resident together): once more, from the
             // basis, with the whole update behind each panel
             if (attempt > 0 || !a.look) return GOMILP_ERR_DEVICE;
-            a.look = 0;
+            a.look = 0; oneshot = false;
             lu_look_faults_++; lu_look_fault_ = true;
             if (GOMILP_DBG_ENV("GOMILP_DEBUG_LOOP")) fprintf(stderr, "final_solve: a look-ahead launch gave up a wait (m %d, rounds enqueued %d, cnt_x %u cnt_u %u cnt_s %u): plain schedule\n", m, enq, w.luctl_host[0].cnt_x, w.luctl_host[0].cnt_u, w.luctl_host[0].cnt_s);
             if (compressed != transpose) launch_luc_gather(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);
@@ -871,32 +899,33 @@ int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_hos
     // Only the columns whose elimination step did arithmetic carry non-zero L / off-diagonal U entries (a unit-column
     // step has zero multipliers and its column is zero in every earlier pivot row), so the host solves need those
     // columns and the diagonal only: m*(nd+1) doubles cross PCIe instead of m*m.
-    std::vector<int32_t> dl;
-    if (blocked) {
-        if (!compressed) {
-            HIP_TRY(hipMemcpyAsync(w.h_idx, w.denseflag, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-            HIP_TRY(sync_stream());
-        }
-        for (int k = 0; k < m; k++) if (w.h_idx[k]) dl.push_back(k);
+    int nd;
+    bool split;
+    int ndense = 0;   // steps that did arithmetic (stats)
+    if (oneshot) {    // everything is on the host already
+        nd = m; split = false;
+        for (int k = 0; k < m; k++) ndense += h_dense[k] != 0;
     } else {
-        for (int k = 0; k < m; k++) dl.push_back(k);
+        dl.clear();
+        if (blocked) {
+            if (!compressed) {
+                HIP_TRY(hipMemcpyAsync(h_dense, w.denseflag, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+                HIP_TRY(sync_stream());
+            }
+            for (int k = 0; k < m; k++) if (h_dense[k]) dl.push_back(k);
+        } else {
+            for (int k = 0; k < m; k++) dl.push_back(k);
+        }
+        nd = (int)dl.size();
+        ndense = nd;
+        // large bases: only the nd x nd part that couples the dense positions goes to the host (lu_compressed.hip,
+        // k_luc_pack_dense / k_luc_solve_rows); small ones take one host pass over all rows (one round trip fewer)
+        split = compressed && m >= 1024 && nd > 0;
+        int rcp = enqueue_pack(nd);
+        if (rcp != GOMILP_OK) return rcp;
+        HIP_TRY(sync_stream());
     }
-    const int nd = (int)dl.size();
-    lu_dense_ = nd;
-    { int rcd = stage_upload(w.dlist, dl.data(), (size_t)nd * sizeof(int32_t)); if (rcd != GOMILP_OK) return rcd; }
-    double *Wd = w.Wd;
-    // large bases: only the nd x nd part that couples the dense positions goes to the host (lu_compressed.hip,
-    // k_luc_pack_dense / k_luc_solve_rows); small ones take one host pass over all rows (one round trip fewer)
-    const bool split = compressed && m >= 1024 && nd > 0;
-    if (split) launch_luc_pack_dense(a, w.dlist, nd, w.rho, Wd, w.ludiag, stream_);
-    else if (compressed) launch_luc_pack(a, w.dlist, nd, Wd, w.ludiag, stream_);
-    else launch_lu_pack(a, w.dlist, nd, Wd, w.ludiag, stream_);
-    launches_++;
-    if (nd) HIP_TRY(hipMemcpyAsync(w.h_W, Wd, (size_t)(split ? nd : m) * nd * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipMemcpyAsync(w.h_vec, w.ludiag, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipMemcpyAsync(w.h_idx, w.lpos, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(sync_stream());
+    lu_dense_ = ndense;
     HIP_TRY(hipGetLastError());
     const double tf1 = now_s();
     fs_device_ += tf1 - tf0;

@@ -334,9 +334,13 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
     const int64_t q = min_idx(r.data(), nn);   // simplex.go:247
     if (r[q] >= -tol) return 1;                // :248
     // computeMove (:306-342): d = -solve(ab, A[:, entering])
-    HIP_TRY(hipMemcpyAsync(w.h_vec, P.dAt + (size_t)nonbasic[q] * P.ld, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(sync_stream());
-    for (int i = 0; i < m; i++) col[i] = w.h_vec[i];
+    if (!P.hA.empty() && nonbasic[q] < n) {   // (a host copy of A is there: no round trip for the entering column)
+        for (int i = 0; i < m; i++) col[i] = P.hA[(size_t)i * n + nonbasic[q]];
+    } else {
+        HIP_TRY(hipMemcpyAsync(w.h_vec, P.dAt + (size_t)nonbasic[q] * P.ld, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(sync_stream());
+        for (int i = 0; i < m; i++) col[i] = w.h_vec[i];
+    }
     if ((rc = lu_solve(P, dsol, col.data())) != GOMILP_OK) return -rc;
     // Accuracy of the resident tableau: its column q against the fresh one.  On badly scaled LPs (entries over 1e19) the updated
     // tableau loses digits within a few hundred pivots, its ratio tests then leave the reference's path and may never end; beyond
