@@ -151,9 +151,9 @@ int Engine::ensure_work(int m, int ncols) {
     // (rowstep: + two snapshots, by round parity, for the look-ahead schedule of the compressed LU)
     HIP_TRY(dmalloc(&w.lpos, (size_t)nm)); HIP_TRY(dmalloc(&w.rowstep, (size_t)3 * nm)); HIP_TRY(dmalloc(&w.rho, (size_t)nm));
     HIP_TRY(dmalloc(&w.unitrow, (size_t)nm)); HIP_TRY(dmalloc(&w.denseflag, (size_t)nm)); HIP_TRY(dmalloc(&w.dlist, (size_t)nm));
-    HIP_TRY(dmalloc(&w.ludiag, (size_t)nm)); HIP_TRY(dmalloc(&w.Wd, (size_t)nm * nld));
+    HIP_TRY(dmalloc(&w.ludiag, (size_t)nm)); HIP_TRY(dmalloc(&w.Wd, (size_t)nm * nld + 512));   // (+ the tail of k_luc_pack_small: row positions, flags, two control blocks)
     HIP_TRY(dmalloc(&w.luLp, (size_t)64 * nld)); HIP_TRY(dmalloc(&w.luUp, (size_t)64 * nld));   // (2 x 32 rows: by round parity)
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_W), (size_t)nm * nld * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_W), ((size_t)nm * nld + 512) * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_vec), (size_t)std::max(nld, nc) * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_chk), (size_t)nld * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w.h_idx), ((size_t)nm + (size_t)nc) * sizeof(int32_t), hipHostMallocDefault));   // mirrors the basic | nonbasic device block
@@ -824,14 +824,16 @@ int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_hos
     a.rowsnap = w.rowstep + w.cap_m; a.rowsnap_prev = a.rowsnap;   // (launch_luc_rounds sets the round's parity)
     a.ctl_base = a.ctl; a.round = 0; a.pad3 = bt_fault_ == 2 ? 1 : 0;
     w.st_host->lu_singular = 0;
-    sync_state_to_device();
+    if (!(compressed && m <= 128)) sync_state_to_device();   // (small bases: k_luc_init clears the flag on the device, the packed block brings it back)
     lu_rounds_ = 0;
     int32_t *h_dense = w.h_idx + w.cap_m;   // landing place of the dense-step flags (h_idx holds nm + nc entries; lpos lands in front)
-    // Small bases: the packed factors are asked for together with the control block, in ONE host round trip — all m columns (the
-    // compact list of dense columns would need the flags first; a unit-column step has zero multipliers and zero off-diagonal U
-    // entries, which the solves skip like gonum's do: same bits, m*m instead of m*nd doubles over PCIe).  An exact step factors
-    // twice and small trees are made of round trips.  Should the batch of rounds turn out too short, the pack is simply repeated.
-    bool oneshot = compressed && m <= 128;
+    // Small bases: the packed factors are asked for together with the control block, in ONE host round trip and ONE copy — all m
+    // columns (the compact list of dense columns would need the flags first; a unit-column step has zero multipliers and zero
+    // off-diagonal U entries, which the solves skip like gonum's do: same bits, m*m instead of m*nd doubles over PCIe), with the
+    // diagonal, the row positions, the flags and both control blocks behind them (k_luc_pack_small).  An exact step factors twice and
+    // small trees are made of round trips and 3 us copies (60 per relaxation before this).  Should the batch of rounds turn out too
+    // short, the general path takes over from where the rounds stand.
+    bool oneshot = compressed && m <= 128 && luc_pack_small_bytes(m) <= ((size_t)w.cap_m * w.cap_ld + 512) * sizeof(double);   // (the block fits Wd / h_W: ensure_work)
     std::vector<int32_t> dl;
     auto enqueue_pack = [&](int nd2) -> int {
         int rcd = stage_upload(w.dlist, dl.data(), (size_t)nd2 * sizeof(int32_t));
@@ -844,7 +846,10 @@ int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_hos
         if (nd2) HIP_TRY(hipMemcpyAsync(w.h_W, w.Wd, (size_t)(split2 ? nd2 : m) * nd2 * sizeof(double), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipMemcpyAsync(w.h_vec, w.ludiag, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipMemcpyAsync(w.h_idx, w.lpos, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+        if (compressed && m <= 128)   // (the state block was not uploaded in front of this factorization: only the flag comes back)
+            HIP_TRY(hipMemcpyAsync(&w.st_host->lu_singular, &w.st->lu_singular, sizeof(w.st_host->lu_singular), hipMemcpyDeviceToHost, stream_));
+        else
+            HIP_TRY(hipMemcpyAsync(w.st_host, w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
         return GOMILP_OK;
     };
     if (compressed) {
@@ -863,16 +868,26 @@ int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_hos
             for (;;) {
                 launches_ += launch_luc_rounds(a, w.rho, batch, enq, stream_);
                 enq += batch;
-                HIP_TRY(hipMemcpyAsync(w.luctl_host, w.luctl, 2 * sizeof(LUCtl), hipMemcpyDeviceToHost, stream_));
-                // the dense-step flags ride along (final once k_next == m): no separate round trip for them
-                HIP_TRY(hipMemcpyAsync(h_dense, w.denseflag, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
                 if (oneshot) {
+                    launch_luc_pack_small(a, w.Wd, stream_);
+                    launches_++;
+                    HIP_TRY(hipMemcpyAsync(w.h_W, w.Wd, luc_pack_small_bytes(m), hipMemcpyDeviceToHost, stream_));
+                    HIP_TRY(sync_stream());
+                    const double *blk = w.h_W;
+                    const int32_t *io = reinterpret_cast<const int32_t *>(blk + (size_t)m * m + m);
+                    memcpy(w.h_vec, blk + (size_t)m * m, (size_t)m * sizeof(double));   // diag
+                    memcpy(w.h_idx, io, (size_t)m * sizeof(int32_t));                   // lpos
+                    memcpy(h_dense, io + m, (size_t)m * sizeof(int32_t));
+                    memcpy(w.luctl_host, io + 2 * m, 2 * sizeof(LUCtl));
+                    w.st_host->lu_singular = io[2 * m + (int)(2 * sizeof(LUCtl) / sizeof(int32_t))];
                     dl.resize(m);
                     for (int k = 0; k < m; k++) dl[k] = k;
-                    int rcp = enqueue_pack(m);
-                    if (rcp != GOMILP_OK) return rcp;
+                } else {
+                    HIP_TRY(hipMemcpyAsync(w.luctl_host, w.luctl, 2 * sizeof(LUCtl), hipMemcpyDeviceToHost, stream_));
+                    // the dense-step flags ride along (final once k_next == m): no separate round trip for them
+                    HIP_TRY(hipMemcpyAsync(h_dense, w.denseflag, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+                    HIP_TRY(sync_stream());
                 }
-                HIP_TRY(sync_stream());
                 last = w.luctl_host + (a.look ? ((enq - 1) & 1) : 0);
                 if (w.luctl_host[0].fault || last->k_next >= m) break;
                 oneshot = false;   // (the batch was too short: that pack came too early)

@@ -315,6 +315,8 @@ void launch_luc_pack_dense(const LUArgs &a, const int32_t *dlist, int nd, const 
 void launch_luc_solve_rows(const LUArgs &a, const int32_t *dlist, int nd, const double *b, const double *xdL, const double *xdU,
                            double *x, hipStream_t s);
 void launch_luc_pack(const LUArgs &a, const int32_t *dlist, int nd, double *Wd, double *diag, hipStream_t s);
+void launch_luc_pack_small(const LUArgs &a, double *out, hipStream_t s);   // small bases: factors, diagonal, row positions, flags, control blocks in one block
+size_t luc_pack_small_bytes(int m);
 void launch_lu_pack(const LUArgs &a, const int32_t *dlist, int nd, double *Wd, double *diag, hipStream_t s);
 
 }  // namespace gomilp

@@ -894,6 +894,7 @@ __global__ void k_luc_init(LUArgs a) {
         if (a.dense_flag) a.dense_flag[R] = 0;
     }
     if (R == 0) {
+        a.st->lu_singular = 0;   // (the host resets its copy; small bases skip the upload of the state block)
         for (int t = 0; t < 2; t++) {   // (two: by round parity)
             LUCtl *c = a.ctl + t;
             c->k_next = 0; c->k0 = 0; c->k1 = 0; c->nsteps = 0; c->ndrop = 0; c->rounds = 0; c->nnext = 0;
@@ -1040,6 +1041,32 @@ void launch_luc_pack_dense(const LUArgs &a, const int32_t *dlist, int nd, const 
 void launch_luc_solve_rows(const LUArgs &a, const int32_t *dlist, int nd, const double *b, const double *xdL, const double *xdU,
                            double *x, hipStream_t s) {
     hipLaunchKernelGGL(k_luc_solve_rows, dim3((a.m + 255) / 256), dim3(256), 0, s, a, dlist, nd, b, xdL, xdU, x);
+}
+// Small bases: everything the host needs after a factorization in ONE block (one copy instead of six: a 5-row relaxation of a small
+// tree is made of such copies).  Layout: m x m doubles W(R, t) row-major | m doubles diag | int32 lpos[m] | int32 dense_flag[m] |
+// LUCtl[2] | int32 lu_singular.
+__global__ __launch_bounds__(256) void k_luc_pack_small(LUArgs a, double *__restrict__ out) {
+    const int m = a.m;
+    const size_t ldw = (size_t)a.ldw;
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    for (int idx = tid; idx < m * m; idx += nth) {
+        const int R = idx / m, t = idx % m;
+        out[idx] = a.W[(size_t)t * ldw + R];
+    }
+    double *diag = out + (size_t)m * m;
+    for (int R = tid; R < m; R += nth) diag[R] = a.W[(size_t)a.lpos[R] * ldw + R];
+    int32_t *io = reinterpret_cast<int32_t *>(diag + m);
+    for (int R = tid; R < m; R += nth) { io[R] = a.lpos[R]; io[m + R] = a.dense_flag ? a.dense_flag[R] : 1; }
+    int32_t *cb = io + 2 * m;
+    const int32_t *src = reinterpret_cast<const int32_t *>(a.ctl_base);
+    constexpr int NC = (int)(2 * sizeof(LUCtl) / sizeof(int32_t));
+    for (int t = tid; t < NC; t += nth) cb[t] = src[t];
+    if (tid == 0) cb[NC] = a.st->lu_singular;
+}
+size_t luc_pack_small_bytes(int m) { return ((size_t)m * m + m) * sizeof(double) + (size_t)(2 * m + 1) * sizeof(int32_t) + 2 * sizeof(LUCtl); }
+void launch_luc_pack_small(const LUArgs &a, double *out, hipStream_t s) {
+    const int grid = std::max(1, std::min(64, (a.m * a.m + 255) / 256));
+    hipLaunchKernelGGL(k_luc_pack_small, dim3(grid), dim3(256), 0, s, a, out);
 }
 void launch_luc_pack(const LUArgs &a, const int32_t *dlist, int nd, double *Wd, double *diag, hipStream_t s) {
     dim3 grid((nd + 31) / 32 > 0 ? (nd + 31) / 32 : 1, (a.m + 31) / 32);
