@@ -55,6 +55,42 @@ struct gomilp_pool {
     std::vector<int64_t> extra_root;
     std::vector<std::unique_ptr<Engine::RootView>> extra_view;
     std::mutex call_mu;         // one wave at a time per pool
+    // A schedule that runs beside the calling thread's (the wide half of a split wave, the second half of a wave of large LPs) gets a
+    // thread that LIVES with the pool: a std::thread per wave cost, once in ~50 waves, milliseconds (stack mapped and unmapped in a
+    // process full of pinned and device-mapped memory: 6-10 ms waves among 4.0 ms ones in tools/wave_outliers.py).
+    struct Aux {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<void()> task;
+        bool has = false, done = true, stop = false;
+        void loop() {
+            for (;;) {
+                std::function<void()> f;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || has; });
+                    if (stop && !has) return;
+                    f = std::move(task); has = false;
+                }
+                f();
+                { std::lock_guard<std::mutex> lk(mu); done = true; }
+                cv.notify_all();
+            }
+        }
+        void run(std::function<void()> f) {
+            { std::lock_guard<std::mutex> lk(mu); task = std::move(f); has = true; done = false; }
+            if (!th.joinable()) th = std::thread([this] { loop(); });
+            cv.notify_all();
+        }
+        void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); }
+        ~Aux() {
+            { std::lock_guard<std::mutex> lk(mu); stop = true; }
+            cv.notify_all();
+            if (th.joinable()) th.join();
+        }
+    };
+    Aux aux[3];
     // persistent workers
     std::vector<std::thread> threads;
     std::mutex mu;
@@ -462,12 +498,12 @@ static int frontier_solve_impl(gomilp_pool *pool, int64_t count, const int32_t *
             int rc2 = GOMILP_OK;
             pool->batch->set_low_priority(true);   // the wide group yields to the long chains
             // (the long chains on the calling thread: they are the critical path of the wave and start without waiting for a thread to come up)
-            std::thread t2([&] {
+            pool->aux[0].run([&] {
                 hipSetDevice(pool->device);
                 rc = run_group(*pool->batch, grp_p, gp, false, &bsc);
             });
             rc2 = run_group(*pool->batch2, grp_f, gf, false, &bs2);
-            t2.join();
+            pool->aux[0].wait();
             pool->batch->set_low_priority(false);
             if (rc == GOMILP_OK) rc = rc2;
             merge_stats(bsc, true); merge_stats(bs2, false);
@@ -504,10 +540,9 @@ static int frontier_solve_impl(gomilp_pool *pool, int64_t count, const int32_t *
                 rcx[t] = be[t]->run_roots(views.data(), nroots, root_of ? root_of + off : nullptr, lo[t + 1] - off, koff + off, var, sign, rhs, tol, od, &bsx[t]);
                 be[t]->set_xcd_offset(0);
             };
-            std::vector<std::thread> ths;
-            for (int t = 1; t < nsched; t++) ths.emplace_back(run_part, t);
+            for (int t = 1; t < nsched; t++) pool->aux[t - 1].run([&run_part, t] { run_part(t); });
             run_part(0);
-            for (auto &th : ths) th.join();
+            for (int t = 1; t < nsched; t++) pool->aux[t - 1].wait();
             bs = bsx[0];
             for (int t = 0; t < nsched; t++) { if (rc == GOMILP_OK) rc = rcx[t]; if (t) merge_stats(bsx[t], false); }
         } else {

@@ -16,6 +16,10 @@ for mode in ("gc on", "gc off"):
     ts = []
     for r in range(n):
         t0 = time.perf_counter(); res = pool.solve(children); ts.append(1e3 * (time.perf_counter() - t0))
+        if ts[-1] > 8:   # what the C side says about a slow wave
+            st = res.stats
+            print("  slow wave %d: %.2f ms | C side total %.2f batch %.2f busy %.2f supersteps %d blocks %d launches %d fallbacks %d" % (r, ts[-1], 1e3 * st["seconds_total"], 1e3 * st["seconds_batch"],
+                  1e3 * st["seconds_busy_sum"], st["supersteps"], st["blocks"], st["kernel_launches"], st["host_fallbacks"]), flush=True)
     ts = np.array(ts)
     print(mode, "median %.2f ms mean %.2f max %.2f  >8ms: %d of %d" % (np.median(ts), ts.mean(), ts.max(), int((ts > 8).sum()), n), " ".join("%.1f" % t for t in ts), flush=True)
 pool.close()
