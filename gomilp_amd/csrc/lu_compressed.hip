@@ -20,7 +20,11 @@
 //                 are still active, the steps before its own for a row retired by a bookkeeping step of the round.
 // Rounds are data dependent, so the kernels take their step range from a device control block (LUCtl) and the host
 // enqueues rounds in batches until k_next == m.
-// m = 2048 metric basis: 2048 steps, 384 dense -> 24 rounds instead of 128 panels.
+// m = 2048 metric basis: 2048 steps, 384 dense -> 23 rounds instead of 128 panels.
+// Two schedules of the same rounds (knob lu_blocked): the PLAIN one launches the three kernels above one after the other; the
+// LOOK-AHEAD one (default beyond 768 rows, luc_role below) is ONE launch per round — workgroup 0 the panel of round r, the other
+// workgroups the U-solve and update of round r-1 beside it, the columns the panel loads first.  Small bases (<= 128 rows) bring
+// everything the host needs home in one block (k_luc_pack_small).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
