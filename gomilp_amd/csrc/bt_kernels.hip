@@ -1337,6 +1337,23 @@ __global__ __launch_bounds__(kBlock) void k_bt_update_tiled_batch(const BatchLP 
     const BatchLP &lp = lps[ids[li]];
     const int stage = lp.stage;
     if (stage == BS_DONE || stage == BS_HOST || stage == BS_COLD) return;
+    if (stage == BS_P1 && lp.st->done) {
+        // Phase I ended inside this block step.  With the artificial still basic above the zero tolerance the relaxation is infeasible (or
+        // goes to the host path, which starts from the root data), and a wrapped error ends it too: k_b_ctrl, next in the stream, decides
+        // exactly so, and nobody reads this tableau again — on a B&B frontier that is most of a wide wave, each a 2.4 MB tableau streamed
+        // for nothing (2048 children: 2.4 of 11.5 ms).  The tests of k_b_ctrl, on the same lists.
+        const int status = lp.st->status;
+        if (status == ST_UNBOUNDED || status == ST_BLAND_FAILED) return;
+        if (status == ST_OPTIMAL) {
+            __shared__ int s_skip;
+            if (threadIdx.x == 0) s_skip = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < lp.m; i += kBlock)
+                if (lp.basic[i] == lp.n && fabs(lp.xb[i]) > 1e-13) s_skip = 1;
+            __syncthreads();
+            if (s_skip) return;
+        }
+    }
     const BTArgs a = lp.bt;
     const unsigned int bx = tile % (unsigned int)gx, by = tile / (unsigned int)gx;
     if (bx * kBlock >= 2u * (unsigned int)a.ldt || (int)by * tilerows_per_wg * 4 >= ((a.m + 3) & ~3)) return;
