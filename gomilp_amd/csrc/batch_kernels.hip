@@ -211,9 +211,20 @@ __global__ void k_b_gather(const BatchLP *__restrict__ lps) {
     for (int rr = threadIdx.y; rr < 32; rr += 8) tile[rr][threadIdx.x] = b_entry(lp, p0 + threadIdx.x, j0 + rr, nn);
     __syncthreads();
     double *T = lp.T[0];
-    for (int rr = threadIdx.y; rr < 32; rr += 8) {
-        const int pos = p0 + rr, jp = j0 + threadIdx.x;
-        if (jp < ldt && pos < m4) T[tab_idx(pos, jp, ldt, 1)] = tile[threadIdx.x][rr];   // padding rows / columns are zeros
+    // the 32 x 32 block is 8 x 8 tiles of the 4x4-tiled tableau: a thread stores one row of a tile (32 contiguous bytes), four neighbours
+    // a whole tile, a wave two tile rows of 1 KB each — full lines (row by row, 32 lanes wrote 32-byte pieces 128 bytes apart: 2.9 TB/s
+    // for the 4.9 GB of a 2048-wide wave).  ldt is a multiple of 4, m4 too: a tile is inside or outside as a whole.
+    const int t = threadIdx.y * 32 + threadIdx.x;
+    const int til = t >> 2, rit = t & 3;
+    const int tr = til >> 3, tc = til & 7;
+    const int pos = p0 + tr * 4 + rit, jp = j0 + tc * 4;
+    if (jp < ldt && pos < m4) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2 lo, hi;
+        lo.x = tile[tc * 4 + 0][tr * 4 + rit]; lo.y = tile[tc * 4 + 1][tr * 4 + rit];
+        hi.x = tile[tc * 4 + 2][tr * 4 + rit]; hi.y = tile[tc * 4 + 3][tr * 4 + rit];
+        d2 *dst = reinterpret_cast<d2 *>(T + tab_idx(pos, jp, ldt, 1));   // (16-byte aligned: 4 doubles of a tile row)
+        dst[0] = lo; dst[1] = hi;   // padding rows / columns are zeros
     }
 }
 

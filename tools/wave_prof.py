@@ -1,11 +1,12 @@
-"""Developer tool: batched C5 waves only (for rocprofv3 --kernel-trace --stats, or warm-up patterns)."""
+"""Developer tool: batched C5 waves only (for rocprofv3 --kernel-trace --stats, or warm-up patterns).
+usage: wave_prof.py [waves] [workers] [gap_s] [branch_vars: 8 = 256 children, 11 = 2048]"""
 import sys, time, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gomilp_amd import lp, synth
 m, seed = synth.CONFIGS["C5"]
 c, A, b = synth.dense_lp_standard_form(m, seed)
 mask = synth.integrality_mask(m, m)
 cx = lp.Context(); root = cx.upload(c, A, b).solve(0.0); cx.close()
-children = synth.frontier_children(root.x, mask, 8)
+children = synth.frontier_children(root.x, mask, int(sys.argv[4]) if len(sys.argv) > 4 else 8)
 pool = lp.FrontierPool(workers=int(sys.argv[2]) if len(sys.argv) > 2 else 16, batched=1)
 pool.set_root(c, A, b)
 gap = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
