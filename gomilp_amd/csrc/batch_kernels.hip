@@ -200,7 +200,14 @@ __device__ __forceinline__ double b_entry(const BatchLP &lp, int pos, int jp, in
     return (r == lp.m0 + (j - lp.n0)) ? 1.0 : 0.0;    // (a branch slack can only be nonbasic here if the list said so)
 }
 
-__global__ void k_b_gather(const BatchLP *__restrict__ lps) {
+// mode 0: every relaxation's whole tableau.
+// mode 1 (with k_b_gather mode 2 behind the set-up block): a relaxation that starts with the forced Phase-I pivot (BS_FORCED) gets only
+//   the 32 x 32 blocks that hold the pivot's row and column — all the block kernel reads for that one pivot;
+// mode 2: the whole tableau of those relaxations WITH the pivot's rank-1 term applied, T' = T + u v'^T, in the arithmetic of
+//   k_bt_update_tiled_batch (a rounded multiply, a rounded add, then the + 0 of its seven empty terms) — the tableau is written once
+//   instead of written, read and written again: on a wide frontier wave, where Phase I is most of the work, 4.9 GB instead of 14.7 GB
+//   (2048 children).  Everybody else was gathered in full by mode 1 and has no term to apply (kmax = 0 in the set-up block).
+__global__ void k_b_gather(const BatchLP *__restrict__ lps, int mode) {
     __shared__ double tile[32][33];
     const BatchLP &lp = lps[blockIdx.z];
     if (lp.stage == BS_HOST || lp.stage == BS_DONE || lp.stage == BS_COLD) return;
@@ -208,7 +215,25 @@ __global__ void k_b_gather(const BatchLP *__restrict__ lps) {
     const int m4 = (m + 3) & ~3;
     const int p0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
     if (p0 >= m4 || j0 >= ldt) return;
+    const bool forced = lp.stage == BS_FORCED;
+    if (mode == 2 && !forced) return;
+    if (mode == 1 && forced) {
+        const int fp = lp.bt.forced_p, fq = lp.bt.forced_q;
+        if (!(fp >= p0 && fp < p0 + 32) && !(fq >= j0 && fq < j0 + 32)) return;
+    }
     for (int rr = threadIdx.y; rr < 32; rr += 8) tile[rr][threadIdx.x] = b_entry(lp, p0 + threadIdx.x, j0 + rr, nn);
+    if (mode == 2 && lp.st->kdone > 0) {   // (uniform) the pivot ran: its term, row 0 of U / V
+        const double *U = lp.bt.U, *V = lp.bt.V;
+        for (int rr = threadIdx.y; rr < 32; rr += 8) {
+            const int pos = p0 + threadIdx.x, jp = j0 + rr;
+            const double u = pos < m ? U[pos] : 0.0;       // (rows beyond m: zero, as the update kernel stages them)
+            const double v = jp < ldt ? V[jp] : 0.0;
+            double t = tile[rr][threadIdx.x];
+            t = __dadd_rn(t, __dmul_rn(u, v));
+            t = __dadd_rn(t, 0.0);                        // the empty terms k = 1 .. 7 of the update kernel: t + 0 * 0
+            tile[rr][threadIdx.x] = t;
+        }
+    }
     __syncthreads();
     double *T = lp.T[0];
     // the 32 x 32 block is 8 x 8 tiles of the 4x4-tiled tableau: a thread stores one row of a tile (32 contiguous bytes), four neighbours
@@ -546,9 +571,9 @@ void launch_b_setup_warm(BatchLP *lps, int nlp, hipStream_t s) { hipLaunchKernel
 int batch_ldt(int nn) { return b_ldt(nn); }
 
 void launch_b_setup(BatchLP *lps, int nlp, hipStream_t s) { hipLaunchKernelGGL(k_b_setup, dim3(nlp), dim3(kBlock), 0, s, lps); }
-void launch_b_gather(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s) {
+void launch_b_gather(const BatchLP *lps, int nlp, int m_max, int ldt_max, int mode, hipStream_t s) {
     dim3 grid(((m_max + 3) / 4 * 4 + 31) / 32, (ldt_max + 31) / 32, nlp), block(32, 8);
-    hipLaunchKernelGGL(k_b_gather, grid, block, 0, s, lps);
+    hipLaunchKernelGGL(k_b_gather, grid, block, 0, s, lps, mode);
 }
 // ids_in / count_in: the active list the previous control step left (everybody at the start); bound >= *count_in on the host
 void launch_b_ctrl(BatchLP *lps, const int *ids_in, const int *count_in, int bound, int n_max, BatchOut *outs, int *ids_out, int *count_out, int loop_par, hipStream_t s) {

@@ -337,7 +337,8 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
     };
     // the blocks of superstep `step` work on the active list the control step of superstep step - 1 left behind
     int last_loop_par = -1;   // parity of the loop launch that ran the blocks of the superstep being enqueued (-1: launch pairs)
-    auto blocks = [&](int nb, bool allow_loop) {
+    // (fused_setup: the set-up block — its update is folded into the gather of the tableau, batch_kernels.hip k_b_gather mode 2)
+    auto blocks = [&](int nb, bool allow_loop, bool fused_setup = false) {
         const int *ids = b.d_ids[(step + 1) & 1];
         const int *cnt = step == 0 ? b.d_active + (kMaxSteps - 1) : b.d_active + (step - 1);
         last_loop_par = -1;
@@ -365,7 +366,12 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
             }
             launch_bt_inner_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_, e[0], e[1], xcd_off_);
             if (nwarm) { launch_bt_inner_dual_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_); S.launches += 1; }   // (stage BS_DUAL only)
-            launch_bt_update_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_, e[2], e[3]);
+            if (fused_setup) {
+                if (e[2]) hipEventRecord(e[2], stream_);
+                launch_b_gather(b.d_lps, nlp, m_max, ldt1, 2, stream_);
+                if (e[3]) hipEventRecord(e[3], stream_);
+            }
+            else launch_bt_update_batch(b.d_lps, ids, cnt, bound, m_max, ldt1, stream_, e[2], e[3]);
         }
         S.launches += 2 * nb; S.blocks += nb;
     };
@@ -381,10 +387,13 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
     // ---- prologue: set-up, T, the forced Phase-I pivots, first reduced costs
     launch_b_setup(b.d_lps, nlp, stream_);
     if (nwarm) { launch_b_setup_warm(b.d_lps, nlp, stream_); S.launches += 1; }
-    launch_b_gather(b.d_lps, nlp, m_max, ldt1, stream_);
+    // the tiled rank-8 update (blocks of 8 pivots) has its arithmetic in the gather too: relaxations that start with the forced Phase-I
+    // pivot get the pivot's row and column first, the whole tableau once, with the pivot applied, behind the set-up block
+    const bool fuse_setup = kb == 8;
+    launch_b_gather(b.d_lps, nlp, m_max, ldt1, fuse_setup ? 1 : 0, stream_);
     S.launches += 2;
     S.warm_started = nwarm;
-    blocks(1, false);   // (set-up pivots: one block each, launch pair)
+    blocks(1, false, fuse_setup);   // (set-up pivots: one block each, launch pair)
     control(false);
     if ((rc = snapshot(0)) != GOMILP_OK) return rc;
     S.seconds_setup = bnow() - t0;
