@@ -207,49 +207,54 @@ __device__ __forceinline__ double b_entry(const BatchLP &lp, int pos, int jp, in
 //   k_bt_update_tiled_batch (a rounded multiply, a rounded add, then the + 0 of its seven empty terms) — the tableau is written once
 //   instead of written, read and written again: on a wide frontier wave, where Phase I is most of the work, 4.9 GB instead of 14.7 GB
 //   (2048 children).  Everybody else was gathered in full by mode 1 and has no term to apply (kmax = 0 in the set-up block).
+constexpr int kGatherTiles = 8;   // 32 x 32 blocks per workgroup, side by side in a row of blocks (one block per workgroup: 554 k workgroups of ~1 us for a 2048-wide wave)
 __global__ void k_b_gather(const BatchLP *__restrict__ lps, int mode) {
     __shared__ double tile[32][33];
     const BatchLP &lp = lps[blockIdx.z];
     if (lp.stage == BS_HOST || lp.stage == BS_DONE || lp.stage == BS_COLD) return;
     const int m = lp.m, nn = lp.bt.nn, ldt = lp.bt.ldt;
     const int m4 = (m + 3) & ~3;
-    const int p0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
-    if (p0 >= m4 || j0 >= ldt) return;
+    const int p0 = blockIdx.x * 32;
+    if (p0 >= m4) return;
     const bool forced = lp.stage == BS_FORCED;
     if (mode == 2 && !forced) return;
-    if (mode == 1 && forced) {
-        const int fp = lp.bt.forced_p, fq = lp.bt.forced_q;
-        if (!(fp >= p0 && fp < p0 + 32) && !(fq >= j0 && fq < j0 + 32)) return;
-    }
-    for (int rr = threadIdx.y; rr < 32; rr += 8) tile[rr][threadIdx.x] = b_entry(lp, p0 + threadIdx.x, j0 + rr, nn);
-    if (mode == 2 && lp.st->kdone > 0) {   // (uniform) the pivot ran: its term, row 0 of U / V
-        const double *U = lp.bt.U, *V = lp.bt.V;
-        for (int rr = threadIdx.y; rr < 32; rr += 8) {
-            const int pos = p0 + threadIdx.x, jp = j0 + rr;
-            const double u = pos < m ? U[pos] : 0.0;       // (rows beyond m: zero, as the update kernel stages them)
-            const double v = jp < ldt ? V[jp] : 0.0;
-            double t = tile[rr][threadIdx.x];
-            t = __dadd_rn(t, __dmul_rn(u, v));
-            t = __dadd_rn(t, 0.0);                        // the empty terms k = 1 .. 7 of the update kernel: t + 0 * 0
-            tile[rr][threadIdx.x] = t;
-        }
-    }
-    __syncthreads();
+    const int fp = lp.bt.forced_p, fq = lp.bt.forced_q;
+    const bool rowhit = fp >= p0 && fp < p0 + 32;
+    const bool term = mode == 2 && lp.st->kdone > 0;   // (uniform) the pivot ran: its term, row 0 of U / V
+    const double *U = lp.bt.U, *V = lp.bt.V;
     double *T = lp.T[0];
-    // the 32 x 32 block is 8 x 8 tiles of the 4x4-tiled tableau: a thread stores one row of a tile (32 contiguous bytes), four neighbours
-    // a whole tile, a wave two tile rows of 1 KB each — full lines (row by row, 32 lanes wrote 32-byte pieces 128 bytes apart: 2.9 TB/s
-    // for the 4.9 GB of a 2048-wide wave).  ldt is a multiple of 4, m4 too: a tile is inside or outside as a whole.
     const int t = threadIdx.y * 32 + threadIdx.x;
     const int til = t >> 2, rit = t & 3;
     const int tr = til >> 3, tc = til & 7;
-    const int pos = p0 + tr * 4 + rit, jp = j0 + tc * 4;
-    if (jp < ldt && pos < m4) {
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        d2 lo, hi;
-        lo.x = tile[tc * 4 + 0][tr * 4 + rit]; lo.y = tile[tc * 4 + 1][tr * 4 + rit];
-        hi.x = tile[tc * 4 + 2][tr * 4 + rit]; hi.y = tile[tc * 4 + 3][tr * 4 + rit];
-        d2 *dst = reinterpret_cast<d2 *>(T + tab_idx(pos, jp, ldt, 1));   // (16-byte aligned: 4 doubles of a tile row)
-        dst[0] = lo; dst[1] = hi;   // padding rows / columns are zeros
+    for (int g = 0; g < kGatherTiles; g++) {
+        const int j0 = ((int)blockIdx.y * kGatherTiles + g) * 32;
+        if (j0 >= ldt) break;
+        if (mode == 1 && forced && !rowhit && !(fq >= j0 && fq < j0 + 32)) continue;   // (uniform)
+        for (int rr = threadIdx.y; rr < 32; rr += 8) {
+            double v = b_entry(lp, p0 + threadIdx.x, j0 + rr, nn);
+            if (term) {
+                const int pos = p0 + threadIdx.x, jp = j0 + rr;
+                const double u = pos < m ? U[pos] : 0.0;       // (rows beyond m: zero, as the update kernel stages them)
+                const double vv = jp < ldt ? V[jp] : 0.0;
+                v = __dadd_rn(v, __dmul_rn(u, vv));
+                v = __dadd_rn(v, 0.0);                        // the empty terms k = 1 .. 7 of the update kernel: t + 0 * 0
+            }
+            tile[rr][threadIdx.x] = v;
+        }
+        __syncthreads();
+        // the 32 x 32 block is 8 x 8 tiles of the 4x4-tiled tableau: a thread stores one row of a tile (32 contiguous bytes), four neighbours
+        // a whole tile, a wave two tile rows of 1 KB each — full lines (row by row, 32 lanes wrote 32-byte pieces 128 bytes apart: 2.9 TB/s
+        // for the 4.9 GB of a 2048-wide wave).  ldt is a multiple of 4, m4 too: a tile is inside or outside as a whole.
+        const int pos = p0 + tr * 4 + rit, jp = j0 + tc * 4;
+        if (jp < ldt && pos < m4) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 lo, hi;
+            lo.x = tile[tc * 4 + 0][tr * 4 + rit]; lo.y = tile[tc * 4 + 1][tr * 4 + rit];
+            hi.x = tile[tc * 4 + 2][tr * 4 + rit]; hi.y = tile[tc * 4 + 3][tr * 4 + rit];
+            d2 *dst = reinterpret_cast<d2 *>(T + tab_idx(pos, jp, ldt, 1));   // (16-byte aligned: 4 doubles of a tile row)
+            dst[0] = lo; dst[1] = hi;   // padding rows / columns are zeros
+        }
+        __syncthreads();   // (the block's values are out of LDS before the next one comes in)
     }
 }
 
@@ -572,7 +577,7 @@ int batch_ldt(int nn) { return b_ldt(nn); }
 
 void launch_b_setup(BatchLP *lps, int nlp, hipStream_t s) { hipLaunchKernelGGL(k_b_setup, dim3(nlp), dim3(kBlock), 0, s, lps); }
 void launch_b_gather(const BatchLP *lps, int nlp, int m_max, int ldt_max, int mode, hipStream_t s) {
-    dim3 grid(((m_max + 3) / 4 * 4 + 31) / 32, (ldt_max + 31) / 32, nlp), block(32, 8);
+    dim3 grid(((m_max + 3) / 4 * 4 + 31) / 32, ((ldt_max + 31) / 32 + kGatherTiles - 1) / kGatherTiles, nlp), block(32, 8);
     hipLaunchKernelGGL(k_b_gather, grid, block, 0, s, lps, mode);
 }
 // ids_in / count_in: the active list the previous control step left (everybody at the start); bound >= *count_in on the host
