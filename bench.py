@@ -529,8 +529,10 @@ def main() -> int:
                       "drift_xb": last.stats["drift_xb"], "z": last.z},
     }
 
-    # ---- CPU baseline (the oracle = the reference algorithm), bounded sample of the same workload
-    if not args.no_cpu_baseline:
+    # ---- CPU baseline (the oracle = the reference algorithm), bounded sample of the same workload.  Timed LAST (deferred below): 15-25 s
+    # of 16 busy host threads in front of the latency-bound GPU legs cost those legs 5-10 % (frontier wave 3.7 -> 4.1 ms on the same box)
+    deferred = []
+    def _cpu_headline():
         from oracle import oracle as O   # the checker, timed as the CPU baseline (never the product path)
         cores = max(1, min(args.cpu_threads, os.cpu_count() or 1))
         O.set_threads(cores)
@@ -560,6 +562,8 @@ def main() -> int:
         out["cpu_baseline"]["full_solve_256x512"] = {
             "pivots": int(npv), "cpu_cores": 1, "cpu_seconds": t_cpu, "cpu_pivots_per_s": npv / t_cpu, "gpu_seconds": t_gpu,
             "gpu_pivots_per_s": npv / t_gpu, "same_x_bits": bool(g256.status == 0 and r256.x is not None and np.array_equal(g256.x, r256.x))}
+    if not args.no_cpu_baseline:
+        deferred.append(_cpu_headline)
 
     # ---- extra: B independent LPs of the headline shape on this GPU, advancing TOGETHER through the device-batched schedule
     # (children with no branch rows of B roots in one pool: one launch per kernel type per block step for all of them)
@@ -705,7 +709,7 @@ def main() -> int:
                              "c5": {"note": "a relaxation starts warm only from a kept parent it extends by ONE branch row; the 256 children of the C5 wave extend the root by 8 "
                                             "rows each and start cold by rule (the frontier figures above are theirs): the worst case of the mode is cold + the dual-pivot budget"},
                              "note": "opt-in (gomilp_frontier_solve_warm): parity on status / decision / z <= 1e-9, not on the pivot path"}
-        if not args.no_cpu_baseline and args.milp_cpu_nodes > 0:
+        def _cpu_c3():
             from oracle import oracle as O   # the checker, timed as the CPU baseline (never the product path)
             O.set_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
             tc0 = time.perf_counter()
@@ -720,6 +724,8 @@ def main() -> int:
                                               "sample": "root + the first %d nodes of the same tree in the reference's FIFO order, one oracle solve after the other "
                                                         "(LU panels threaded over the host cores), %.1f s wall" % (len(osolved) - 1, tc),
                                               "gpu_nodes_identical_on_sample": bool(same)}
+        if not args.no_cpu_baseline and args.milp_cpu_nodes > 0:
+            deferred.append(_cpu_c3)
     # ---- degenerate trees: the 240 integer-data MILPs of the parity suite (duplicate rows, stacked branch rows: every node sits on a
     # degenerate vertex, decided on fresh gonum-order solves — Engine::exact_step): what the exact steps cost
     if args.milp_nodes > 0:
@@ -740,6 +746,8 @@ def main() -> int:
                                    "note": "bases of up to 64 rows: every relaxation on a worker's single-relaxation engine with the pivot-by-pivot condition replay and the "
                                            "exact-degenerate steps (two gonum-order device LUs per degenerate pivot: ab^T, and ab once for x_B / the entering column / the Bland candidates); tests/test_gpu_golden.py checks every node of these trees "
                                            "bit for bit against the oracle tree"}
+    for fn in deferred:   # the CPU baselines (oracle), behind every GPU leg
+        fn()
     emit(out)
     prob.free()
     ctx.close()
