@@ -863,6 +863,7 @@ int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_hos
             // (the slot panel takes up to nb steps per round whatever the order of the columns; a wrong guess costs one more look at the
             // control block, a generous one a run of empty rounds)
             int batch = a.slots ? std::max(1, (std::min(m, (5 * nonunit) / 2) + nb - 1) / nb) : std::max(1, (3 * nonunit + nb - 1) / nb + 1);
+            if (oneshot && GOMILP_DBG_ENV("GOMILP_DEBUG_LU_SHORT")) batch = 1;   // (diagnostic flavour: a first batch that is too short — the small-basis block comes too early and the general path takes over)
             int enq = 0;   // rounds enqueued so far: the look-ahead schedule keeps two control blocks, by round parity
             const LUCtl *last = w.luctl_host;
             for (;;) {
