@@ -18,7 +18,12 @@ for rep in range(reps):
     def run(i): got[i] = ps[i].solve(0.0)
     ths = [threading.Thread(target=run, args=(i,)) for i in range(len(ps))]
     [t.start() for t in ths]; [t.join() for t in ths]
-    bad += sum(1 for g, o in zip(got, ref) if g.status != o.status or not np.array_equal(g.x, o.x) or g.stats["device_retries"])
+    for i, (g, o) in enumerate(zip(got, ref)):
+        wrong = g.status != o.status or not np.array_equal(g.x, o.x)
+        if wrong or g.stats["device_retries"]:
+            bad += 1
+            print("round %d shape %s: %s (status %d vs %d, retries %d, pivots %d)" % (rep, shapes[i], "MISMATCH" if wrong else "retry, same bits", g.status, o.status, g.stats["device_retries"],
+                                                                                  g.stats["pivots_phase1"] + g.stats["pivots_phase2"]), flush=True)
 print("mixed shapes x %d rounds: %.1f ms per round, mismatches / retries %d" % (reps, 1e3 * (time.perf_counter() - t0) / reps, bad), flush=True)
 for cx in cxs: cx.close()
 sys.exit(1 if bad else 0)
