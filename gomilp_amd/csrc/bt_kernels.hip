@@ -159,6 +159,7 @@ __global__ __launch_bounds__(NT) void k_bt_inner(BTArgs a) {
             bt_block_argmin<kBtWaves>(c, sm2 + kBtWaves * (sm_par ^= 1));
             q = (int)c.i;
             rq = r_s[q];
+            if (a.guard == inf && !(k == 0 && a.exact_once)) { status = ST_NEED_EXACT; break; }   // strict mode (knob exact_degenerate = 3): the stop test too is the host's, on fresh reduced costs
             if (rq >= -a.tol) { status = ST_OPTIMAL; break; }  // simplex.go:248
             column(q, k, dcol);
             BtCand w = ratio(dcol, mvv);
@@ -639,7 +640,8 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a, const int nupd =
                     // at the stop threshold itself only the drift of the updated reduced costs matters (1e-12; a Phase-I optimum has
                     // many reduced costs at zero, 1e-10 above its threshold: nothing to re-decide there); a tie matters only when
                     // the loop goes on
-                    if (fabs(rq0 + a.tol) <= 1e-12 || (!(rq0 >= -a.tol) && r2 - rq0 <= a.guard * fmax(1.0, fabs(rq0)))) { status = ST_NEED_EXACT; break; }
+                    // (an infinite guard — knob exact_degenerate = 3, strict — stops in front of EVERY decision, the stop test included)
+                    if (a.guard == inf || fabs(rq0 + a.tol) <= 1e-12 || (!(rq0 >= -a.tol) && r2 - rq0 <= a.guard * fmax(1.0, fabs(rq0)))) { status = ST_NEED_EXACT; break; }
                 }
             }
             q = (int)fq.i;

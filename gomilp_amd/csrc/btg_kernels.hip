@@ -449,6 +449,7 @@ __device__ __forceinline__ void bt_innerG_body(const BTArgs &a, const int g, con
             if (dead) break;
             q = (int)fq.i; rq = fq.p0; ent = (int)fq.p1;
             if (fq.i >= (unsigned int)a.nn) { q = 0; rq = __builtin_nan(""); }   // every r_j is NaN: MinIdx returns 0
+            if (a.guard == inf && !(k == 0 && blk == 0 && a.exact_once)) { status = ST_NEED_EXACT; break; }   // strict mode (knob exact_degenerate = 3): every decision is the host's, on fresh solves
             if (rq >= -a.tol) { status = ST_OPTIMAL; break; }                    // simplex.go:248
             column(q, k, dcol, fq.p3);
             XWin w;

@@ -100,7 +100,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "bt_groups") { if (v != -1 && v != 0 && v != 2 && v != 4 && v != 8 && v != 16) return GOMILP_ERR_BAD_SHAPE; bt_groups_ = v; }
     else if (key == "bt_stamps") bt_stamps_ = v ? 1 : 0;
     else if (key == "bt_lag") bt_lag_ = v ? 1 : 0;
-    else if (key == "exact_degenerate") { if (v < 0 || v > 2) return GOMILP_ERR_BAD_SHAPE; exact_degenerate_ = v; }
+    else if (key == "exact_degenerate") { if (v < 0 || v > 3) return GOMILP_ERR_BAD_SHAPE; exact_degenerate_ = v; }   // 3: strict — EVERY pivot decided on fresh gonum-order solves (engine_tableau.cpp exact_step)
     else if (key == "loop_grid") { if (v < 0 || v > 4096) return GOMILP_ERR_BAD_SHAPE; loop_grid_ = v; }
     else if (key == "loop_chunk") { if (v < 32) return GOMILP_ERR_BAD_SHAPE; loop_chunk_ = v; }
     else if (key == "cond_guard") cond_guard_ = v ? 1 : 0;

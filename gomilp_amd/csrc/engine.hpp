@@ -145,6 +145,7 @@ class Engine {
     // one iteration of the reference on fresh solves (engine_tableau.cpp): the decision a degenerate or tied pivot needs
     int exact_step(const Problem &P, int phase, double tol, int nn, int *q_out, int *p_out, gomilp_lp_stats *st);
     int cond_check(const Problem &P, int nn, double *k1, double *kinf);
+    int cond_fresh(const Problem &P, const int32_t *basic_host, double *k1, double *kinf);   // from a fresh host inverse of the basis
     int groups_knob(const Problem &P) const;
     bool ensure_host_A(const Problem &P);
     // findLinearlyIndependent with the scan on the device (general_kernels.hip) and the last, square step on the host
@@ -180,7 +181,7 @@ class Engine {
             loop_upd_ = 0,     // update workgroups of the loop kernel that take part (0: all of the grid's)
             loop_g_ = 0,       // its pivot workgroups (0 / 16: 16 x 128 threads up to 2048 rows, 16 x 256 beyond; 8: 8 x 256 / 8 x 512)
             loop_k_ = 0,       // its pivots per block (0: 8 up to 2048 rows, 16 beyond; 8 / 16 forced where instantiated)
-            exact_degenerate_ = 1,   // 0 never, 1 bases of up to 256 rows and every non-slack start, 2 always: pivots whose winning ratio is (nearly) zero are decided on a fresh gonum-order x_B
+            exact_degenerate_ = 1,   // 0 never, 1 bases of up to 256 rows and every non-slack start, 2 always: pivots whose winning ratio is (nearly) zero are decided on a fresh gonum-order x_B; 3 strict: EVERY pivot and the stop test are decided on fresh gonum-order solves
             cond_guard_ = 1;   // replay the condition guards of the reference on the host for bases of up to 64 rows
     bool badly_scaled_ = false;   // the current problem's entries span more than nine decades (Problem::scale_span): guard on, tableau checked
     bool gen_start_ = false;      // the current solve starts from a searched (non-slack) basis: the degenerate-pivot guard stays on
@@ -277,6 +278,11 @@ const char *bt_batch_kernel_name(int m_max, int ldt_max);
 int b_loop_slots(int ncu);
 bool b_loop_supported(int m_max, int ldt_max);
 void launch_b_loop(const BatchLP *lps, const int *ids, const int *count, int nlp, int nblocks, int par, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// res_kernels.hip: the register-resident tableau kernel for the long chains of a narrow wave (G workgroups per relaxation on one XCD)
+size_t b_res_slot_bytes();
+int b_res_max_slots();
+int b_res_groups(int m_max, int ldt_max);
+void launch_b_res(const BatchLP *lps, const int *ids, const int *count, int nlp, int G, int nb, double seq0, void *xbase, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 // batch_kernels.hip
 int batch_ldt(int nn);
 void launch_b_setup(BatchLP *lps, int nlp, hipStream_t s);

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <limits>
 #include <chrono>
 
 namespace gomilp {
@@ -90,6 +91,8 @@ struct BatchEngine::Buf {
     hipEvent_t ev[kRing] = {nullptr, nullptr};
     double *d_T = nullptr, *d_R = nullptr, *d_xb = nullptr, *d_U = nullptr, *d_V = nullptr, *d_scratch = nullptr, *d_art = nullptr;
     double *d_xbuf = nullptr;   // exchange records of the multi-workgroup block kernel, one set per relaxation slot
+    void *d_res = nullptr;      // register-resident kernel (res_kernels.hip): records + candidate rows per launch SLOT, zeroed once: every exchange of
+    uint64_t res_launches = 0;  // every launch carries its own sequence numbers (launch number * 2^20 + exchange)
     int32_t *d_basic = nullptr, *d_nonbasic = nullptr, *d_srcpos = nullptr;
     DevState *d_st = nullptr;
     int32_t *d_var = nullptr, *h_var = nullptr;
@@ -115,7 +118,8 @@ struct BatchEngine::Buf {
     }
     void free_all() {
         free_lp_buffers();
-        for (void *p : {(void *)d_var, (void *)d_sr, (void *)d_active}) if (p) hipFree(p);
+        for (void *p : {(void *)d_var, (void *)d_sr, (void *)d_active, d_res}) if (p) hipFree(p);
+        d_res = nullptr;
         for (auto &r : rho) hipFree(r.d);
         rho.clear();
         for (void *p : {(void *)h_var, (void *)h_sr, (void *)h_active[0], (void *)h_active[1]}) if (p) hipHostFree(p);
@@ -251,6 +255,15 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_) != hipSuccess || ncu <= 0) ncu = 64;
     const int loop_slots = (loop_ && b_loop_supported(m_max, ldt1)) ? b_loop_slots(ncu) : 0;
     int loop_launches = 0;
+    // the register-resident kernel (res_kernels.hip) takes them when they are few: G workgroups per relaxation on one XCD, at most 8
+    // relaxations per launch — half the CUs of every XCD, so that the two schedules of a split wave can both be resident
+    const int res_G = (res_ && ncu >= 256 && exact_degenerate_ != 3) ? b_res_groups(m_max, ldt1) : 0;
+    const int res_slots = res_G ? b_res_max_slots() : 0;
+    if (res_slots && !b.d_res) {
+        const size_t bytes = (size_t)b_res_max_slots() * b_res_slot_bytes();
+        B_TRY(hipMalloc(&b.d_res, bytes));
+        B_TRY(hipMemsetAsync(b.d_res, 0, bytes, stream_));
+    }
     // ---- root data the kernels read in place + the unit-column rows of each root's slack basis
     std::vector<const int32_t *> rho_of(nroots, nullptr);
     for (int r = 0; r < nroots; r++) {
@@ -310,7 +323,9 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
             }
         }
         // degenerate pivots are decided on a fresh gonum-order x_B: such a relaxation is handed to the worker path (ST_NEED_EXACT -> BS_HOST)
-        lp.bt.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && (lp.m <= 256 || lp.gen || R.scale_span > 1e9))) ? 1e-9 : 0.0;
+        // (3, strict: every relaxation stops in front of its first decision and goes to a worker, whose engine runs the strict mode)
+        lp.bt.guard = exact_degenerate_ == 3 ? std::numeric_limits<double>::infinity()
+                                              : (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && (lp.m <= 256 || lp.gen || R.scale_span > 1e9))) ? 1e-9 : 0.0;
         lp.bt.fault = fault_;
         lp.bt.cguard = (cond_guard_ && !lp.gen) ? 1e-9 : 0.0;   // a pivot element of rounding-noise size: ST_NEED_EXACT -> BS_HOST, the worker path measures the condition numbers
         lp.bt.xbuf = b.d_xbuf + (size_t)i * bt_xbuf_doubles();
@@ -342,6 +357,21 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         const int *ids = b.d_ids[(step + 1) & 1];
         const int *cnt = step == 0 ? b.d_active + (kMaxSteps - 1) : b.d_active + (step - 1);
         last_loop_par = -1;
+        if (allow_loop && res_slots > 0 && bound <= res_slots && nwarm == 0) {
+            hipEvent_t e[2] = {nullptr, nullptr};
+            if (sampling_) {
+                while (b.samp_ev.size() < (size_t)(nsamp + 1) * 4) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) break; b.samp_ev.push_back(ev); }
+                if (b.samp_ev.size() >= (size_t)(nsamp + 1) * 4) {
+                    e[0] = b.samp_ev[(size_t)nsamp * 4]; e[1] = b.samp_ev[(size_t)nsamp * 4 + 1];
+                    hipEventRecord(b.samp_ev[(size_t)nsamp * 4 + 2], stream_); hipEventRecord(b.samp_ev[(size_t)nsamp * 4 + 3], stream_);   // (no update launch)
+                    nsamp++;
+                }
+            }
+            b.res_launches++;
+            launch_b_res(b.d_lps, ids, cnt, bound, res_G, nb, (double)(b.res_launches << 20), b.d_res, stream_, e[0], e[1]);
+            S.launches += 1; S.blocks += nb; S.loop_launches += 1; S.res_launches += 1;
+            return;   // (the tableau stays in the relaxation's current buffer: the control step needs no buffer choice, last_loop_par = -1)
+        }
         if (allow_loop && loop_slots > 0 && bound <= loop_slots && nwarm == 0) {
             hipEvent_t e[2] = {nullptr, nullptr};
             if (sampling_) {
@@ -462,6 +492,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         int nb = nlp <= 16 ? (step < 2 ? 4 : 8) : (step < 2 ? 1 : (step < 4 ? 2 : (step < 8 ? 4 : 8)));
         // a loop launch has no boundary between its blocks: longer supersteps (fewer control steps on the chain) once the wave is narrow
         if (loop_slots > 0 && bound <= loop_slots && step >= 2 && nwarm == 0) nb = bound <= 8 ? (step >= 3 ? 32 : 16) : 8;
+        if (res_slots > 0 && bound <= res_slots && nwarm == 0) nb = step >= 3 ? 32 : (step >= 1 ? 16 : 8);   // one launch whatever the length: longer supersteps from the start
         step++;
         blocks(nb, true);
         control(true);

@@ -248,7 +248,10 @@ BTArgs Engine::make_bt_args(const Problem &P, int phase, double tol, int nn, int
     // every start that is not a slack basis (equality rows: a tree's repeated branch rows make nearly dependent tableau rows
     // there, and a pivot on their 1e-12 drift walks into a singular basis)
     // (and for inputs whose entries span more than nine decades: their updated tableau loses digits, the exact steps check and rebuild it)
-    a.guard = (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && (P.m <= 256 || gen_start_ || badly_scaled_))) ? 1e-9 : 0.0;
+    // (3, strict: an infinite guard — the block kernel stops in front of EVERY decision, stop test included, and the host repeats the
+    // reference's iteration on fresh solves: slow by design, the mode that follows the reference wherever its rounding noise leads)
+    a.guard = exact_degenerate_ == 3 ? std::numeric_limits<double>::infinity()
+                                     : (exact_degenerate_ == 2 || (exact_degenerate_ == 1 && (P.m <= 256 || gen_start_ || badly_scaled_))) ? 1e-9 : 0.0;
     a.cguard = (cond_guard_ && !gen_start_ && P.m > 64) ? 1e-9 : 0.0;   // (<= 64 rows: the per-pivot replay of Engine::solve; general starts: the guard above is on)
     if (a.tiled && !bt_old_) {
         const BtGroupCfg gc = bt_group_cfg(P.m, ldt_, groups_knob(P));
@@ -299,6 +302,13 @@ int Engine::exact_step(const Problem &P, int phase, double tol, int nn, int *q_o
         if (rc0 != GOMILP_OK) return -rc0;
         // (kappa_inf belongs to the x_B solve that closed the PREVIOUS iteration, simplex.go:289-292: the reference would have left
         // its loop there with mat.Condition, before this iteration's computeMove could report lp.ErrLinSolve)
+        if (k1 > 1e16 || k1 != k1 || kinf > 1e16 || kinf != kinf) return -GOMILP_ERR_CONDITION;
+    } else if (cond_guard_ && exact_degenerate_ == 3) {
+        // strict mode on a searched start basis (or a small one): no B^-1 inside the tableau — the same verdict from a fresh host inverse,
+        // every pivot (the mode is slow by design: it exists to follow the reference wherever its solves' rounding noise leads)
+        double k1 = 0, kinf = 0;
+        int rc0 = cond_fresh(P, basic.data(), &k1, &kinf);
+        if (rc0 != GOMILP_OK) return -rc0;
         if (k1 > 1e16 || k1 != k1 || kinf > 1e16 || kinf != kinf) return -GOMILP_ERR_CONDITION;
     }
     auto cost = [&](int var) -> double { return phase == 1 ? (var == n ? 1.0 : 0.0) : (var < n ? P.hc[var] : 0.0); };
@@ -889,16 +899,31 @@ int Engine::cond_check(const Problem &P, int nn, double *k1, double *kinf) {
     // number: gonum measures cond with Dgecon's Hager / Higham estimate of |B^-1| (lapack/gonum/dgecon.go:26-81,
     // dlacn2.go:24-136), a lower bound of the exact norm within a small factor.
     const int m = P.m;
+    const double tk1 = *k1, tkinf = *kinf;
+    { int rc = cond_fresh(P, nullptr, k1, kinf); if (rc != GOMILP_OK) return rc; }
+    if (GOMILP_DBG_ENV("GOMILP_DEBUG_LOOP")) fprintf(stderr, "cond_check: m %d tableau kappa_1 %.6g kappa_inf %.6g -> fresh %.6g %.6g\n", m, tk1, tkinf, *k1, *kinf);
+    return GOMILP_OK;
+}
+
+
+// kappa_1 / kappa_inf of the current basis (positions in basic_host, or the device list) from a FRESH inverse on the host: exact norms,
+// and beyond 1e16 the Hager / Higham estimate gonum's Dgecon computes (a lower bound of the exact norm within a small factor); a singular
+// basis: +Inf.  The columns come from the resident At (row n = the Phase-I artificial column)
+int Engine::cond_fresh(const Problem &P, const int32_t *basic_host, double *k1, double *kinf) {
+    Work &w = *w_;
+    const int m = P.m;
     std::vector<int32_t> basic(m);
-    HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(sync_stream());
-    for (int i = 0; i < m; i++) basic[i] = w.h_idx[i];
+    if (basic_host) for (int i = 0; i < m; i++) basic[i] = basic_host[i];
+    else {
+        HIP_TRY(hipMemcpyAsync(w.h_idx, w.basic, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(sync_stream());
+        for (int i = 0; i < m; i++) basic[i] = w.h_idx[i];
+    }
     std::vector<double> cols((size_t)m * P.ld), B((size_t)m * m), inv;
     for (int p = 0; p < m; p++)
         HIP_TRY(hipMemcpyAsync(&cols[(size_t)p * P.ld], P.dAt + (size_t)basic[p] * P.ld, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(sync_stream());
     for (int i = 0; i < m; i++) for (int p = 0; p < m; p++) B[(size_t)i * m + p] = cols[(size_t)p * P.ld + i];
-    const double tk1 = *k1, tkinf = *kinf;
     if (!general_invert(B, m, inv)) { *k1 = *kinf = std::numeric_limits<double>::infinity(); return GOMILP_OK; }
     double n1 = 0, ninf = 0, i1 = 0, iinf = 0;
     {
@@ -915,7 +940,6 @@ int Engine::cond_check(const Problem &P, int nn, double *k1, double *kinf) {
         *k1 = n1 * inverse_norm1_estimate(inv, m, false);
         *kinf = ninf * inverse_norm1_estimate(inv, m, true);
     }
-    if (GOMILP_DBG_ENV("GOMILP_DEBUG_LOOP")) fprintf(stderr, "cond_check: m %d tableau kappa_1 %.6g kappa_inf %.6g -> fresh %.6g %.6g\n", m, tk1, tkinf, *k1, *kinf);
     return GOMILP_OK;
 }
 

@@ -17,7 +17,6 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import numpy as np
 
 BIG_INDEX = 1 << 52   # == GOMILP_NO_INCUMBENT (include/gomilp_lp.h): exact in a double
-_SHARD_CACHE: dict = {}
 
 
 def _mix(i: int) -> int:
@@ -99,21 +98,23 @@ def allreduce_incumbent(z_local: float, idx_local: int, dist=None, device=None, 
                      "torch.distributed is only the CPU rehearsal path (gloo)")
 
 
+def make_shard(children: List[list], rank: int = 0, world: int = 1) -> Tuple[List[int], List[list]]:
+    """This rank's part of a wave: (global child indices, the children themselves).  A caller that solves the SAME frontier again
+    (a bench, a re-solve with other knobs) builds it once and hands it to solve_wave; the library keeps no cache of its own — a
+    frontier list that its owner updates in place must never meet an older wave's shard."""
+    mine = shard_indices(len(children), rank, world)
+    return mine, [children[i] for i in mine]
+
+
 def solve_wave(solve_shard: Callable[[List[list]], tuple], children: List[list], integrality: Sequence[bool],
-               rank: int = 0, world: int = 1, dist=None, device=None, comm=None) -> dict:
+               rank: int = 0, world: int = 1, dist=None, device=None, comm=None, shard: Optional[Tuple[List[int], List[list]]] = None) -> dict:
     """One wave: shard -> solve the shard -> incumbent all-reduce.
 
     `solve_shard(list_of_children)` returns (status, z, x, has_x) arrays for that list (FrontierPool.solve on
-    the GPU box; a stub in the gloo tests)."""
-    mine = shard_indices(len(children), rank, world)
-    key = (id(children), len(children), rank, world)
-    shard = _SHARD_CACHE.get(key)
-    if shard is None or shard[0] is not children:   # the same frontier list, wave after wave (benches): its shard is built once
-        if len(_SHARD_CACHE) > 16:
-            _SHARD_CACHE.clear()
-        shard = (children, [children[i] for i in mine])
-        _SHARD_CACHE[key] = shard
-    status, z, x, has_x = solve_shard(shard[1])
+    the GPU box; a stub in the gloo tests).  `shard`: make_shard(children, rank, world) of exactly this wave, built by the caller
+    (optional: built here otherwise, every call)."""
+    mine, mine_children = shard if shard is not None else make_shard(children, rank, world)
+    status, z, x, has_x = solve_shard(mine_children)
     zl, il = local_incumbent(mine, status, z, x, has_x, integrality)
     zg, ig = allreduce_incumbent(zl, il, dist, device, comm)
     return {"indices": mine, "status": status, "z": z, "x": x, "has_x": has_x, "incumbent_z": zg, "incumbent_index": ig,

@@ -122,7 +122,9 @@ int gomilp_ctx_device(const gomilp_ctx *ctx);
  * diagnostic flavour of the library (libgomilp_hip_debug.so, GOMILP_DEBUG_BUILD=1) adds "bt_fault" and the GOMILP_DEBUG_* / GOMILP_LUC_*
  * environment hooks; the product library has none of them.  Knobs that DO change what is decided, and how faithfully:
  * "exact_degenerate" (0 never, 1 default: bases of up to 256 rows, non-slack starts and badly scaled inputs, 2 always — degenerate,
- * tied and tiny pivots are decided on fresh gonum-order solves), "cond_guard" (1 default: gonum's
+ * tied and tiny pivots are decided on fresh gonum-order solves; 3 strict: EVERY pivot and the stop test are the
+ * reference's iteration on fresh gonum-order solves with its condition guard, simplex.go:233-293 — milliseconds per pivot, the mode that
+ * follows the reference wherever the rounding noise of its solves leads), "cond_guard" (1 default: gonum's
  * mat.Condition guard, from a pivot-by-pivot replay up to 64 rows and from the tableau's exact condition numbers beyond — at every exact
  * step (Phase I too), on the final basis, and in front of any pivot whose element is of rounding-noise size).
  * Returns GOMILP_OK or GOMILP_ERR_BAD_SHAPE. */

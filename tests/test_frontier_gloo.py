@@ -1,5 +1,5 @@
-"""N > 1 path on CPU: world_size-2 gloo run of the wave sharding + incumbent all-reduce (no GPU needed: the
-per-shard solver is the CPU oracle here, standing in for FrontierPool.solve)."""
+"""N > 1 path on CPU: world_size 2 / 4 / 8 gloo runs of the wave sharding + incumbent all-reduce (no GPU needed: the
+per-shard solver is the CPU oracle here, standing in for FrontierPool.solve) — the control flow bench.py --gpus N runs on a node."""
 import math
 import os
 import socket
@@ -30,7 +30,7 @@ def _case():
     c0, A0, b0 = synth.dense_lp_standard_form(m, seed)
     root = O.simplex(c0, A0, b0, 0.0, None, fast_initial_basis=True)
     mask = synth.integrality_mask(m, m)
-    children = synth.frontier_children(root.x, mask, 3)
+    children = synth.frontier_children(root.x, mask, 4)   # 16 children: two per rank at world size 8
     return c0, A0, b0, mask, children
 
 
@@ -56,9 +56,12 @@ def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     c0, A0, b0, mask, children = _case()
-    res = frontier.solve_wave(_oracle_shard_solver(c0, A0, b0), children, mask, rank, world, dist, torch.device("cpu"))
+    # the caller-built shard (what bench.py hands over wave after wave) and the shard built inside the call must be the same wave
+    shard = frontier.make_shard(children, rank, world)
+    res = frontier.solve_wave(_oracle_shard_solver(c0, A0, b0), children, mask, rank, world, dist, torch.device("cpu"), shard=shard if rank % 2 else None)
     out.put((rank, res["indices"], res["incumbent_z"], res["incumbent_index"], res["local_incumbent_z"],
              [int(s) for s in res["status"]], [float(v) for v in res["z"]]))
     dist.barrier()
@@ -82,28 +85,48 @@ def test_integrality_semantics_follow_tree_go():
     assert frontier.feasible_for_ip([False, True], [0.5, 3.0]) and not frontier.feasible_for_ip([True, True], [0.5, 3.0])
 
 
-def test_two_rank_gloo_wave_matches_single_rank():
+def test_solve_wave_keeps_no_cache_of_a_frontier_list():
+    """A frontier list that its owner updates IN PLACE between waves (same object, same length) must be solved as it stands: the library
+    keeps no shard cache (round-4 advisory); a caller-built shard is the caller's statement about THAT wave."""
+    c0, A0, b0, mask, children = _case()
+    seen = []
+
+    def stub(chs):
+        seen.append([list(ch) for ch in chs])
+        n = len(chs)
+        return np.full(n, 2, dtype=np.int32), np.full(n, math.nan), np.zeros((n, A0.shape[1])), np.zeros(n, dtype=np.int32)
+
+    frontier.solve_wave(stub, children, mask)
+    first = [list(ch) for ch in children]
+    children[0] = children[-1]          # in place: same list object, same length
+    frontier.solve_wave(stub, children, mask)
+    assert seen[0] == first and seen[1] == [list(ch) for ch in children] and seen[0] != seen[1]
+    assert not hasattr(frontier, "_SHARD_CACHE")
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_gloo_wave_matches_single_rank(world):
     c0, A0, b0, mask, children = _case()
     single = frontier.solve_wave(_oracle_shard_solver(c0, A0, b0), children, mask)
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [out.get(timeout=120) for _ in procs]
+    got = [out.get(timeout=300) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     got.sort()
-    # both ranks agree on the global incumbent, and it is the single-process answer
-    assert got[0][2] == got[1][2] == single["incumbent_z"]
-    assert got[0][3] == got[1][3] == single["incumbent_index"]
-    assert min(got[0][4], got[1][4]) == single["incumbent_z"]
+    # every rank agrees on the global incumbent, and it is the single-process answer
+    assert all(g[2] == single["incumbent_z"] for g in got)
+    assert all(g[3] == single["incumbent_index"] for g in got)
+    assert min(g[4] for g in got) == single["incumbent_z"]
     # the shards tile the wave and reproduce the single-rank per-child results bit for bit
     merged_status, merged_z = {}, {}
     for rank, idx, _, _, _, st, zz in got:
-        assert idx == frontier.shard_indices(len(children), rank, 2)
+        assert idx == frontier.shard_indices(len(children), rank, world)
         for i, s, v in zip(idx, st, zz):
             merged_status[i], merged_z[i] = s, v
     assert sorted(merged_status) == list(range(len(children)))
