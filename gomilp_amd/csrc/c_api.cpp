@@ -39,7 +39,7 @@ struct gomilp_pool {
     std::unique_ptr<BatchEngine> batch;
     std::unique_ptr<BatchEngine> batch2;   // second schedule (split waves, waves of large relaxations; created on first use)
     std::unique_ptr<BatchEngine> batchx[2];   // third and fourth schedule for waves of large relaxations (split_large)
-    int cond_guard = 1, exact_degenerate = 1, sample_batch = 0, batch_loop = 1, batch_res = 1;   // knob values kept for batch2: both halves of a split wave decide alike
+    int cond_guard = 1, exact_degenerate = 1, sample_batch = 0, batch_loop = 1, batch_res = 0;   // knob values kept for batch2: both halves of a split wave decide alike
     int split_large = 1;        // knob: waves of >= 4 large relaxations run as two interleaved schedules
     int split_phase = 1;        // knob: relaxations that start feasible (Phase II from the slack basis: the long pivot chains of a wave) and
                                 // relaxations that need Phase I (on a B&B frontier mostly proved infeasible within a few pivots) run as two
@@ -134,7 +134,7 @@ struct gomilp_pool {
 };
 
 #ifdef GOMILP_DEBUG
-namespace gomilp { void luc_stamps_read(unsigned long long *out); }
+namespace gomilp { void luc_stamps_read(unsigned long long *out); void res_stamps_read(unsigned long long *out); }
 #endif
 
 extern "C" {
@@ -206,7 +206,7 @@ int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value) {
     if (std::string(key) == "batched") { pool->batched = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "split_large") { pool->split_large = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "split_phase") { pool->split_phase = value ? 1 : 0; return GOMILP_OK; }
-    if (std::string(key) == "batch_res") {   // block steps of narrow waves in the register-resident kernel (default 1; 0: k_b_loop / launch pairs)
+    if (std::string(key) == "batch_res") {   // block steps of narrow waves in the register-resident kernel (opt-in, default 0: k_b_loop / launch pairs)
         pool->batch_res = value ? 1 : 0;
         pool->batch->set_res(value != 0);
         if (pool->batch2) pool->batch2->set_res(value != 0);
@@ -673,6 +673,7 @@ int64_t gomilp_debug_find_independent_device(gomilp_ctx *ctx, int64_t problem, i
 #ifdef GOMILP_DEBUG
 // diagnostic flavour only: cycle sums of the final-solve panel kernel (lu_compressed.hip), 4 waves x 16 segments
 void gomilp_debug_luc_stamps(unsigned long long *out) { gomilp::luc_stamps_read(out); }
+void gomilp_debug_res_stamps(unsigned long long *out) { gomilp::res_stamps_read(out); }
 #endif
 
 int64_t gomilp_lp_last_trace(gomilp_ctx *ctx, gomilp_pivot *out, int64_t cap) {

@@ -281,7 +281,7 @@ void launch_b_loop(const BatchLP *lps, const int *ids, const int *count, int nlp
 // res_kernels.hip: the register-resident tableau kernel for the long chains of a narrow wave (G workgroups per relaxation on one XCD)
 size_t b_res_slot_bytes();
 int b_res_max_slots();
-int b_res_groups(int m_max, int ldt_max);
+int b_res_groups(int m_max, int nn_max, int ldt_max);
 void launch_b_res(const BatchLP *lps, const int *ids, const int *count, int nlp, int G, int nb, double seq0, void *xbase, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 // batch_kernels.hip
 int batch_ldt(int nn);

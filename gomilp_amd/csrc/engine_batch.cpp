@@ -229,7 +229,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
     if (count <= 0) return GOMILP_OK;
     if (count > 65535 || nroots < 1) return GOMILP_ERR_UNSUPPORTED;
     const int nlp = (int)count;
-    int m_max = 0, n_max = 0, ldt1 = 0;
+    int m_max = 0, n_max = 0, ldt1 = 0, nn_max = 0;   // (nn_max: nonbasic columns of the widest tableau, the Phase-I artificial included)
     for (int i = 0; i < nlp; i++) {
         const int ri = root_of ? root_of[i] : 0;
         if (ri < 0 || ri >= nroots) return GOMILP_ERR_BAD_SHAPE;
@@ -241,6 +241,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         for (double v : Ri.hb) if (v < -1e-13) { p1 = true; break; }
         for (int64_t k = koff[i]; k < koff[i + 1] && !p1; k++) if (rhs[k] < -1e-13) p1 = true;
         ldt1 = std::max(ldt1, batch_ldt(Ri.n - Ri.m + (p1 ? 1 : 0)));   // Phase-I tableau: one column more (the artificial)
+        nn_max = std::max(nn_max, Ri.n - Ri.m + (p1 ? 1 : 0));
     }
     const int64_t ktot = koff[nlp] - koff[0];
     int rc = ensure(nlp, m_max, n_max, ldt1, ktot);
@@ -257,7 +258,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
     int loop_launches = 0;
     // the register-resident kernel (res_kernels.hip) takes them when they are few: G workgroups per relaxation on one XCD, at most 8
     // relaxations per launch — half the CUs of every XCD, so that the two schedules of a split wave can both be resident
-    const int res_G = (res_ && ncu >= 256 && exact_degenerate_ != 3) ? b_res_groups(m_max, ldt1) : 0;
+    const int res_G = (res_ && ncu >= 256 && exact_degenerate_ != 3) ? b_res_groups(m_max, nn_max, ldt1) : 0;
     const int res_slots = res_G ? b_res_max_slots() : 0;
     if (res_slots && !b.d_res) {
         const size_t bytes = (size_t)b_res_max_slots() * b_res_slot_bytes();

@@ -56,7 +56,7 @@ if "soak" in args:
         c, A, b = synth.dense_lp_standard_form(m0, seed)
         cx = lp.Context(); root = cx.upload(c, A, b); r0 = root.solve(0.0)
         frac = [j for j in range(m0) if r0.x[j] != math.floor(r0.x[j])]
-        pr = lp.FrontierPool(workers=4); pr.set_root(c, A, b)
+        pr = lp.FrontierPool(workers=4, batch_res=1); pr.set_root(c, A, b)
         pp = lp.FrontierPool(workers=4, batch_res=0, batch_loop=0); pp.set_root(c, A, b)
         fb = [0, 0]
         for w in range(waves):
