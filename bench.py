@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--frontier-vars", type=int, default=8, help="C5: 2^k children from the k highest fractional integer vars (0 = skip at N = 1)")
     ap.add_argument("--workers", type=int, default=4, help="worker contexts per GPU (final solves / fall-backs of the batched frontier): 4 measured best — the pivot loops run in ONE batched schedule, and every further spinning host thread only delays it (16 workers: 1 wave in 6 takes 11 ms instead of 6)")
     ap.add_argument("--frontier-wide-vars", type=int, default=11, help="second frontier line at N = 1: 2^k children (0 = skip)")
+    ap.add_argument("--frontier-xwide-vars", type=int, default=13, help="third frontier line: 2^k children (8192: the width at which >= 6x from 8 GPUs is arithmetically "
+                    "possible — one GPU needs more than 6x the heaviest child's time for the wave) (0 = skip)")
     ap.add_argument("--milp-cpu-nodes", type=int, default=7, help="C3: nodes behind the root that the CPU oracle solves too (baseline + check; 0 = skip)")
     ap.add_argument("--frontier-cpu-children", type=int, default=8, help="children solved on the CPU oracle too (baseline + check)")
     ap.add_argument("--concurrent", type=int, default=4, help="extra figure: independent LPs of the headline shape solved together on one GPU (0 = skip)")
@@ -146,6 +148,7 @@ def main() -> int:
               "frontier_scaling_bound_per_s": g("frontier", "scaling_bound", "max_relaxations_per_s"),
               "heaviest_child_ms": None if g("frontier", "scaling_bound", "heaviest_child", "seconds_alone") is None else 1e3 * g("frontier", "scaling_bound", "heaviest_child", "seconds_alone"),
               "frontier_wide_relaxations_per_s": g("frontier_wide", "relaxations_per_s"),
+              "frontier_xwide_relaxations_per_s": g("frontier_xwide", "relaxations_per_s"),
               "c4_pivots_per_s": g("c4", "pivots_per_s"), "c2_pivots_per_s": g("c2", "pivots_per_s"),
               "batched_vs_single": g("batched", "vs_single"), "batched_pivots_per_s": g("batched", "pivots_per_s"),
               "milp_c3_relaxations_per_s": g("milp_c3", "relaxations_per_s"),
@@ -276,12 +279,14 @@ def main() -> int:
             wave = fr.solve_wave(solve_shard, children, mask5, rank, world, wave_dist, dev, comm=comm, shard=shard)
         acc = dict(inner=0.0, update=0.0, blocks=0, blocks_sampled=0, batch=0.0, pivots=0, phase1=0, bland=0, fallbacks=0, batched=0)
         per_wave = []
+        split = [0.0, 0.0, 0.0]   # this rank's solve / incumbent scan / exchange seconds over the timed waves
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             tw = time.perf_counter()
             wave = fr.solve_wave(solve_shard, children, mask5, rank, world, wave_dist, dev, comm=comm, shard=shard)
             per_wave.append(time.perf_counter() - tw)
+            split[0] += wave["seconds_solve"]; split[1] += wave["seconds_scan"]; split[2] += wave["seconds_exchange"]
             st = holder["stats"]
             if os.environ.get("GOMILP_BENCH_DEBUG"):
                 print("wave %.2f ms: solve %.2f (batch %.2f) exchange+rest %.2f" % (1e3 * per_wave[-1], 1e3 * holder["solve_s"], 1e3 * st["seconds_batch"],
@@ -305,6 +310,12 @@ def main() -> int:
         unpacked_s = time.perf_counter() - tu
         tot = allsum([acc["pivots"], acc["phase1"], acc["bland"], acc["fallbacks"], acc["batched"],
                       float(sum(1 for s in wave["status"] if s == lp.OK))])
+        # per rank: mean wave time and its split (one slot per rank, summed over the ranks: every rank fills its own)
+        slots = [0.0] * (4 * world)
+        slots[4 * rank: 4 * rank + 4] = [sum(per_wave) / max(steps, 1), split[0] / max(steps, 1), split[1] / max(steps, 1), split[2] / max(steps, 1)]
+        slots = allsum(slots)
+        per_rank = [{"rank": rk, "children": len(fr.shard_indices(len(children), rk, world)), "wave_ms": 1e3 * slots[4 * rk], "solve_ms": 1e3 * slots[4 * rk + 1],
+                     "incumbent_scan_ms": 1e3 * slots[4 * rk + 2], "exchange_ms": 1e3 * slots[4 * rk + 3]} for rk in range(world)]
         # scaling bound: the heaviest child alone through the same batched path (a wave can never be faster than that)
         solo = None
         if rank == 0 and not light:
@@ -328,6 +339,7 @@ def main() -> int:
                         % (len(children), m5, 2 * m5, seed5, nvars, world),
             "relaxations_per_s": steps * len(children) / dt, "wave_seconds": dt / steps, "waves_timed": steps, "n_gpus": world,
             "host_pack_seconds": host_pack_s, "wave_seconds_unpacked_rank0": unpacked_s,
+            "per_rank": per_rank,   # exchange_ms = the ONE all-reduce(min) of the wave + the wait for the slowest rank's solve
             "wave_seconds_rank0": per_wave, "wave_seconds_median_rank0": float(np.median(per_wave)) if len(per_wave) else None, "pivots_per_wave": int(tot[0] / steps), "phase1_runs_per_wave": int(tot[1] / steps),
             "bland_steps_per_wave": int(tot[2] / steps), "host_fallbacks_per_wave": tot[3] / steps, "device_batched_per_wave": tot[4] / steps,
             "feasible_children": int(tot[5]), "incumbent_z": wave["incumbent_z"], "incumbent_child": wave["incumbent_index"],
@@ -389,7 +401,14 @@ def main() -> int:
             # shape where more GPUs can pay; compare with `frontier_wide` of the --gpus 1 line
             wout, _, _ = frontier_leg(3, 2, nvars=args.frontier_wide_vars, light=True)
             wide = {k: wout[k] for k in ("workload", "relaxations_per_s", "wave_seconds", "waves_timed", "pivots_per_wave", "feasible_children",
-                                         "host_fallbacks_per_wave", "device_batched_per_wave", "schedule")}
+                                         "host_fallbacks_per_wave", "device_batched_per_wave", "schedule", "per_rank")}
+        xwide = None
+        if args.frontier_xwide_vars > args.frontier_wide_vars:
+            # third line: 2^13 = 8192 children — one GPU needs ~4x the 2048-wide wave for it, more than 6x its heaviest child: the width at
+            # which the >= 6x of BASELINE.json is arithmetically reachable from 8 GPUs; compare with `frontier_xwide` of the --gpus 1 line
+            xout, _, _ = frontier_leg(2, 1, nvars=args.frontier_xwide_vars, light=True)
+            xwide = {k: xout[k] for k in ("workload", "relaxations_per_s", "wave_seconds", "waves_timed", "pivots_per_wave", "feasible_children",
+                                          "host_fallbacks_per_wave", "device_batched_per_wave", "per_rank")}
         if rank == 0:
             out = {
                 "metric": "LP relaxations/sec on the 256-wide B&B frontier of 512x1024 relaxations", "value": fout["relaxations_per_s"],
@@ -398,7 +417,7 @@ def main() -> int:
                 "dtype": "f64", "data": "synthetic",
                 "config": {"workload": fout["workload"], "parallelism": "frontier sharded over %d GPUs, device-batched pivot loops per GPU" % world,
                            "scale_from": "frontier.relaxations_per_s of the --gpus 1 line"},
-                "roofline": roof, "frontier": fout, "frontier_wide": wide,
+                "roofline": roof, "frontier": fout, "frontier_wide": wide, "frontier_xwide": xwide,
                 "mfma": {"util": 0.0, "why": "no GEMM-shaped step on this path: every relaxation has its own tableau (no shared operand for a batched "
                          "pricing GEMM) and the rank-8 update is HBM-bound at 1 flop/byte (f64 MFMA ridge ~10 flop/byte)"},
             }
@@ -681,6 +700,11 @@ def main() -> int:
             wout, wroof, _ = frontier_leg(3, 2, nvars=args.frontier_wide_vars, light=True)
             out["frontier_wide"] = {k: wout[k] for k in ("workload", "relaxations_per_s", "wave_seconds", "waves_timed", "pivots_per_wave", "feasible_children",
                                                        "host_fallbacks_per_wave", "device_batched_per_wave", "schedule")}
+        if args.frontier_xwide_vars > args.frontier_wide_vars > args.frontier_vars:
+            # 8192 children: the 1-GPU figure the N > 1 `frontier_xwide` lines scale from (the width at which >= 6x is reachable)
+            xout, _, _ = frontier_leg(2, 1, nvars=args.frontier_xwide_vars, light=True)
+            out["frontier_xwide"] = {k: xout[k] for k in ("workload", "relaxations_per_s", "wave_seconds", "waves_timed", "pivots_per_wave", "feasible_children",
+                                                         "host_fallbacks_per_wave", "device_batched_per_wave")}
 
     # ---- BASELINE config 3: host branch-and-bound (tree.go semantics, gomilp_amd/bnb.py) driving GPU relaxations
     if args.milp_nodes > 0:

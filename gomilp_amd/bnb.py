@@ -193,8 +193,12 @@ def solve_milp(c, A, b, G, h, integrality, *, max_nodes: int = 255, workers: int
                 if err:
                     out.error = err
                     return out
+                if warm and nd.decision != "BETTER_THAN_INCUMBENT_BRANCHING":
+                    pool.release_warm(nd.id)   # a leaf (pruned, integer feasible, infeasible): nobody will start from its basis
             queue = pending + queue
     finally:
+        if warm:
+            pool.release_warm(-1)   # whatever is still kept (the deadline, an early return): 2-3 MB of HBM per 520-row node
         if own_pool:
             pool.close()
     if out.error == "DeadlineExceeded":

@@ -583,7 +583,7 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a, const int nupd =
             if (wv == 0) {
                 const int cj = (blk - 2) & 3;
                 const unsigned int ub = cj == 0 ? upd_base[0] : cj == 1 ? upd_base[1] : cj == 2 ? upd_base[2] : upd_base[3];
-                const bool ok = spin_counter(upd_cnt + 16 * cj * 2, ub + (unsigned int)nupd * (unsigned int)((blk - 2) / 4 + 1), 0);
+                const bool ok = spin_counter(upd_cnt + 16 * cj * 2, ub + (unsigned int)nupd * (unsigned int)((blk - 2) / 4 + 1), 0, 4 * kBLoopSpinLimit);   // (no sleep between these polls: ~0.4 us each)
                 if (lane == 0) s_ok = ok ? 1 : 0;
             }
             __syncthreads();

@@ -22,6 +22,7 @@ constexpr int kXSpinLimit = 2000000;   // polls (~0.5 us each) before a launch g
 constexpr int kXSync = kXHeader + 2 * 16 * kXSlots * 2;   // doubles in front of the counters (records of up to 16 workgroups, two parities)
 constexpr int kXSyncDoubles = 16 * 5;   // the block counter and four update counters (blocks = j mod 4), a line each
 constexpr int kLoopSpinLimit = 600000;   // polls (~1.5 us each) of a block / update counter before a workgroup gives up
+constexpr int kBLoopSpinLimit = 100000;  // the same in the batched loop kernel (k_b_loop): giving up there costs one relaxation a re-solve on a worker — milliseconds, not a failed solve — so a wave that lost the device to somebody else should not sit out the best part of a second (round-4 advisory)
 
 typedef double xpair __attribute__((ext_vector_type(2)));   // {sequence number, value}
 
@@ -59,8 +60,8 @@ __device__ __forceinline__ void st_agent(double *p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // wait until a monotonic arrival counter has reached `target` (wrap-safe); false: no progress within the limit
-__device__ __forceinline__ bool spin_counter(const unsigned int *p, unsigned int target, int sleep_ticks) {
-    for (int it = 0; it < kLoopSpinLimit; it++) {
+__device__ __forceinline__ bool spin_counter(const unsigned int *p, unsigned int target, int sleep_ticks, int limit = kLoopSpinLimit) {
+    for (int it = 0; it < limit; it++) {
         const unsigned int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int)(v - target) >= 0) return true;
         if (sleep_ticks > 8) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(4);
@@ -100,7 +101,7 @@ __device__ __forceinline__ void bt_loop_update_role(const BTArgs &a, const int u
     const int ntr = (a.m + 3) >> 2;                  // tile rows that exist
     const size_t trow = (size_t)(a.ldt >> 2) * 16;   // doubles per tile row
     for (int blk = 0; blk < a.nblocks; blk++) {
-        if (tid == 0) s_go = spin_counter(blk_cnt, blk_base + (unsigned int)G * (unsigned int)(blk + 1), 32) ? 1 : 0;
+        if (tid == 0) s_go = spin_counter(blk_cnt, blk_base + (unsigned int)G * (unsigned int)(blk + 1), 32, FLAT ? kBLoopSpinLimit : kLoopSpinLimit) ? 1 : 0;   // (FLAT: the batched loop kernel)
         __syncthreads();
         if (!s_go) return;   // the pivot workgroups never arrived: give up (they report the failure, or nobody is left to)
         const int kd = __hip_atomic_load(&st->kdone2[blk & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -505,6 +505,7 @@ static int frontier_solve_impl(gomilp_pool *pool, int64_t count, const int32_t *
             BatchEngine::Stats bs2;
             int rc2 = GOMILP_OK;
             pool->batch->set_low_priority(true);   // the wide group yields to the long chains
+            pool->batch->set_loop_share(2); pool->batch2->set_loop_share(2);   // two schedules with persistent launches: half the loop slots each
             // (the long chains on the calling thread: they are the critical path of the wave and start without waiting for a thread to come up)
             pool->aux[0].run([&] {
                 hipSetDevice(pool->device);
@@ -513,6 +514,7 @@ static int frontier_solve_impl(gomilp_pool *pool, int64_t count, const int32_t *
             rc2 = run_group(*pool->batch2, grp_f, gf, false, &bs2);
             pool->aux[0].wait();
             pool->batch->set_low_priority(false);
+            pool->batch->set_loop_share(1); pool->batch2->set_loop_share(1);
             if (rc == GOMILP_OK) rc = rc2;
             merge_stats(bsc, true); merge_stats(bs2, false);
         } else if (subset) {
@@ -601,6 +603,9 @@ int gomilp_frontier_solve_warm(gomilp_pool *pool, int64_t count, const int64_t *
 
 int gomilp_pool_release_warm(gomilp_pool *pool, int64_t tag) {
     if (!pool) return GOMILP_ERR_BAD_SHAPE;
+    // (behind the pool's call lock like every other entry point: an entry released while a warm wave runs would go back to the free list and
+    // could be recycled by that wave's own harvest — the copy of a kept child into it would overwrite a parent tableau the wave still reads)
+    std::lock_guard<std::mutex> g(pool->call_mu);
     if (tag < 0) pool->warm.clear(); else pool->warm.release(tag);
     return GOMILP_OK;
 }

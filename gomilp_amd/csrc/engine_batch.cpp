@@ -254,7 +254,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
     // the persistent loop kernel takes the block steps whenever the active relaxations fit one launch (one workgroup per CU at most)
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_) != hipSuccess || ncu <= 0) ncu = 64;
-    const int loop_slots = (loop_ && b_loop_supported(m_max, ldt1)) ? b_loop_slots(ncu) : 0;
+    const int loop_slots = (loop_ && b_loop_supported(m_max, ldt1)) ? std::max(8, b_loop_slots(ncu) / loop_share_ / 4 * 4) : 0;   // (loop_share_: schedules side by side)
     int loop_launches = 0;
     // the register-resident kernel (res_kernels.hip) takes them when they are few: G workgroups per relaxation on one XCD, at most 8
     // relaxations per launch — half the CUs of every XCD, so that the two schedules of a split wave can both be resident

@@ -72,6 +72,9 @@ class BatchEngine {
     void set_xcd_offset(int x) { xcd_off_ = x & 7; }   // XCD of list position 0 of the 8-workgroup block kernel (several schedules side by side)
     void set_fault(int v) { fault_ = v; }   // diagnostic flavour: the first update workgroup of every relaxation of a loop launch leaves at once
     void set_res(bool on) { res_ = on; }     // block steps of narrow waves in the register-resident kernel (res_kernels.hip k_b_res; opt-in: correct, but 4.4 us per exchange round against the loop kernel's 3.6 us per pivot — DESIGN.md section 2.7)
+    // several schedules of one pool side by side (a split wave): each sizes its persistent launches for 1 / share of the device's loop slots —
+    // every workgroup of such a launch must be resident, and two schedules that each plan for the whole device wait for each other's CUs
+    void set_loop_share(int share) { loop_share_ = share < 1 ? 1 : share; }
     void set_loop(bool on) { loop_ = on; }   // block steps in the persistent loop kernel where the active relaxations fit one launch (default on)
     void set_cond_guard(int v) { cond_guard_ = v; }   // as the engine knob of the same name
     void set_exact_degenerate(int v) { exact_degenerate_ = v; }   // as the engine knob of the same name
@@ -100,7 +103,7 @@ class BatchEngine {
     int ensure(int nlp, int m_max, int n_max, int ldt1, int64_t ktot);
     int device_;
     bool sampling_ = false, low_priority_ = false, loop_ = true, res_ = false;
-    int exact_degenerate_ = 1, xcd_off_ = 0, fault_ = 0;
+    int exact_degenerate_ = 1, xcd_off_ = 0, fault_ = 0, loop_share_ = 1;
     int cond_guard_ = 1;
     hipStream_t stream_ = nullptr, stream_hi_ = nullptr, stream_lo_ = nullptr, copy_stream_ = nullptr;   // stream_: the one this run uses
     Buf *b_;

@@ -113,9 +113,15 @@ def solve_wave(solve_shard: Callable[[List[list]], tuple], children: List[list],
     `solve_shard(list_of_children)` returns (status, z, x, has_x) arrays for that list (FrontierPool.solve on
     the GPU box; a stub in the gloo tests).  `shard`: make_shard(children, rank, world) of exactly this wave, built by the caller
     (optional: built here otherwise, every call)."""
+    import time
     mine, mine_children = shard if shard is not None else make_shard(children, rank, world)
+    t0 = time.perf_counter()
     status, z, x, has_x = solve_shard(mine_children)
+    t1 = time.perf_counter()
     zl, il = local_incumbent(mine, status, z, x, has_x, integrality)
+    t2 = time.perf_counter()
     zg, ig = allreduce_incumbent(zl, il, dist, device, comm)
+    t3 = time.perf_counter()
+    # (seconds: this rank's solve, its host scan for the local incumbent, the exchange — which also absorbs the wait for the slowest rank)
     return {"indices": mine, "status": status, "z": z, "x": x, "has_x": has_x, "incumbent_z": zg, "incumbent_index": ig,
-            "local_incumbent_z": zl}
+            "local_incumbent_z": zl, "seconds_solve": t1 - t0, "seconds_scan": t2 - t1, "seconds_exchange": t3 - t2}
