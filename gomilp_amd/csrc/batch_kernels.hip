@@ -20,19 +20,9 @@
 
 #include "device_types.h"
 #include "kernels_common.h"
+#include "batch_dev.h"
 
 namespace gomilp {
-
-__device__ __forceinline__ int b_rho(const BatchLP &lp, int pos) {   // row of the 1 in the slack column at basis position pos
-    return pos < lp.K ? lp.m0 + lp.K - 1 - pos : lp.rho0[pos - lp.K];
-}
-__device__ __forceinline__ double b_rhs(const BatchLP &lp, int r) { return r < lp.m0 ? lp.b0[r] : lp.rhs[r - lp.m0]; }
-// cost of variable j in the given phase: Phase I minimises the artificial (simplex.go:545-547), Phase II c' = [c0, 0]
-__device__ __forceinline__ double b_cost(const BatchLP &lp, int phase, int j) {
-    if (phase == 1) return j == lp.n ? 1.0 : 0.0;
-    return j < lp.n0 ? lp.c0[j] : 0.0;
-}
-__host__ __device__ __forceinline__ int b_ldt(int nn) { return ((nn + 63) / 64) * 64; }
 
 __device__ __forceinline__ void b_reset_state(DevState *st) {
     st->done = 0; st->status = ST_RUNNING; st->pivots = 0; st->kdone = 0; st->bland_steps = 0; st->trace_len = 0;
@@ -169,37 +159,6 @@ __global__ __launch_bounds__(kBlock) void k_b_setup_warm(BatchLP *__restrict__ l
     }
 }
 
-// ---- T[pos, jp] = A'[rho(pos)][var(jp)] in 4x4 tiles, A' = [[A0, 0], [G#, I_K]] never materialised ---------------------
-__device__ __forceinline__ double b_entry(const BatchLP &lp, int pos, int jp, int nn) {
-    if (pos >= lp.m || jp >= nn) return 0.0;
-    if (lp.warm) {   // row 0 = the new branch row in the parent's nonbasic terms, then the parent's rows (k_b_setup_warm)
-        const int ldt = b_ldt(nn);
-        if (pos > 0) return lp.wT[tab_idx(pos - 1, jp, ldt, 1)];
-        const int kk = lp.K - 1, pv = lp.wposvar[lp.var[kk]];
-        if (pv >= 0) return -lp.sign[kk] * lp.wT[tab_idx(pv, jp, ldt, 1)];
-        return (-1 - pv) == jp ? lp.sign[kk] : 0.0;
-    }
-    if (lp.gen) {
-        const int nn0 = lp.n0 - lp.m0;
-        if (jp >= nn0) return lp.art[pos];   // the artificial (tableau space, by position: k_b_setup)
-        if (pos >= lp.K) return lp.gT0[(size_t)(pos - lp.K) * lp.gldt + jp];
-        // branch row kk: sign * x_var + s = rhs with x_var = x_B0[pv] - T0[pv, :] x_N (var basic at pv) or the nonbasic variable itself
-        const int kk = lp.K - 1 - pos, pv = lp.gposvar0[lp.var[kk]];
-        if (pv >= 0) return -lp.sign[kk] * lp.gT0[(size_t)pv * lp.gldt + jp];
-        return (-1 - pv) == jp ? lp.sign[kk] : 0.0;
-    }
-    const int r = b_rho(lp, pos);
-    const int nn2 = lp.n - lp.m;
-    const int j = jp < nn2 ? jp : lp.n;   // slack start: the nonbasic list is 0 .. nn2-1 (+ the artificial)
-    if (j == lp.n) return lp.art[r];
-    if (j < lp.n0) {
-        if (r < lp.m0) return lp.At0[(size_t)j * lp.ld0 + r];
-        const int kk = r - lp.m0;
-        return lp.var[kk] == j ? lp.sign[kk] : 0.0;   // G# row k = sign_k * e_{var_k} (subproblem.go:245-255)
-    }
-    return (r == lp.m0 + (j - lp.n0)) ? 1.0 : 0.0;    // (a branch slack can only be nonbasic here if the list said so)
-}
-
 // mode 0: every relaxation's whole tableau.
 // mode 1 (with k_b_gather mode 2 behind the set-up block): a relaxation that starts with the forced Phase-I pivot (BS_FORCED) gets only
 //   the 32 x 32 blocks that hold the pivot's row and column — all the block kernel reads for that one pivot;
@@ -207,21 +166,45 @@ __device__ __forceinline__ double b_entry(const BatchLP &lp, int pos, int jp, in
 //   k_bt_update_tiled_batch (a rounded multiply, a rounded add, then the + 0 of its seven empty terms) — the tableau is written once
 //   instead of written, read and written again: on a wide frontier wave, where Phase I is most of the work, 4.9 GB instead of 14.7 GB
 //   (2048 children).  Everybody else was gathered in full by mode 1 and has no term to apply (kmax = 0 in the set-up block).
+// mode 3 (virtual tableau, BatchLP::virt == 1: the set-up pivot and the first block ran on computed entries): the tableau of every relaxation
+//   that is still alive, ONCE: T0, the set-up pivot's term (U / V row 8) as mode 2 applies it, then the first block's kdone terms (rows 0 .. 7)
+//   in the arithmetic of k_bt_update_tiled_batch<8> (k ascending, a rounded multiply and a rounded add per term, empty terms as + 0 * 0) — the
+//   bits the materialised path would hold behind its first update.  Relaxations whose Phase I ended inside the block with the artificial
+//   above the zero tolerance are skipped by the update kernel's own test: on a B&B frontier that is nearly all of a wide wave.
 constexpr int kGatherTiles = 8;   // 32 x 32 blocks per workgroup, side by side in a row of blocks (one block per workgroup: 554 k workgroups of ~1 us for a 2048-wide wave)
 __global__ void k_b_gather(const BatchLP *__restrict__ lps, int mode) {
     __shared__ double tile[32][33];
+    __shared__ int s_skip3;
     const BatchLP &lp = lps[blockIdx.z];
     if (lp.stage == BS_HOST || lp.stage == BS_DONE || lp.stage == BS_COLD) return;
     const int m = lp.m, nn = lp.bt.nn, ldt = lp.bt.ldt;
     const int m4 = (m + 3) & ~3;
     const int p0 = blockIdx.x * 32;
     if (p0 >= m4) return;
+    if (mode == 3) {
+        if (lp.virt != 1) return;
+        if (lp.stage == BS_P1 && lp.st->done) {   // (the test of k_bt_update_tiled_batch: nobody reads this tableau again)
+            const int status = lp.st->status;
+            if (status == ST_UNBOUNDED || status == ST_BLAND_FAILED) return;
+            if (status == ST_OPTIMAL) {
+                const int t0 = threadIdx.y * 32 + threadIdx.x;
+                if (t0 == 0) s_skip3 = 0;
+                __syncthreads();
+                for (int i = t0; i < lp.m; i += 256)
+                    if (lp.basic[i] == lp.n && fabs(lp.xb[i]) > 1e-13) s_skip3 = 1;
+                __syncthreads();
+                if (s_skip3) return;
+            }
+        }
+    }
     const bool forced = lp.stage == BS_FORCED;
     if (mode == 2 && !forced) return;
     const int fp = lp.bt.forced_p, fq = lp.bt.forced_q;
     const bool rowhit = fp >= p0 && fp < p0 + 32;
     const bool term = mode == 2 && lp.st->kdone > 0;   // (uniform) the pivot ran: its term, row 0 of U / V
     const double *U = lp.bt.U, *V = lp.bt.V;
+    const int kd3 = mode == 3 ? lp.st->kdone : 0;       // mode 3: terms of the first block
+    const int ldu3 = lp.bt.ldu;
     double *T = lp.T[0];
     const int t = threadIdx.y * 32 + threadIdx.x;
     const int til = t >> 2, rit = t & 3;
@@ -232,6 +215,23 @@ __global__ void k_b_gather(const BatchLP *__restrict__ lps, int mode) {
         if (mode == 1 && forced && !rowhit && !(fq >= j0 && fq < j0 + 32)) continue;   // (uniform)
         for (int rr = threadIdx.y; rr < 32; rr += 8) {
             double v = b_entry(lp, p0 + threadIdx.x, j0 + rr, nn);
+            if (mode == 3) {
+                const int pos = p0 + threadIdx.x, jp = j0 + rr;
+                if (lp.virt_t0) {
+                    const double u = pos < m ? U[(size_t)8 * ldu3 + pos] : 0.0;
+                    const double vv = jp < ldt ? V[(size_t)8 * ldt + jp] : 0.0;
+                    v = __dadd_rn(v, __dmul_rn(u, vv));
+                    v = __dadd_rn(v, 0.0);
+                }
+                if (kd3 > 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const double u = (k < kd3 && pos < m) ? U[(size_t)k * ldu3 + pos] : 0.0;
+                        const double vv = (k < kd3 && jp < ldt) ? V[(size_t)k * ldt + jp] : 0.0;
+                        v = __dadd_rn(v, __dmul_rn(u, vv));
+                    }
+                }
+            }
             if (term) {
                 const int pos = p0 + threadIdx.x, jp = j0 + rr;
                 const double u = pos < m ? U[pos] : 0.0;       // (rows beyond m: zero, as the update kernel stages them)
@@ -277,6 +277,9 @@ __global__ __launch_bounds__(kBlock) void k_b_ctrl(BatchLP *__restrict__ lps, co
     if (tid == 0) {
         lp.do_permute = 0; lp.do_r = 0; s_added = -1;
         if (loop_par >= 0) { lp.tcur = st->tsel2[(loop_par ^ 1) & 1] & 1; lp.bt.T = lp.T[lp.tcur]; }
+        // virtual tableau: 2 (set-up pivot) -> 1 (first block) -> 0 (k_b_gather mode 3 has written out what is alive, in front of this step)
+        if (lp.virt == 2) { lp.virt = 1; lp.virt_t0 = (stage == BS_FORCED && st->kdone > 0) ? 1 : 0; }
+        else if (lp.virt == 1) lp.virt = 0;
     }
     __syncthreads();
     bool to_phase2 = false;   // uniform
@@ -540,10 +543,12 @@ __global__ __launch_bounds__(kBlock) void k_b_tab_r_partial(const BatchLP *__res
     if (chunk >= nchunks || j >= ldt) return;
     const int i0 = chunk * rpc, i1 = min(m, i0 + rpc);
     const double *T = lp.bt.T;
+    const bool virt = lp.virt > 0;   // no tableau in HBM yet: the entries are computed (the set-up pivot's term: U / V row 8)
+    const double v0 = (virt && lp.virt_t0) ? lp.bt.V[(size_t)8 * ldt + j] : 0.0;
     double acc = 0;
     for (int i = i0; i < i1; i++) {
         const double cb = b_cost(lp, phase, lp.basic[i]);
-        if (cb != 0) acc += cb * T[tab_idx(i, j, ldt, 1)];
+        if (cb != 0) acc += cb * (virt ? b_virt_entry<true>(lp, i, j, lp.bt.nn, lp.virt_t0 ? lp.bt.U[(size_t)8 * lp.bt.ldu + i] : 0.0, v0) : T[tab_idx(i, j, ldt, 1)]);
     }
     lp.scratch[(size_t)chunk * ldt + j] = acc;
 }

@@ -31,6 +31,7 @@
 #include "device_types.h"
 #include "kernels_common.h"
 #include "bt_loop.h"
+#include "batch_dev.h"
 
 namespace gomilp {
 
@@ -325,10 +326,14 @@ struct BtWin { double m; unsigned int i; };   // minimum and the first index tha
 // LOOP: the pivot role of the batched persistent loop kernel (k_b_loop below): up to a.nblocks blocks of KR / 2 pivots in one launch; the
 // registers hold the running block's terms AND the previous block's (not yet in the tableau buffer this block reads: the update
 // workgroups of the same launch apply them beside this block) — the protocol of k_bt_loop (bt_loop.h) with ONE pivot workgroup.
-template <int NT, int RI, int CJ, int KR, int VL, bool STAMP = false, bool LOOP = false>
-__device__ __forceinline__ void bt_inner2_body(const BTArgs &a, const int nupd = 0) {
+// VIRT: the tableau does not exist in HBM yet (BatchLP::virt > 0: the set-up pivot and the first block of a wide wave): the column and the row
+// a pivot looks at are computed — T0 from the root's resident A and the child's branch rows, plus the set-up pivot's rank-1 term (batch_dev.h
+// b_virt_entry: the bits a read of the materialised tableau would return); the block's terms go on top as always
+template <int NT, int RI, int CJ, int KR, int VL, bool STAMP = false, bool LOOP = false, bool VIRT = false>
+__device__ __forceinline__ void bt_inner2_body(const BTArgs &a, const int nupd = 0, const BatchLP *vl = nullptr) {
     constexpr int NW = NT / 64;
     static_assert(!LOOP || (VL == 0 && !STAMP && (KR & 1) == 0), "loop mode: all terms in registers, KR / 2 lagging + KR / 2 current");
+    static_assert(!VIRT || (!LOOP && !STAMP), "virtual tableau: the plain block kernel only");
     constexpr int KB = LOOP ? KR / 2 : KR;   // pivots per block
     // STAMP: diagnostic build (context knob "bt_stamps"): every wave sums the shader cycles it spends in each segment of
     // a pivot (s_memtime, cdna_hip_programming.md §7 "In-kernel stamps") and adds them to a.stamps[wave][segment]; the
@@ -359,6 +364,10 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a, const int nupd =
     double *vl_s = reinterpret_cast<double *>(nonbasic_s + CJ * NT);   // VL*KR*NT, element (slot, ring position, thread)
     constexpr int CR = CJ - VL;   // column slots with register-resident terms
     int vhead = 0;                // ring position of the newest term
+    // virtual tableau: the set-up pivot's term u0 (by row), v0' (by column) for the scalar look-ups (own rows / columns: registers)
+    double *u0_s = vl_s + VL * KR * NT;   // RI*NT
+    double *v0_s = u0_s + RI * NT;        // CJ*NT
+    double u0r[RI], v0r[CJ];
     __shared__ double redMA[16], redMB[16];
     __shared__ unsigned int redIA[16], redIB[16];
     __shared__ double payA[16][KR + 1];  // per wave: r_q, v'_k[q]
@@ -445,6 +454,14 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a, const int nupd =
         }
     }
     if (tid < KR + 1) payA[0][tid] = 0;   // a host-chosen first pivot reads v'_k[q] = 0 from here
+    if constexpr (VIRT) {
+        const bool t0 = vl->virt_t0 != 0;
+        const double *U8 = a.U + (size_t)8 * a.ldu, *V8 = a.V + (size_t)8 * a.ldt;   // the set-up pivot's term: row 8 (the block's own terms take rows 0 .. 7)
+#pragma unroll
+        for (int s = 0; s < RI; s++) { const int i = tid + s * NT; u0r[s] = (t0 && i < a.m) ? U8[i] : 0.0; u0_s[i] = u0r[s]; }
+#pragma unroll
+        for (int s = 0; s < CJ; s++) { const int j = tid + s * NT; v0r[s] = (t0 && j < a.ldt) ? V8[j] : 0.0; v0_s[j] = v0r[s]; }
+    }
     __syncthreads();
     int kd = 0, status = ST_RUNNING, blands = 0;
     // thread 0 keeps the pivot / trace counters in registers: a global read-modify-write per pivot would stall its wave
@@ -544,11 +561,15 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a, const int nupd =
             BT_STAMP(4);   // block corrections of the column
             return;
         }
+        double v0q = 0;
+        if constexpr (VIRT) v0q = v0_s[q];
 #pragma unroll
         for (int s = 0; s < RI; s++) {
             const int i = tid + s * NT;
             const unsigned int ic = (unsigned int)(i < a.m ? i : a.m - 1);
-            double d = ldT(tile_off(ic, (unsigned int)q, ldt));   // T in 4x4 tiles (k_bt_tile)
+            double d;
+            if constexpr (VIRT) d = b_virt_entry<false>(*vl, (int)ic, q, a.nn, i < a.m ? u0r[s] : u0_s[ic], v0q);
+            else d = ldT(tile_off(ic, (unsigned int)q, ldt));   // T in 4x4 tiles (k_bt_tile)
 #pragma unroll
             for (int j = 0; j < KR; j++) d = __builtin_fma(ureg[s][j], vq[j], d);
             dcol[s] = i < a.m ? d : 0.0;
@@ -575,6 +596,7 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a, const int nupd =
     };
 
     int nbe = 0, cur0 = 0;   // loop mode: blocks run by this launch; first U / V row of the running block
+    if constexpr (VIRT) { if (vl->virt == 2) cur0 = 8; }   // the set-up pivot's term is kept beside the first block's (rows 0 .. 7): both are applied when the tableau is written out
     bool dead = false;       // loop mode: an update counter made no progress within the limit
     for (int blk = 0; blk < (LOOP ? a.nblocks : 1); blk++) {
     if constexpr (LOOP) {
@@ -741,10 +763,13 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a, const int nupd =
         };
         // the row loads go out first: the u terms / x_B update below need nothing from them and run under their latency
         double vrow[CJ];
+        double u0p = 0;
+        if constexpr (VIRT) u0p = u0_s[p];
 #pragma unroll
         for (int s = 0; s < CJ; s++) {
             const int j = tid + s * NT;
-            vrow[s] = j < a.ldt ? ldT(tile_off((unsigned int)p, (unsigned int)j, ldt)) : 0.0;   // columns nn..ldt of T are zero
+            if constexpr (VIRT) vrow[s] = j < a.ldt ? b_virt_entry<true>(*vl, p, j, a.nn, u0p, v0r[s]) : 0.0;
+            else vrow[s] = j < a.ldt ? ldT(tile_off((unsigned int)p, (unsigned int)j, ldt)) : 0.0;   // columns nn..ldt of T are zero
         }
 #pragma unroll
         for (int s = 0; s < RI; s++) {
@@ -1127,6 +1152,17 @@ __global__ __launch_bounds__(NT) void k_bt_inner2_batch(const BatchLP *__restric
     if (stage == BS_DONE || stage == BS_HOST || stage == BS_DUAL || stage == BS_COLD) return;   // (BS_DUAL: the dual kernel's)
     const BTArgs a = lp.bt;
     bt_inner2_body<NT, RI, CJ, KR, VL, false>(a);
+}
+
+// the same while the wave's tableaus are virtual (BatchLP::virt > 0: engine_batch.cpp)
+template <int NT, int RI, int CJ, int KR, int VL>
+__global__ __launch_bounds__(NT) void k_bt_inner2_virt_batch(const BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count) {
+    if ((int)blockIdx.x >= *count) return;
+    const BatchLP &lp = lps[ids[blockIdx.x]];
+    const int stage = lp.stage;
+    if (stage == BS_DONE || stage == BS_HOST || stage == BS_DUAL || stage == BS_COLD || lp.virt <= 0) return;
+    const BTArgs a = lp.bt;
+    bt_inner2_body<NT, RI, CJ, KR, VL, false, false, true>(a, 0, &lp);
 }
 
 // ---- batched persistent loop kernel (round 4) -----------------------------------------------------------------------------------------
@@ -1547,6 +1583,16 @@ void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count,
     const BtCfg c = bt_cfg(m_max, ldt_max, 0);
     if (c.ri == 2) { if (c.nt == 512) bt_inner_batch_nt<512, 2, 0>(lps, ids, count, nlp, s, e0, e1); else bt_inner_batch_nt<1024, 2, 1>(lps, ids, count, nlp, s, e0, e1); }
     else bt_inner_batch_nt<512, 4, 0>(lps, ids, count, nlp, s, e0, e1);
+}
+// virtual-tableau form (the 512-thread, two rows + two columns per thread instance: relaxations of up to 1024 rows / columns)
+bool bt_virt_batch_supported(int m_max, int ldt_max) {
+    if (bt_batch_k(m_max, ldt_max) != 8) return false;
+    const BtCfg c = bt_cfg(m_max, ldt_max, 0);
+    return c.ri == 2 && c.nt == 512;
+}
+void launch_bt_inner_virt_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const size_t lds = (size_t)(2 + 2) * 512 * (sizeof(double) + sizeof(int)) + (size_t)(2 + 2) * 512 * sizeof(double);
+    hipExtLaunchKernelGGL((k_bt_inner2_virt_batch<512, 2, 2, 8, 0>), dim3(nlp), dim3(512), lds, s, e0, e1, 0, lps, ids, count);
 }
 // batched persistent loop kernel: relaxations of up to 1024 rows / columns (two rows + two columns per thread)
 constexpr int kBLoopNU = 7;   // update workgroups per relaxation: 1 + 7 = 8 workgroups, four relaxations per XCD, 32 per launch

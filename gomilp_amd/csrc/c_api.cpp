@@ -39,7 +39,7 @@ struct gomilp_pool {
     std::unique_ptr<BatchEngine> batch;
     std::unique_ptr<BatchEngine> batch2;   // second schedule (split waves, waves of large relaxations; created on first use)
     std::unique_ptr<BatchEngine> batchx[2];   // third and fourth schedule for waves of large relaxations (split_large)
-    int cond_guard = 1, exact_degenerate = 1, sample_batch = 0, batch_loop = 1, batch_res = 0;   // knob values kept for batch2: both halves of a split wave decide alike
+    int cond_guard = 1, exact_degenerate = 1, sample_batch = 0, batch_loop = 1, batch_res = 0, batch_virt = 1;   // knob values kept for batch2: both halves of a split wave decide alike
     int split_large = 1;        // knob: waves of >= 4 large relaxations run as two interleaved schedules
     int split_phase = 1;        // knob: relaxations that start feasible (Phase II from the slack basis: the long pivot chains of a wave) and
                                 // relaxations that need Phase I (on a B&B frontier mostly proved infeasible within a few pivots) run as two
@@ -206,6 +206,13 @@ int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value) {
     if (std::string(key) == "batched") { pool->batched = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "split_large") { pool->split_large = value ? 1 : 0; return GOMILP_OK; }
     if (std::string(key) == "split_phase") { pool->split_phase = value ? 1 : 0; return GOMILP_OK; }
+    if (std::string(key) == "batch_virt") {   // wide waves on virtual tableaus for their first block (default 1)
+        pool->batch_virt = value ? 1 : 0;
+        pool->batch->set_virt(value != 0);
+        if (pool->batch2) pool->batch2->set_virt(value != 0);
+        for (auto &bx : pool->batchx) if (bx) bx->set_virt(value != 0);
+        return GOMILP_OK;
+    }
     if (std::string(key) == "batch_res") {   // block steps of narrow waves in the register-resident kernel (opt-in, default 0: k_b_loop / launch pairs)
         pool->batch_res = value ? 1 : 0;
         pool->batch->set_res(value != 0);
@@ -425,6 +432,7 @@ static int frontier_solve_impl(gomilp_pool *pool, int64_t count, const int32_t *
                 pool->batch2->set_sampling(pool->sample_batch != 0);
                 pool->batch2->set_loop(pool->batch_loop != 0);
                 pool->batch2->set_res(pool->batch_res != 0);
+                pool->batch2->set_virt(pool->batch_virt != 0);
             }
         };
         auto merge_stats = [&](const BatchEngine::Stats &bs2, bool serial) {
@@ -536,6 +544,7 @@ static int frontier_solve_impl(gomilp_pool *pool, int64_t count, const int32_t *
                     pool->batchx[t - 2]->set_sampling(pool->sample_batch != 0);
                     pool->batchx[t - 2]->set_loop(pool->batch_loop != 0);
                     pool->batchx[t - 2]->set_res(pool->batch_res != 0);
+                    pool->batchx[t - 2]->set_virt(pool->batch_virt != 0);
                 }
                 be[t] = pool->batchx[t - 2].get();
             }

@@ -218,6 +218,14 @@ struct BatchLP {
     int32_t warm, wm;        // warm = 1: start from that state (m = wm + 1)
     int32_t dual_budget, pad1;   // dual pivots before the relaxation is handed back (BS_COLD)
     int64_t pivd;            // dual pivots performed
+    // Virtual tableau (wide waves of slack-start relaxations, engine_batch.cpp): virt = 2 while the host-chosen Phase-I pivot runs, 1 while the
+    // first block of 8 pivots runs, 0 from then on (k_b_ctrl counts it down).  While virt > 0 NO tableau exists in HBM: the block kernel
+    // (k_bt_inner2_virt_batch) and the reduced-cost kernel compute the entries they read — T0 = rows / columns of the ROOT's A (b_entry) plus
+    // the set-up pivot's rank-1 term (virt_t0: U / V row 8) — and only what survives the first block is written out, once, with the
+    // block's terms applied in the update kernel's arithmetic (k_b_gather mode 3).  On a B&B frontier most relaxations are proved
+    // infeasible inside that block: their 2.4 MB tableaus (4.9 of the 7.2 GB a 2048-wide wave moved) are never written.
+    const double *A0r;       // the root's A row-major (m0 x lda0r): a row of T0 as one contiguous read (At0 serves the columns)
+    int32_t lda0r, virt, virt_t0, pad2;
     double tol_user;         // Phase-II tolerance of the call (GoMILP: 0)
     int32_t stage;           // BS_*
     int32_t tcur;            // index of the current T buffer

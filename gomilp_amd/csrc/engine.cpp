@@ -1543,8 +1543,21 @@ bool Engine::root_view(int64_t id, RootView *out) {
         if (!(P.nnz[j] == 1 && P.allone[j]) || used[P.lastrow[j]]) { out->unit_basis = false; break; }
         out->rho0[pos] = P.lastrow[j]; used[P.lastrow[j]] = 1;
     }
+    out->rm.reset();
+    if (out->unit_basis && P.verify_status == GOMILP_OK && (size_t)P.m * (size_t)P.n <= ((size_t)1 << 23) && hipSetDevice(device_) == hipSuccess) {
+        if (!stream_ && hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) return true;
+        std::shared_ptr<RootView::RowMajor> rm(new RootView::RowMajor);
+        rm->lda = (P.n + 1) & ~1;
+        if (dmalloc(&rm->dA, (size_t)P.m * rm->lda) == hipSuccess) {
+            // "A" of the transposing kernel = At (n rows of ld), its output = m rows of lda: dA[i * lda + j] = At[j * ld + i]
+            launch_transpose_in(P.dAt, P.ld, P.n, P.m, rm->dA, rm->lda, stream_);
+            if (hipStreamSynchronize(stream_) == hipSuccess) out->rm = rm;
+        }
+    }
     return true;
 }
+
+Engine::RootView::RowMajor::~RowMajor() { if (dA) hipFree(dA); }
 
 Engine::RootView::General::~General() {
     for (void *p : {(void *)dT0, (void *)dxb0, (void *)dbasic0, (void *)dnonbasic0, (void *)dposvar0}) if (p) hipFree(p);

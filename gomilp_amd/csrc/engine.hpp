@@ -92,6 +92,9 @@ class Engine {
             ~General();
         };
         std::shared_ptr<General> gen;     // null: slack basis, or no usable basis (the single-relaxation engine reports why)
+        // the root's A row-major on the device (one transposing copy per root): rows of the virtual tableau of a wide wave (BatchLP::A0r)
+        struct RowMajor { double *dA = nullptr; int lda = 0; ~RowMajor(); };
+        std::shared_ptr<RowMajor> rm;     // null: not made (large roots)
     };
     bool root_view(int64_t id, RootView *out);
     // fills out->gen for a root without a slack basis (false: not possible — too large for the host copy of A, singular, ...)
@@ -274,6 +277,9 @@ int bt_batch_k(int m_max, int ldt_max);
 void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int xcd_off = 0);
 void launch_bt_update_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 const char *bt_batch_kernel_name(int m_max, int ldt_max);
+// the batched block kernel on a virtual tableau (bt_kernels.hip k_bt_inner2_virt_batch; BatchLP::virt)
+bool bt_virt_batch_supported(int m_max, int ldt_max);
+void launch_bt_inner_virt_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 // batched persistent loop kernel (bt_kernels.hip k_b_loop): relaxations per launch on a device with ncu CUs; shapes it takes
 int b_loop_slots(int ncu);
 bool b_loop_supported(int m_max, int ldt_max);

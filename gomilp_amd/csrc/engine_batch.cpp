@@ -288,6 +288,8 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
     // ---- per-relaxation argument blocks
     std::vector<std::shared_ptr<WarmEntry>> warm_used;
     int nwarm = 0;
+    bool slack_only = true;   // every relaxation starts from a slack basis of a root whose A is resident row-major too (virtual tableau below)
+    for (int r = 0; r < nroots; r++) if (!roots[r]->unit_basis || roots[r]->gen || !roots[r]->rm) slack_only = false;
     const size_t sT = (size_t)b.cap_m4 * b.cap_ldt;
     for (int64_t k = 0; k < ktot; k++) { b.h_var[k] = var[koff[0] + k]; b.h_sr[k] = sign[koff[0] + k]; b.h_sr[b.cap_k + k] = rhs[koff[0] + k]; }
     for (int i = 0; i < nlp; i++) {
@@ -298,6 +300,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         const int ri = root_of ? root_of[i] : 0;
         const Engine::RootView &R = *roots[ri];
         lp.At0 = R.dAt; lp.c0 = R.dc; lp.b0 = R.db; lp.rho0 = rho_of[ri];
+        if (R.rm) { lp.A0r = R.rm->dA; lp.lda0r = R.rm->lda; }
         if (!R.unit_basis && R.gen) {   // equality rows: start from the root's searched basis + the branch slacks
             lp.gen = 1; lp.gT0 = R.gen->dT0; lp.gxb0 = R.gen->dxb0; lp.gbasic0 = R.gen->dbasic0; lp.gnonbasic0 = R.gen->dnonbasic0;
             lp.gposvar0 = R.gen->dposvar0; lp.gldt = R.gen->ldt;
@@ -332,6 +335,11 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         lp.bt.xbuf = b.d_xbuf + (size_t)i * bt_xbuf_doubles();
         if (kb == 16) { lp.bt.groups = grp.groups; lp.bt.group_ri = grp.ri; lp.bt.group_nt = grp.nt; }
     }
+    // Virtual tableau (device_types.h BatchLP::virt): a WIDE wave of slack-start relaxations runs its set-up pivot and its first block of 8
+    // pivots on computed tableau entries; only what is alive behind that block is written out.  Narrow waves go to the persistent kernels
+    // with the first superstep and need their tableaus at once.
+    const bool virt_on = virt_ && slack_only && nwarm == 0 && kb == 8 && bt_virt_batch_supported(m_max, ldt1) && nlp > std::max(std::max(loop_slots, res_slots), 32);
+    if (virt_on) for (int i = 0; i < nlp; i++) b.h_lps[i].virt = 2;
     B_TRY(hipMemsetAsync(b.d_active, 0, kMaxSteps * sizeof(int), stream_));
     B_TRY(hipMemsetAsync(b.d_out, 0, (size_t)nlp * sizeof(BatchOut), stream_));   // stage 0 = not terminal
     B_TRY(hipMemcpyAsync(b.d_lps, b.h_lps, (size_t)nlp * sizeof(BatchLP), hipMemcpyHostToDevice, stream_));
@@ -358,6 +366,21 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         const int *ids = b.d_ids[(step + 1) & 1];
         const int *cnt = step == 0 ? b.d_active + (kMaxSteps - 1) : b.d_active + (step - 1);
         last_loop_par = -1;
+        if (virt_on && step <= 1) {
+            // step 0: the set-up pivot (term -> U / V row 8); step 1: the first block, then the tableaus of the survivors — written once, both
+            // applied (k_b_gather mode 3) — in front of the control step that may read them
+            hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+            if (sampling_) {
+                while (b.samp_ev.size() < (size_t)(nsamp + 1) * 4) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) break; b.samp_ev.push_back(ev); }
+                if (b.samp_ev.size() >= (size_t)(nsamp + 1) * 4) { for (int q = 0; q < 4; q++) e[q] = b.samp_ev[(size_t)nsamp * 4 + q]; nsamp++; }
+            }
+            launch_bt_inner_virt_batch(b.d_lps, ids, cnt, bound, stream_, e[0], e[1]);
+            if (e[2]) hipEventRecord(e[2], stream_);
+            if (step == 1) launch_b_gather(b.d_lps, nlp, m_max, ldt1, 3, stream_);
+            if (e[3]) hipEventRecord(e[3], stream_);
+            S.launches += step == 1 ? 2 : 1; S.blocks += 1; S.virt_blocks += 1;
+            return;
+        }
         if (allow_loop && res_slots > 0 && bound <= res_slots && nwarm == 0) {
             hipEvent_t e[2] = {nullptr, nullptr};
             if (sampling_) {
@@ -421,8 +444,8 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
     // the tiled rank-8 update (blocks of 8 pivots) has its arithmetic in the gather too: relaxations that start with the forced Phase-I
     // pivot get the pivot's row and column first, the whole tableau once, with the pivot applied, behind the set-up block
     const bool fuse_setup = kb == 8;
-    launch_b_gather(b.d_lps, nlp, m_max, ldt1, fuse_setup ? 1 : 0, stream_);
-    S.launches += 2;
+    if (!virt_on) launch_b_gather(b.d_lps, nlp, m_max, ldt1, fuse_setup ? 1 : 0, stream_);
+    S.launches += virt_on ? 1 : 2;
     S.warm_started = nwarm;
     blocks(1, false, fuse_setup);   // (set-up pivots: one block each, launch pair)
     control(false);
@@ -494,6 +517,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         // a loop launch has no boundary between its blocks: longer supersteps (fewer control steps on the chain) once the wave is narrow
         if (loop_slots > 0 && bound <= loop_slots && step >= 2 && nwarm == 0) nb = bound <= 8 ? (step >= 3 ? 32 : 16) : 8;
         if (res_slots > 0 && bound <= res_slots && nwarm == 0) nb = step >= 3 ? 32 : (step >= 1 ? 16 : 8);   // one launch whatever the length: longer supersteps from the start
+        if (virt_on && step == 0) nb = 1;   // (the first block of a wave with virtual tableaus: one block step)
         step++;
         blocks(nb, true);
         control(true);

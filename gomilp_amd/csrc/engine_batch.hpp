@@ -59,7 +59,7 @@ class BatchEngine {
         int warm = 0;                                      // started from its parent's basis
     };
     struct Stats {
-        int64_t launches = 0, supersteps = 0, blocks = 0, loop_launches = 0, res_launches = 0, warm_started = 0, warm_kept = 0;
+        int64_t launches = 0, supersteps = 0, blocks = 0, loop_launches = 0, res_launches = 0, virt_blocks = 0, warm_started = 0, warm_kept = 0;
         double seconds_setup = 0, seconds_total = 0;
         double seconds_inner = 0, seconds_update = 0;   // HIP-event time of the sampled block launches (set_sampling)
         int64_t blocks_sampled = 0;
@@ -75,6 +75,7 @@ class BatchEngine {
     // several schedules of one pool side by side (a split wave): each sizes its persistent launches for 1 / share of the device's loop slots —
     // every workgroup of such a launch must be resident, and two schedules that each plan for the whole device wait for each other's CUs
     void set_loop_share(int share) { loop_share_ = share < 1 ? 1 : share; }
+    void set_virt(bool on) { virt_ = on; }   // wide waves: set-up pivot and first block on computed tableau entries, only the survivors' tableaus written (default on)
     void set_loop(bool on) { loop_ = on; }   // block steps in the persistent loop kernel where the active relaxations fit one launch (default on)
     void set_cond_guard(int v) { cond_guard_ = v; }   // as the engine knob of the same name
     void set_exact_degenerate(int v) { exact_degenerate_ = v; }   // as the engine knob of the same name
@@ -102,7 +103,7 @@ class BatchEngine {
     struct Buf;
     int ensure(int nlp, int m_max, int n_max, int ldt1, int64_t ktot);
     int device_;
-    bool sampling_ = false, low_priority_ = false, loop_ = true, res_ = false;
+    bool sampling_ = false, low_priority_ = false, loop_ = true, res_ = false, virt_ = true;
     int exact_degenerate_ = 1, xcd_off_ = 0, fault_ = 0, loop_share_ = 1;
     int cond_guard_ = 1;
     hipStream_t stream_ = nullptr, stream_hi_ = nullptr, stream_lo_ = nullptr, copy_stream_ = nullptr;   // stream_: the one this run uses
