@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "device_types.h"
 #include "kernels_common.h"
 #include "batch_dev.h"
@@ -27,7 +29,7 @@ namespace gomilp {
 __device__ __forceinline__ void b_reset_state(DevState *st) {
     st->done = 0; st->status = ST_RUNNING; st->pivots = 0; st->kdone = 0; st->bland_steps = 0; st->trace_len = 0;
     st->max_pivots = 0; st->lu_singular = 0;
-    st->kdone2[0] = st->kdone2[1] = 0; st->loop_blocks = 0;
+    st->kdone2[0] = st->kdone2[1] = 0; st->loop_blocks = 0; st->dead1 = 0;
 }
 
 // ---- set-up: slack basis of the child, feasibility, Phase-I order ---------------------------------------------------
@@ -115,6 +117,7 @@ __global__ __launch_bounds__(kBlock) void k_b_setup(BatchLP *__restrict__ lps) {
             lp.nonbasic[nn2] = n;   // the artificial is the last nonbasic column; one forced pivot brings it to position minidx
             a.nn = nn1; a.ldt = b_ldt(nn1); a.phase = 1; a.tol = 1e-10; a.kmax = 1;
             a.forced_q = nn1 - 1; a.forced_p = minidx; a.forced_nocommit = 2;   // lists exchanged on the device, uncounted
+            lp.art_pos = minidx;
             lp.stage = art_zero ? BS_HOST : BS_FORCED;   // zero artificial column: verifyInputs of the recursive call fails (host path reports it)
         }
     }
@@ -172,33 +175,20 @@ __global__ __launch_bounds__(kBlock) void k_b_setup_warm(BatchLP *__restrict__ l
 //   bits the materialised path would hold behind its first update.  Relaxations whose Phase I ended inside the block with the artificial
 //   above the zero tolerance are skipped by the update kernel's own test: on a B&B frontier that is nearly all of a wide wave.
 constexpr int kGatherTiles = 8;   // 32 x 32 blocks per workgroup, side by side in a row of blocks (one block per workgroup: 554 k workgroups of ~1 us for a 2048-wide wave)
-__global__ void k_b_gather(const BatchLP *__restrict__ lps, int mode) {
+__global__ void k_b_gather(const BatchLP *__restrict__ lps, int nlp, int mode) {
     __shared__ double tile[32][33];
-    __shared__ int s_skip3;
-    const BatchLP &lp = lps[blockIdx.z];
-    if (lp.stage == BS_HOST || lp.stage == BS_DONE || lp.stage == BS_COLD) return;
+    // (grid.z may be smaller than the wave: a slice walks the relaxations z, z + gridDim.z, ... — mode 3 visits a wide wave of which a few
+    // per cent are alive, and one workgroup per relaxation and tile that only finds out that it has nothing to do was most of its time)
+    for (int zi = blockIdx.z; zi < nlp; zi += gridDim.z) {
+    const BatchLP &lp = lps[zi];
+    if (lp.stage == BS_HOST || lp.stage == BS_DONE || lp.stage == BS_COLD) continue;
     const int m = lp.m, nn = lp.bt.nn, ldt = lp.bt.ldt;
     const int m4 = (m + 3) & ~3;
     const int p0 = blockIdx.x * 32;
-    if (p0 >= m4) return;
-    if (mode == 3) {
-        if (lp.virt != 1) return;
-        if (lp.stage == BS_P1 && lp.st->done) {   // (the test of k_bt_update_tiled_batch: nobody reads this tableau again)
-            const int status = lp.st->status;
-            if (status == ST_UNBOUNDED || status == ST_BLAND_FAILED) return;
-            if (status == ST_OPTIMAL) {
-                const int t0 = threadIdx.y * 32 + threadIdx.x;
-                if (t0 == 0) s_skip3 = 0;
-                __syncthreads();
-                for (int i = t0; i < lp.m; i += 256)
-                    if (lp.basic[i] == lp.n && fabs(lp.xb[i]) > 1e-13) s_skip3 = 1;
-                __syncthreads();
-                if (s_skip3) return;
-            }
-        }
-    }
+    if (p0 >= m4) continue;
+    if (mode == 3 && (lp.virt != 1 || lp.st->dead1)) continue;   // (dead1: the block kernel's verdict — the test of k_bt_update_tiled_batch, taken once per relaxation)
     const bool forced = lp.stage == BS_FORCED;
-    if (mode == 2 && !forced) return;
+    if (mode == 2 && !forced) continue;
     const int fp = lp.bt.forced_p, fq = lp.bt.forced_q;
     const bool rowhit = fp >= p0 && fp < p0 + 32;
     const bool term = mode == 2 && lp.st->kdone > 0;   // (uniform) the pivot ran: its term, row 0 of U / V
@@ -206,6 +196,14 @@ __global__ void k_b_gather(const BatchLP *__restrict__ lps, int mode) {
     const int kd3 = mode == 3 ? lp.st->kdone : 0;       // mode 3: terms of the first block
     const int ldu3 = lp.bt.ldu;
     double *T = lp.T[0];
+    // mode 3: the nine u entries of this thread's row (the same for every column it visits)
+    double u3[9];
+    if (mode == 3) {
+        const int pos = p0 + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 8; k++) u3[k] = (k < kd3 && pos < m) ? U[(size_t)k * ldu3 + pos] : 0.0;
+        u3[8] = (lp.virt_t0 && pos < m) ? U[(size_t)8 * ldu3 + pos] : 0.0;
+    }
     const int t = threadIdx.y * 32 + threadIdx.x;
     const int til = t >> 2, rit = t & 3;
     const int tr = til >> 3, tc = til & 7;
@@ -216,20 +214,18 @@ __global__ void k_b_gather(const BatchLP *__restrict__ lps, int mode) {
         for (int rr = threadIdx.y; rr < 32; rr += 8) {
             double v = b_entry(lp, p0 + threadIdx.x, j0 + rr, nn);
             if (mode == 3) {
-                const int pos = p0 + threadIdx.x, jp = j0 + rr;
+                const int jp = j0 + rr;
                 if (lp.virt_t0) {
-                    const double u = pos < m ? U[(size_t)8 * ldu3 + pos] : 0.0;
                     const double vv = jp < ldt ? V[(size_t)8 * ldt + jp] : 0.0;
-                    v = __dadd_rn(v, __dmul_rn(u, vv));
+                    v = __dadd_rn(v, __dmul_rn(u3[8], vv));
                     v = __dadd_rn(v, 0.0);
                 }
                 if (kd3 > 0) {
+                    double vk[8];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const double u = (k < kd3 && pos < m) ? U[(size_t)k * ldu3 + pos] : 0.0;
-                        const double vv = (k < kd3 && jp < ldt) ? V[(size_t)k * ldt + jp] : 0.0;
-                        v = __dadd_rn(v, __dmul_rn(u, vv));
-                    }
+                    for (int k = 0; k < 8; k++) vk[k] = (k < kd3 && jp < ldt) ? V[(size_t)k * ldt + jp] : 0.0;   // (all eight loads in flight together)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) v = __dadd_rn(v, __dmul_rn(u3[k], vk[k]));
                 }
             }
             if (term) {
@@ -255,6 +251,7 @@ __global__ void k_b_gather(const BatchLP *__restrict__ lps, int mode) {
             dst[0] = lo; dst[1] = hi;   // padding rows / columns are zeros
         }
         __syncthreads();   // (the block's values are out of LDS before the next one comes in)
+    }
     }
 }
 
@@ -541,6 +538,21 @@ __global__ __launch_bounds__(kBlock) void k_b_tab_r_partial(const BatchLP *__res
     const int nchunks = b_r_chunks(m), rpc = (m + nchunks - 1) / nchunks;
     const int chunk = blockIdx.y, j = blockIdx.x * kBlock + threadIdx.x;
     if (chunk >= nchunks || j >= ldt) return;
+    // Phase I on a slack start: the artificial (cost 1) sits at its entering position, every other basic variable costs nothing — the sum
+    // below is the one term 0 + 1 * T[art_pos, j] in the chunk of that row and zeros elsewhere (a wide wave spent more time finding that
+    // out row by row than on the pivots of the block)
+    if (phase == 1 && !lp.gen && !lp.warm && lp.art_pos >= 0 && lp.art_pos < m && lp.basic[lp.art_pos] == lp.n) {
+        const int i = lp.art_pos;
+        double acc1 = 0;
+        if (i >= chunk * rpc && i < min(m, chunk * rpc + rpc)) {
+            const bool virt1 = lp.virt > 0;
+            const double t = virt1 ? b_virt_entry<true>(lp, i, j, lp.bt.nn, lp.virt_t0 ? lp.bt.U[(size_t)8 * lp.bt.ldu + i] : 0.0, lp.virt_t0 ? lp.bt.V[(size_t)8 * ldt + j] : 0.0)
+                                   : lp.bt.T[tab_idx(i, j, ldt, 1)];
+            acc1 += 1.0 * t;
+        }
+        lp.scratch[(size_t)chunk * ldt + j] = acc1;
+        return;
+    }
     const int i0 = chunk * rpc, i1 = min(m, i0 + rpc);
     const double *T = lp.bt.T;
     const bool virt = lp.virt > 0;   // no tableau in HBM yet: the entries are computed (the set-up pivot's term: U / V row 8)
@@ -582,8 +594,8 @@ int batch_ldt(int nn) { return b_ldt(nn); }
 
 void launch_b_setup(BatchLP *lps, int nlp, hipStream_t s) { hipLaunchKernelGGL(k_b_setup, dim3(nlp), dim3(kBlock), 0, s, lps); }
 void launch_b_gather(const BatchLP *lps, int nlp, int m_max, int ldt_max, int mode, hipStream_t s) {
-    dim3 grid(((m_max + 3) / 4 * 4 + 31) / 32, ((ldt_max + 31) / 32 + kGatherTiles - 1) / kGatherTiles, nlp), block(32, 8);
-    hipLaunchKernelGGL(k_b_gather, grid, block, 0, s, lps, mode);
+    dim3 grid(((m_max + 3) / 4 * 4 + 31) / 32, ((ldt_max + 31) / 32 + kGatherTiles - 1) / kGatherTiles, mode == 3 ? std::min(nlp, 256) : nlp), block(32, 8);
+    hipLaunchKernelGGL(k_b_gather, grid, block, 0, s, lps, nlp, mode);
 }
 // ids_in / count_in: the active list the previous control step left (everybody at the start); bound >= *count_in on the host
 void launch_b_ctrl(BatchLP *lps, const int *ids_in, const int *count_in, int bound, int n_max, BatchOut *outs, int *ids_out, int *count_out, int loop_par, hipStream_t s) {

@@ -873,6 +873,37 @@ __device__ __forceinline__ void bt_inner2_body(const BTArgs &a, const int nupd =
     __syncthreads();
     for (int i = tid; i < a.m; i += NT) a.basic[i] = basic_s[i];
     for (int j = tid; j < a.nn; j += NT) a.nonbasic[j] = nonbasic_s[j];
+    if constexpr (VIRT) {
+        // A block that spent all its pivots looks at the next stop test too: a relaxation whose Phase I is over after exactly kmax pivots would
+        // otherwise stay "running" until the next launch finds min r >= -tol first thing — and have its tableau written out for that one look
+        // (29 % of an 8192-wide wave with 13 branch rows against the 13 % that really go on).  Only the plain stop test: anything a guard might
+        // want to re-decide is left to the next launch, which starts with the same selection.
+        if (status == ST_RUNNING && kd == a.kmax && kd > 0 && a.guard == 0) {
+            double rv[CJ];
+#pragma unroll
+            for (int s = 0; s < CJ; s++) rv[s] = r_s[tid + s * NT];
+            double rq1;
+            const double *vq1;
+            const BtWin f1 = reduce_cols(rv, rq1, vq1);
+            if (f1.i < (unsigned int)a.nn && rq1 >= -a.tol) status = ST_OPTIMAL;
+            __syncthreads();
+        }
+        // will anybody read this relaxation's tableau?  Not when its Phase I ended in this block with the artificial above the zero tolerance (infeasible,
+        // or the host path) or with a wrapped error — the tests k_b_ctrl takes next: then it is never written (k_b_gather mode 3)
+        int deadflag = 0;
+        if (a.phase == 1 && status != ST_RUNNING) {
+            if (status == ST_UNBOUNDED || status == ST_BLAND_FAILED) deadflag = 1;
+            else if (status == ST_OPTIMAL) {
+#pragma unroll
+                for (int s = 0; s < RI; s++) {
+                    const int i = tid + s * NT;
+                    if (i < a.m && basic_s[i] == vl->n && fabs(xb_s[i]) > 1e-13) deadflag = 1;
+                }
+            }
+        }
+        deadflag = __syncthreads_or(deadflag);
+        if (tid == 0) st->dead1 = deadflag;
+    }
     if (tid == 0) {
         st->trace_len = trace_len;
         st->pivots = npiv;

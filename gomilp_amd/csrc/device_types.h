@@ -65,7 +65,8 @@ struct DevState {
     // persistent loop kernel (BTArgs::loop): pivots of the block of each parity (the update of block t runs beside block
     // t+1), which of BTArgs::Tbuf holds the current tableau between launches, blocks run by the last launch
     int32_t kdone2[2];
-    int32_t tsel2[2], loop_blocks, pad3;   // launch i reads tsel2[i & 1] and writes tsel2[(i & 1) ^ 1]: a workgroup that starts late still sees its input
+    int32_t tsel2[2], loop_blocks, dead1;  // launch i reads tsel2[i & 1] and writes tsel2[(i & 1) ^ 1]: a workgroup that starts late still sees its input
+                                           // dead1 (virtual tableau): Phase I ended inside the first block and nobody will read this relaxation's tableau (it is never written)
 };
 
 struct DevPivot {  // mirrors gomilp_pivot
@@ -216,7 +217,7 @@ struct BatchLP {
     const double *wT, *wxb;
     const int32_t *wbasic, *wnonbasic, *wposvar;
     int32_t warm, wm;        // warm = 1: start from that state (m = wm + 1)
-    int32_t dual_budget, pad1;   // dual pivots before the relaxation is handed back (BS_COLD)
+    int32_t dual_budget, art_pos;   // dual pivots before the relaxation is handed back (BS_COLD); basis position the Phase-I artificial enters at (k_b_setup)
     int64_t pivd;            // dual pivots performed
     // Virtual tableau (wide waves of slack-start relaxations, engine_batch.cpp): virt = 2 while the host-chosen Phase-I pivot runs, 1 while the
     // first block of 8 pivots runs, 0 from then on (k_b_ctrl counts it down).  While virt > 0 NO tableau exists in HBM: the block kernel
