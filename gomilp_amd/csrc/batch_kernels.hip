@@ -255,6 +255,64 @@ __global__ void k_b_gather(const BatchLP *__restrict__ lps, int nlp, int mode) {
     }
 }
 
+// ---- the tableaus that survive a virtual first block, written once (the job of k_b_gather mode 3, one 4x4 tile per thread) -------------
+// k_b_gather moves 32 x 32 blocks through LDS, four entries per thread and two barriers per block: built for the plain T0 of mode 0 / 1, it wrote the
+// term-laden tableaus of mode 3 at 0.8 TB/s — 18 dependent term loads per entry.  Here a thread owns a whole tile (one 128-byte line of the
+// 4x4-tiled layout): the nine v' entries of its four columns stay in registers for the four rows, the nine u entries of a row are the same
+// address for every thread of a tile row (broadcast loads), and the finished tile leaves as four 32-byte stores — no LDS, no barrier.
+// Arithmetic per entry exactly as mode 3 / the update kernel: T0, (+ u0 v0' rounded twice, + 0), then k = 0 .. 7 ascending, a rounded multiply
+// and a rounded add each.  grid.x: 256-tile pieces of a tableau, grid.y: slices of the wave (a slice walks z, z + gridDim.y, ...)
+__global__ __launch_bounds__(256) void k_b_write_virt(const BatchLP *__restrict__ lps, int nlp) {
+    for (int zi = blockIdx.y; zi < nlp; zi += gridDim.y) {
+        const BatchLP &lp = lps[zi];
+        if (lp.stage == BS_HOST || lp.stage == BS_DONE || lp.stage == BS_COLD || lp.virt != 1 || lp.st->dead1) continue;
+        const int m = lp.m, nn = lp.bt.nn, ldt = lp.bt.ldt, ldu = lp.bt.ldu;
+        const int ntr = (m + 3) >> 2, ntc = ldt >> 2;
+        const int tile = blockIdx.x * 256 + threadIdx.x;
+        if (tile >= ntr * ntc) continue;
+        const int I = tile / ntc, J = tile % ntc;
+        const int kd = lp.st->kdone;
+        const bool t0 = lp.virt_t0 != 0;
+        const double *U = lp.bt.U, *V = lp.bt.V;
+        double vk[9][4];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const bool on = k < 8 ? k < kd : t0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) vk[k][c] = on ? V[(size_t)k * ldt + 4 * J + c] : 0.0;
+        }
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2 *dst = reinterpret_cast<d2 *>(lp.T[0] + ((size_t)I * ntc + J) * 16);
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int pos = 4 * I + rr;
+            double uk[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) uk[k] = ((k < 8 ? k < kd : t0) && pos < m) ? U[(size_t)k * ldu + pos] : 0.0;
+            double e[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                double v = b_entry<true>(lp, pos, 4 * J + c, nn);
+                if (t0) {
+                    v = __dadd_rn(v, __dmul_rn(uk[8], vk[8][c]));
+                    v = __dadd_rn(v, 0.0);
+                }
+                if (kd > 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) v = __dadd_rn(v, __dmul_rn(uk[k], vk[k][c]));
+                }
+                e[c] = v;
+            }
+            dst[2 * rr] = d2{e[0], e[1]};
+            dst[2 * rr + 1] = d2{e[2], e[3]};
+        }
+    }
+}
+void launch_b_write_virt(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s) {
+    const int tiles = ((m_max + 3) / 4) * (ldt_max / 4);
+    hipLaunchKernelGGL(k_b_write_virt, dim3((tiles + 255) / 256, std::min(nlp, 256)), dim3(256), 0, s, lps, nlp);
+}
+
 // ---- the stage machine ----------------------------------------------------------------------------------------------
 // dynamic LDS: 2 * (n_max + 2) ints (flags, old positions)
 // loop_par >= 0: the blocks of this superstep ran in the persistent loop kernel (launch parity loop_par): it left the buffer that holds
