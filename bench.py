@@ -62,6 +62,7 @@ def parse_args():
     ap.add_argument("--debug-one-gpu", action="store_true", help="rehearsal of the N > 1 control flow on a one-GPU box: every rank uses GPU 0, "
                     "torch.distributed over gloo, incumbent table over gloo + gomilp_incumbent_pick (RCCL refuses two ranks on one device)")
     ap.add_argument("--general", type=int, default=1, help="extra figure: an equality-constrained LP (no slack basis: the findLinearlyIndependent path) (0 = skip)")
+    ap.add_argument("--pool-knob", action="append", default=[], help="key=value set on the frontier pools (A/B runs of a schedule knob, e.g. batch_virt=0); recorded in the line")
     ap.add_argument("--c4", type=int, default=1, help="extra figure: one timed solve of the 4096x8192 LP (BASELINE config 4) (0 = skip)")
     return ap.parse_args()
 
@@ -248,6 +249,8 @@ def main() -> int:
         ctx5.close()
         children = synth.frontier_children(root5.x, mask5, nvars)
         pool = lp.FrontierPool(device=local_rank, workers=args.workers)   # kernel sampling (HIP events per launch) only in the extra waves below
+        for kv in args.pool_knob:
+            pool.set(kv.split("=")[0], int(kv.split("=")[1]))
         pool.set_root(c5, A5, b5)                            # root resident on every GPU before the timed region
         # the incumbent exchange goes through the C-ABI (RCCL), also at N = 1 (a 1-rank communicator)
         comm = None
@@ -338,7 +341,7 @@ def main() -> int:
             "workload": "C5: %d children of the %dx%d root (seed %d), %d bnb rows each, dealt round-robin over a fixed shuffle to %d rank(s)"
                         % (len(children), m5, 2 * m5, seed5, nvars, world),
             "relaxations_per_s": steps * len(children) / dt, "wave_seconds": dt / steps, "waves_timed": steps, "n_gpus": world,
-            "host_pack_seconds": host_pack_s, "wave_seconds_unpacked_rank0": unpacked_s,
+            "pool_knobs": list(args.pool_knob), "host_pack_seconds": host_pack_s, "wave_seconds_unpacked_rank0": unpacked_s,
             "per_rank": per_rank,   # exchange_ms = the ONE all-reduce(min) of the wave + the wait for the slowest rank's solve
             "wave_seconds_rank0": per_wave, "wave_seconds_median_rank0": float(np.median(per_wave)) if len(per_wave) else None, "pivots_per_wave": int(tot[0] / steps), "phase1_runs_per_wave": int(tot[1] / steps),
             "bland_steps_per_wave": int(tot[2] / steps), "host_fallbacks_per_wave": tot[3] / steps, "device_batched_per_wave": tot[4] / steps,
@@ -346,9 +349,10 @@ def main() -> int:
             "collective": "gomilp_incumbent_allreduce: 1 x ncclAllReduce(min) of %d doubles per wave over %d rank(s) (RCCL, C-ABI)" % (2 * world, world),
             "schedule": "device-batched, two schedules side by side (relaxations that start feasible: the long chains, on the higher-priority stream | relaxations that need "
                         "Phase I): one launch per kernel type per block step for a whole schedule while it is wide (grid.x = relaxation), ONE persistent launch per superstep "
-                        "(k_b_loop: per relaxation a pivot workgroup + 7 update workgroups, update of block t beside block t + 1) once <= 24 relaxations are active; "
+                        "(k_b_loop: per relaxation a pivot workgroup + 7 update workgroups, update of block t beside block t + 1) once <= 24 relaxations are active (12 per schedule while two run); "
+                        "a wide schedule of slack-start relaxations runs its set-up pivot and first block on VIRTUAL tableaus (entries computed from the root's A + branch rows + the set-up term) and writes out only what is alive behind that block; "
                         "%d block steps (of 8 pivots) and %.1f host looks per wave on rank 0" % (acc["blocks"] // max(steps, 1), holder["stats"]["supersteps"]),
-            "kernels_rank0": {"inner": "k_b_loop<512,2,4,7> (narrow) / k_bt_inner2_batch<512,2,2,8,0> (wide)", "inner_us_per_launch": inner_us, "update_us_per_launch": upd_us,
+            "kernels_rank0": {"inner": "k_b_loop<512,2,4,7> (narrow) / k_bt_inner2_virt_batch<512,2,2,8,0> (set-up pivot + first block of a wide schedule, on computed tableau entries) / k_bt_inner2_batch<512,2,2,8,0> (wide)", "inner_us_per_launch": inner_us, "update_us_per_launch": upd_us,
                               "time_share_inner": acc["inner"] / max(acc["inner"] + acc["update"], 1e-30),
                               "algorithmic_bytes_per_pivot": alg_bytes,
                               "note": "HIP events of the sampled waves: a k_b_loop launch (up to 32 blocks of 8 pivots for every active relaxation, updates inside) counts as ONE inner launch"},
@@ -358,11 +362,32 @@ def main() -> int:
                                     "<= %d / %.2f ms; more GPUs only remove what the other children add to that" % (len(children), 1e3 * solo["seconds_alone"]),
                                     "max_relaxations_per_s": len(children) / solo["seconds_alone"]}
         roof = {"bound": "hbm", "bound_kind": "latency", "limited_by": "latency: one workgroup per relaxation, two workgroup-wide argmins and two dependent tableau reads per pivot",
-                "kernel": "k_b_loop<512,2,4,7> + k_bt_inner2_batch<512,2,2,8,0>", "achieved": acc["pivots"] * alg_bytes / max(acc["inner"], 1e-30) / 1e9 if acc["inner"] > 0 else 0.0,
+                "kernel": "k_b_loop<512,2,4,7> + k_bt_inner2_virt_batch<512,2,2,8,0> / k_bt_inner2_batch<512,2,2,8,0>", "achieved": acc["pivots"] * alg_bytes / max(acc["inner"], 1e-30) / 1e9 if acc["inner"] > 0 else 0.0,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "note": "one workgroup per relaxation, two workgroup-wide argmins and two dependent tableau reads per pivot: bound by "
                         "latency, not bandwidth; achieved = rank 0's pivots x algorithmic bytes per pivot / HIP-event time of its batched inner launches"}
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        # the same launches with the UPDATE role's bytes: inside k_b_loop seven update workgroups read and write the relaxation's tableau once per
+        # block of 4 pivots (the model the metric-size `roofline` includes); and what the counters saw (C5-only --pmc passes: tools/prof_cmds.sh step 4)
+        m4_c = (m_c + 3) & ~3
+        ldt_c = ((nn_c + 63) // 64) * 64
+        upd_bytes = 16.0 * m4_c * ldt_c / 4.0
+        roof["algorithmic_bytes_per_pivot"] = {"pivot_role": alg_bytes, "with_update_role": alg_bytes + upd_bytes,
+                                               "note": "pivot role: a column and a row of T read, u and v' written; update role: T (%d x %d) read + written once per block of 4 pivots" % (m4_c, ldt_c)}
+        roof["achieved_with_update_role"] = acc["pivots"] * (alg_bytes + upd_bytes) / max(acc["inner"], 1e-30) / 1e9 if acc["inner"] > 0 else 0.0
+        roof["frac_with_update_role"] = roof["achieved_with_update_role"] / HBM_PEAK_GBS
+        try:
+            import glob
+            src = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_C5.json")))[-1]
+            doc = json.load(open(src))
+            loop_k = [k for k in doc["kernels"] if "k_b_loop" in k["kernel"]]
+            if loop_k and nvars == 8:
+                roof["traffic"] = loop_k[0]["traffic_bytes_per_wave"]
+                roof["traffic_unit"] = "bytes per 256-wide wave, all k_b_loop launches of the wave (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes of the C5 wave alone)"
+                roof["traffic_source"] = os.path.relpath(src, ROOT)
+                roof["algorithmic_bytes_per_wave_with_update_role"] = (acc["pivots"] / max(steps, 1)) * (alg_bytes + upd_bytes)
+        except Exception:
+            pass
         cpu = None
         if not args.no_cpu_baseline and world == 1 and args.frontier_cpu_children > 0 and not light:
             from concurrent.futures import ThreadPoolExecutor

@@ -71,7 +71,7 @@ class BatchEngine {
     void set_low_priority(bool low) { low_priority_ = low; }
     void set_xcd_offset(int x) { xcd_off_ = x & 7; }   // XCD of list position 0 of the 8-workgroup block kernel (several schedules side by side)
     void set_fault(int v) { fault_ = v; }   // diagnostic flavour: the first update workgroup of every relaxation of a loop launch leaves at once
-    void set_res(bool on) { res_ = on; }     // block steps of narrow waves in the register-resident kernel (res_kernels.hip k_b_res; opt-in: correct, but 4.4 us per exchange round against the loop kernel's 3.6 us per pivot — DESIGN.md section 2.7)
+    void set_res(bool on) { res_ = on; }     // block steps of narrow waves in the register-resident kernel (res_kernels.hip k_b_res; opt-in: correct, but 4.4 us per exchange round against the loop kernel's 3.6 us per pivot — DESIGN.md section 2.5d)
     // several schedules of one pool side by side (a split wave): each sizes its persistent launches for 1 / share of the device's loop slots —
     // every workgroup of such a launch must be resident, and two schedules that each plan for the whole device wait for each other's CUs
     void set_loop_share(int share) { loop_share_ = share < 1 ? 1 : share; }

@@ -188,7 +188,10 @@ void gomilp_pool_destroy(gomilp_pool *pool);
 /* knobs: "split_phase" (default 1: in a wave of >= 16 the relaxations that start feasible — the long Phase-II chains — and those that need
  * Phase I run as two schedules side by side, the long chains on the higher-priority stream), "batch_loop" (default 1: whenever the active
  * relaxations of a schedule fit one launch their block steps run in the persistent kernel k_b_loop — per relaxation one pivot workgroup and
- * seven update workgroups, the rank-4 update of block t beside block t + 1), "split_large" (default 1: a wave of >= 4 relaxations beyond 1024 rows runs as two interleaved schedules), "sample_batch" (1: time every batched block launch with HIP events), "batched" (default 1: the pivot loops of a wave run device-batched — grid.x = relaxation, O(1) host round trips per
+ * seven update workgroups, the rank-4 update of block t beside block t + 1), "batch_virt" (default 1: a WIDE wave of slack-start
+ * relaxations runs its set-up pivot and its first block of 8 pivots on computed tableau entries and writes out only the tableaus that are
+ * still alive behind that block — bit-identical), "batch_res" (default 0, opt-in: narrow waves in the
+ * register-resident kernel k_b_res instead of k_b_loop — bit-identical, slower: DESIGN.md section 2.5d), "split_large" (default 1: a wave of >= 4 relaxations beyond 1024 rows runs as two interleaved schedules), "sample_batch" (1: time every batched block launch with HIP events), "batched" (default 1: the pivot loops of a wave run device-batched — grid.x = relaxation, O(1) host round trips per
  * superstep for the whole wave; 0: one host thread + stream per relaxation); any gomilp_ctx_set key is forwarded to the
  * worker contexts. */
 int gomilp_pool_set(gomilp_pool *pool, const char *key, int64_t value);
