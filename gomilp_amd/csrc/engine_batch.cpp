@@ -515,7 +515,7 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
         // what a block step costs there); a narrow wave is a few single-workgroup chains: longer supersteps, fewer round trips
         int nb = nlp <= 16 ? (step < 2 ? 4 : 8) : (step < 2 ? 1 : (step < 4 ? 2 : (step < 8 ? 4 : 8)));
         // a loop launch has no boundary between its blocks: longer supersteps (fewer control steps on the chain) once the wave is narrow
-        if (loop_slots > 0 && bound <= loop_slots && step >= 2 && nwarm == 0) nb = bound <= 8 ? (step >= 3 ? 32 : 16) : 8;
+        if (loop_slots > 0 && bound <= loop_slots && step >= 2 && nwarm == 0) nb = bound <= 8 ? (step >= 3 ? 32 : 16) : 8;   // (long supersteps from the FIRST loop launch were tried on the tree waves: 2.77 against 2.58 ms — a twin that leaves Phase I after five pivots then waits for its control step behind 128 pivots of the other)
         if (res_slots > 0 && bound <= res_slots && nwarm == 0) nb = step >= 3 ? 32 : (step >= 1 ? 16 : 8);   // one launch whatever the length: longer supersteps from the start
         if (virt_on && step == 0) nb = 1;   // (the first block of a wave with virtual tableaus: one block step)
         step++;
