@@ -708,6 +708,9 @@ __global__ __launch_bounds__(NT) void k_bt_innerG_batch(const BatchLP *__restric
 // resp. six 16-byte loads per lane and poll).  Same pivots, but 35.1 instead of 32.3 us per 8 pivots at 2048 rows and 114 instead
 // of 52.6 at 4096: what the workgroup stage costs (stamps: ~1000 cycles in wave 0) the wider poll costs again (1600 instead of
 // 760 cycles from post to "all seen").
+// Tried and dropped (round 5, loop mode): 16 pivot workgroups of ONE wave, two rows / columns per thread (k_bt_loop<16,64,2,8>: no workgroup
+// stage and no real barrier in front of a post).  Same pivots, 4.45-4.68 instead of 3.87 us per pivot at 2048 rows (grid 256 / 136): the
+// wave's doubled row / column work costs more than the stage saved.
 // Tried and dropped (round 2): every participant ONE wave on its own CU (no barrier, no LDS hop; terms in LDS by position,
 // prefetched under the load latency).  Bit-identical results, but slower at 2048 rows: 8 waves x 4 rows 107.7 us per 16
 // pivots, 16 waves x 2 rows 97.0 us, against 80.2 us for 4 workgroups of 8 waves: one wave issues its ~1500 instructions

@@ -684,6 +684,8 @@ int64_t gomilp_debug_find_independent_device(gomilp_ctx *ctx, int64_t problem, i
     return (int64_t)idx.size();
 }
 
+// launches of the loop kernel's pivot role with replicated reduced costs so far (tests: the kernel under test really ran)
+long long gomilp_debug_loop_rep_launches(void) { return gomilp::bt_loop_rep_launches(); }
 #ifdef GOMILP_DEBUG
 // diagnostic flavour only: cycle sums of the final-solve panel kernel (lu_compressed.hip), 4 waves x 16 segments
 void gomilp_debug_luc_stamps(unsigned long long *out) { gomilp::luc_stamps_read(out); }

@@ -106,6 +106,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "cond_guard") cond_guard_ = v ? 1 : 0;
     else if (key == "poll_delay") { if (v < 0 || v > 64) return GOMILP_ERR_BAD_SHAPE; poll_delay_ = v; }
     else if (key == "loop_upd") { if (v < 0) return GOMILP_ERR_BAD_SHAPE; loop_upd_ = v; }
+    else if (key == "loop_rep") loop_rep_ = v ? 1 : 0;
     else if (key == "loop_g") { if (v != 0 && v != 8 && v != 16) return GOMILP_ERR_BAD_SHAPE; loop_g_ = v; }
     else if (key == "loop_k") { if (v != 0 && v != 8 && v != 12 && v != 16) return GOMILP_ERR_BAD_SHAPE; loop_k_ = v; }
     else if (key == "block_k") { if (v < 0 || v > bt_max_k()) return GOMILP_ERR_BAD_SHAPE; block_k_ = v; }

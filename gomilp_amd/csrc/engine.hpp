@@ -182,6 +182,7 @@ class Engine {
             loop_grid_ = 0,    // its workgroups (0: one per CU)
             poll_delay_ = 0,   // loop kernel: 64-cycle units between a wave's post and its first poll of an exchange
             loop_upd_ = 0,     // update workgroups of the loop kernel that take part (0: all of the grid's)
+            loop_rep_ = 0,     // 1: pivot role with replicated reduced costs (btr_kernels.hip k_bt_loopR: ONE exchange per pivot; bit-identical pivots, measured slower — DESIGN 2.1d) where the shape fits and the engine gets the whole device
             loop_g_ = 0,       // its pivot workgroups (0 / 16: 16 x 128 threads up to 2048 rows, 16 x 256 beyond; 8: 8 x 256 / 8 x 512)
             loop_k_ = 0,       // its pivots per block (0: 8 up to 2048 rows, 16 beyond; 8 / 16 forced where instantiated)
             exact_degenerate_ = 1,   // 0 never, 1 bases of up to 256 rows and every non-slack start, 2 always: pivots whose winning ratio is (nearly) zero are decided on a fresh gonum-order x_B; 3 strict: EVERY pivot and the stop test are decided on fresh gonum-order solves
@@ -272,6 +273,11 @@ void launch_bt_inner(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e
 void launch_bt_update(const BTArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 bool bt_loop_supported(const BtGroupCfg &c);
 void launch_bt_loop(const BTArgs &a, int ncu, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+// btr_kernels.hip
+bool bt_loop_rep_supported(int m, int ldt);
+int bt_loop_rep_threads(int m, int ldt);
+long long bt_loop_rep_launches();
+void launch_bt_loop_rep(const BTArgs &a, int ncu, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 bool bt_batch_supported(int m_max, int ldt_max);
 int bt_batch_k(int m_max, int ldt_max);
 void launch_bt_inner_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int xcd_off = 0);

@@ -449,7 +449,16 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
     // (weight: the 128-thread shape shares the device with up to three others, every other shape runs alone — engine.cpp)
     // (the 2048-row class in blocks of 16 — knob loop_k — shares the device too: 256-thread workgroups, two per CU, grid of half the CUs)
     const bool small_loop = lag && (K == 8 || K == 16) && loop_g_ != 8 && !bt_stamps_ && bt_group_cfg(P.m, ldt_, groups_knob(P)).nt == 256;
-    LoopSlot loop_slot(device_, small_loop ? 1 : 4, lag);
+    // The pivot role with replicated reduced costs (btr_kernels.hip): 512-thread workgroups that fill a CU each, so the launch must own
+    // the device — taken only if nobody else holds a loop slot right now (no waiting: busy means the shared 16 x 128 shape as before)
+    const BtGroupCfg gc0 = bt_group_cfg(P.m, ldt_, groups_knob(P));
+    const bool rep_ok = lag && K == 8 && loop_rep_ && loop_g_ != 8 && gc0.groups == 8 && gc0.nt == 256 && gc0.ri == 1 && bt_loop_rep_supported(P.m, ldt_);
+    struct RepHold {
+        int dev; bool held;
+        RepHold(int d, bool want) : dev(d), held(want && Engine::loop_try_acquire_all(d)) {}
+        ~RepHold() { if (held) Engine::loop_release(dev, 4, 0); }
+    } rep_hold(device_, rep_ok);
+    LoopSlot loop_slot(device_, small_loop ? 1 : 4, lag && !rep_hold.held);
     const int loop_xcd = (small_loop && loop_slot.slot > 0) ? 2 * loop_slot.slot : 0;
     bt_layout(P, tiled_plan);
     // persistent loop kernel: DevState::tsel2 hands the buffer that holds the tableau from launch to launch
@@ -505,7 +514,9 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
             if (k16_small) ai.groups = 16;   // (16 x 256 threads, blocks of 16: the instance of the 4096-row class)
             // 1025..2048 rows: 16 x 128 threads (two waves per workgroup: a cheaper workgroup stage in front of every exchange; measured
             // 11.47 ms against 11.85 ms per solve of the metric LP for 8 x 256)
-            if (ai.groups == 8 && ai.group_nt == 256 && ai.group_ri == 1 && loop_g_ != 8 && K == 8 && !bt_stamps_) {
+            const bool rep = rep_hold.held && ai.groups == 8 && ai.group_nt == 256 && ai.group_ri == 1;
+            if (rep) { ai.groups = 16; ai.group_nt = bt_loop_rep_threads(P.m, ldt_); }
+            else if (ai.groups == 8 && ai.group_nt == 256 && ai.group_ri == 1 && loop_g_ != 8 && K == 8 && !bt_stamps_) {
                 ai.groups = 16; ai.group_nt = 128;   // (8 x 128 threads measured the same at 1024 rows: 4.74 against 4.75 ms per loop of C2)
             }
             ai.Tbuf[0] = w.T[0]; ai.Tbuf[1] = w.T[1];
@@ -528,7 +539,8 @@ int Engine::run_loop_bt(const Problem &P, int phase, double tol, int nn, gomilp_
             // grid beyond one 512-thread workgroup per CU is not resident as a whole: the launch gives up after its bounded waits)
             int grid = (int)std::min<int64_t>(ncu_, std::max<int64_t>(64, (int64_t)P.m * ldt_ * 8 / (256 << 10)));
             if (loop_grid_ > 0) grid = (int)loop_grid_;
-            launch_bt_loop(ai, grid, stream_, e0, e1);
+            if (rep) launch_bt_loop_rep(ai, grid, stream_, e0, e1);
+            else launch_bt_loop(ai, grid, stream_, e0, e1);
             launch_no++; block_no += nblocks; launches_++;
             HIP_TRY(hipMemcpyAsync(w.pipe_state[slot], w.st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
             HIP_TRY(hipEventRecord(w.pipe_ev[slot], stream_));
