@@ -262,37 +262,61 @@ __global__ void k_b_gather(const BatchLP *__restrict__ lps, int nlp, int mode) {
 // address for every thread of a tile row (broadcast loads), and the finished tile leaves as four 32-byte stores — no LDS, no barrier.
 // Arithmetic per entry exactly as mode 3 / the update kernel: T0, (+ u0 v0' rounded twice, + 0), then k = 0 .. 7 ascending, a rounded multiply
 // and a rounded add each.  grid.x: 256-tile pieces of a tableau, grid.y: slices of the wave (a slice walks z, z + gridDim.y, ...)
-__global__ __launch_bounds__(256) void k_b_write_virt(const BatchLP *__restrict__ lps, int nlp) {
-    for (int zi = blockIdx.y; zi < nlp; zi += gridDim.y) {
-        const BatchLP &lp = lps[zi];
+// (The first form walked the whole wave in every workgroup — grid.y slices over all nlp relaxations, 87 % of them dead: 2.96 ms of an
+// 8192-wide wave, 0.39 of a 2048-wide one, most of it workgroups that only looked.  Now k_b_virt_alive lists the survivors first and the
+// workgroups of k_b_write_virt stride over (survivor, 256-tile piece) items.)
+__global__ __launch_bounds__(1024) void k_b_virt_alive(const BatchLP *__restrict__ lps, const int *__restrict__ ids, const int *__restrict__ count, int *__restrict__ list, int *__restrict__ nalive) {
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int n = *count;
+    for (int k = threadIdx.x; k < n; k += 1024) {
+        const int li = ids[k];
+        const BatchLP &lp = lps[li];
         if (lp.stage == BS_HOST || lp.stage == BS_DONE || lp.stage == BS_COLD || lp.virt != 1 || lp.st->dead1) continue;
+        list[atomicAdd(&s_n, 1)] = li;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *nalive = s_n;
+}
+// Eight threads per 4x4 tile, 16 bytes each: a wave's store is eight whole 128-byte lines (one tile per thread — eight 16-byte stores into a
+// line of its own — ran at 1.0 TB/s).  An item is a strip of 32 tile columns of one survivor, walked from the first tile row to the last:
+// the nine v' pairs of a thread's two columns stay in registers, a tile row costs it nine u loads (shared by the lanes of that row), two
+// entries of T0 and one store — the index arithmetic and the v' loads per ENTRY were what the flat form (a thread = two entries of
+// any tile) spent its time on: 2.1 ms for the 2.6 GB of an 8192-wide wave's survivors.
+__global__ __launch_bounds__(256) void k_b_write_virt(const BatchLP *__restrict__ lps, const int *__restrict__ list, const int *__restrict__ nalive, int strips) {
+    // few survivors: a strip is cut into row segments so that every workgroup of the grid has work
+    const int na = *nalive;
+    const int segs = na * strips >= (int)gridDim.x ? 1 : min(16, ((int)gridDim.x + na * strips - 1) / max(1, na * strips));
+    const int total = na * strips * segs;
+    const int sub = threadIdx.x & 7, rr = sub >> 1, ch = (sub & 1) * 2;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    for (int w0 = blockIdx.x; w0 < total; w0 += gridDim.x) {
+        const int w = w0 / segs, seg = w0 % segs;
+        const BatchLP &lp = lps[list[w / strips]];
         const int m = lp.m, nn = lp.bt.nn, ldt = lp.bt.ldt, ldu = lp.bt.ldu;
         const int ntr = (m + 3) >> 2, ntc = ldt >> 2;
-        const int tile = blockIdx.x * 256 + threadIdx.x;
-        if (tile >= ntr * ntc) continue;
-        const int I = tile / ntc, J = tile % ntc;
+        const int J = (w % strips) * 32 + (threadIdx.x >> 3);
+        if (J >= ntc) continue;
         const int kd = lp.st->kdone;
         const bool t0 = lp.virt_t0 != 0;
         const double *U = lp.bt.U, *V = lp.bt.V;
-        double vk[9][4];
+        const int jc = 4 * J + ch;
+        d2 vk[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const bool on = k < 8 ? k < kd : t0;
-#pragma unroll
-            for (int c = 0; c < 4; c++) vk[k][c] = on ? V[(size_t)k * ldt + 4 * J + c] : 0.0;
-        }
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        d2 *dst = reinterpret_cast<d2 *>(lp.T[0] + ((size_t)I * ntc + J) * 16);
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
+        for (int k = 0; k < 9; k++) vk[k] = (k < 8 ? k < kd : t0) ? *reinterpret_cast<const d2 *>(V + (size_t)k * ldt + jc) : d2{0.0, 0.0};
+        double *dst = lp.T[0] + (size_t)J * 16 + rr * 4 + ch;
+        const int Ia = (int)((long)ntr * seg / segs), Ib = (int)((long)ntr * (seg + 1) / segs);
+#pragma unroll 4
+        for (int I = Ia; I < Ib; I++) {
             const int pos = 4 * I + rr;
             double uk[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) uk[k] = ((k < 8 ? k < kd : t0) && pos < m) ? U[(size_t)k * ldu + pos] : 0.0;
-            double e[4];
+            double e[2];
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                double v = b_entry<true>(lp, pos, 4 * J + c, nn);
+            for (int c = 0; c < 2; c++) {
+                double v = b_entry<true>(lp, pos, jc + c, nn);
                 if (t0) {
                     v = __dadd_rn(v, __dmul_rn(uk[8], vk[8][c]));
                     v = __dadd_rn(v, 0.0);
@@ -303,14 +327,17 @@ __global__ __launch_bounds__(256) void k_b_write_virt(const BatchLP *__restrict_
                 }
                 e[c] = v;
             }
-            dst[2 * rr] = d2{e[0], e[1]};
-            dst[2 * rr + 1] = d2{e[2], e[3]};
+            *reinterpret_cast<d2 *>(dst + (size_t)I * ntc * 16) = d2{e[0], e[1]};
         }
     }
 }
-void launch_b_write_virt(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s) {
-    const int tiles = ((m_max + 3) / 4) * (ldt_max / 4);
-    hipLaunchKernelGGL(k_b_write_virt, dim3((tiles + 255) / 256, std::min(nlp, 256)), dim3(256), 0, s, lps, nlp);
+// ids / count: the active list the first block ran on; list / nalive: scratch (the list and the count the coming control step will write)
+void launch_b_write_virt(const BatchLP *lps, const int *ids, const int *count, int *list, int *nalive, int bound, int m_max, int ldt_max, int ncu, hipStream_t s) {
+    const int strips = (ldt_max / 4 + 31) / 32;
+    hipLaunchKernelGGL(k_b_virt_alive, dim3(1), dim3(1024), 0, s, lps, ids, count, list, nalive);
+    const long want = (long)bound * strips;
+    const int grid = (int)std::max<long>(1, std::min<long>(want, (long)std::max(ncu, 1) * 8));
+    hipLaunchKernelGGL(k_b_write_virt, dim3(grid), dim3(256), 0, s, lps, list, nalive, strips);
 }
 
 // ---- the stage machine ----------------------------------------------------------------------------------------------

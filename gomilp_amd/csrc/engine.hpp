@@ -303,7 +303,7 @@ void launch_b_posvar(const int32_t *basic, int m, const int32_t *nonbasic, int n
 bool bt_dual_batch_supported(int m_max, int ldt_max);
 void launch_bt_inner_dual_batch(const BatchLP *lps, const int *ids, const int *count, int nlp, int m_max, int ldt_max, hipStream_t s);
 void launch_b_gather(const BatchLP *lps, int nlp, int m_max, int ldt_max, int mode, hipStream_t s);   // mode: batch_kernels.hip k_b_gather
-void launch_b_write_virt(const BatchLP *lps, int nlp, int m_max, int ldt_max, hipStream_t s);          // the survivors of a virtual first block (= mode 3, one tile per thread)
+void launch_b_write_virt(const BatchLP *lps, const int *ids, const int *count, int *list, int *nalive, int bound, int m_max, int ldt_max, int ncu, hipStream_t s);          // the survivors of a virtual first block (= mode 3, one tile per thread)
 void launch_b_ctrl(BatchLP *lps, const int *ids_in, const int *count_in, int bound, int n_max, BatchOut *outs, int *ids_out, int *count_out, int loop_par, hipStream_t s);
 void launch_b_init_ids(int *ids, int *count, int nlp, hipStream_t s);
 void launch_b_permute(const BatchLP *lps, const int *ids, const int *count, int bound, int m_max, int ldt_max, hipStream_t s);

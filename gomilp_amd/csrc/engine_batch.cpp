@@ -376,9 +376,9 @@ int BatchEngine::run_roots(const Engine::RootView *const *roots, int nroots, con
             }
             launch_bt_inner_virt_batch(b.d_lps, ids, cnt, bound, stream_, e[0], e[1]);
             if (e[2]) hipEventRecord(e[2], stream_);
-            if (step == 1) launch_b_write_virt(b.d_lps, nlp, m_max, ldt1, stream_);   // (k_b_gather mode 3 is the same arithmetic through 32 x 32 LDS blocks: 0.8 TB/s)
+            if (step == 1) launch_b_write_virt(b.d_lps, ids, cnt, b.d_ids[step & 1], b.d_active + step, bound, m_max, ldt1, ncu, stream_);   // (scratch: the list / count this step's control kernel writes afterwards; k_b_gather mode 3 is the same arithmetic through 32 x 32 LDS blocks: 0.8 TB/s)
             if (e[3]) hipEventRecord(e[3], stream_);
-            S.launches += step == 1 ? 2 : 1; S.blocks += 1; S.virt_blocks += 1;
+            S.launches += step == 1 ? 3 : 1; S.blocks += 1; S.virt_blocks += 1;
             return;
         }
         if (allow_loop && res_slots > 0 && bound <= res_slots && nwarm == 0) {
