@@ -675,6 +675,13 @@ double gomilp_debug_cond_estimate(const double *B, int64_t n, int inf) {
 }
 
 // diagnostic: the same search with the scan on the device (general_kernels.hip), on a problem resident in `ctx`
+int gomilp_debug_gonum_lu_cond(const double *M, int64_t n, int transposed, double *cond) {
+    if (!M || !cond || n < 1 || n > gomilp::kGonumCondMax) return -1;
+    bool dz = false;
+    if (!gomilp::gonum_lu_cond(M, (int)n, (int)n, transposed != 0, cond, &dz)) return -1;
+    return dz ? 1 : 0;
+}
+
 int64_t gomilp_debug_find_independent_device(gomilp_ctx *ctx, int64_t problem, int64_t *idx_out, int64_t cap) {
     if (!ctx || !idx_out) return -GOMILP_ERR_BAD_SHAPE;
     std::vector<int32_t> idx;

@@ -432,7 +432,7 @@ LPArgs Engine::make_args(const Problem &P, int phase, double tol, int nn, const 
     a.pk_price = w.pk_price; a.pi_price = w.pi_price; a.pk_ratio = w.pk_ratio; a.pi_ratio = w.pi_ratio;
     a.pv_price = w.pv_price; a.pd_ratio = w.pd_ratio; a.pb_ratio = w.pb_ratio;
     a.st = w.st;
-    a.trace = trace_on_ ? w.trace : nullptr;
+    a.trace = (trace_on_ || shadow_trace_) ? w.trace : nullptr;
     a.trace_cap = w.trace_cap;
     return a;
 }
@@ -1283,7 +1283,9 @@ int Engine::solve_locked(int64_t id, double tol, const int64_t *initial_basic, d
         if (initial_basic && !feasible) return finish(GOMILP_ERR_PANIC);  // initializeFromBasic errors panic (:156-158)
     }
     // small bases starting feasible: record the pivots for the host replay of the reference's condition guards
-    shadow_trace_ = cond_guard_ && use_tab && feasible && m <= 64 && !initial_basic && ensure_host_A(P);
+    // (every pipeline: until round 5 the revised-simplex pipelines — shapes with n - m >= 2m, wide small LPs among them — went without the
+    // replay, which is what the one status difference of the badly scaled family, seed 1079, a 2 x 6 LP, came from)
+    shadow_trace_ = cond_guard_ && feasible && m <= 64 && !initial_basic && ensure_host_A(P);
     const std::vector<int32_t> basic_start = basic;
     cur_ = 0;
     if (unit_basis && !use_tab) {

@@ -217,6 +217,11 @@ int general_condition_replay(const std::vector<double> &A, int m, int n, std::ve
 double general_cond_inf(const std::vector<double> &A, int n);
 bool general_invert(const std::vector<double> &B, int m, std::vector<double> &inv);
 double inverse_norm1_estimate(const std::vector<double> &M, int n, bool transposed);
+// gonum_cond.cpp: what gonum's mat.LU reports for a row-major n x n matrix (transposed: for its transpose) — cond = 1 / Dgecon(MaxRowSum) of the
+// factors, and the Det() == 0 test of LU.Solve — bit for bit, for n <= kGonumCondMax (the range Dgetrf does not block); false beyond it
+constexpr int kGonumCondMax = 64;
+bool gonum_lu_cond(const double *M, int n, int ldm, bool transposed, double *cond, bool *det_zero);
+bool gonum_lu_solve(const double *M, int n, int ldm, const double *b, double *x);   // LU.SolveVec's result (the point returned with a mat.Condition error)
 double general_basis_cond1(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, const std::vector<double> &art);
 bool general_solve_basis(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, const std::vector<double> &b, std::vector<double> &x);
 

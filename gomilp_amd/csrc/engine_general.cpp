@@ -347,6 +347,16 @@ int general_condition_replay(const std::vector<double> &A, int m, int n, std::ve
     auto conds = [&](double &k1, double &kinf) {
         basis_matrix(A, m, n, basic, B);
         (*evaluations)++;
+        if (m <= kGonumCondMax) {
+            // the reference's own quantities: the cond mat.LU estimated when it factorized ab^T (duals) resp. ab (x_B, computeMove), and its
+            // Det() == 0 test (gonum_cond.cpp) — an ESTIMATE on rounded factors, which near 1e16 can fall on either side of the exact value
+            bool dz = false;
+            gonum_lu_cond(B.data(), m, m, true, &k1, &dz);
+            if (dz) k1 = std::numeric_limits<double>::infinity();
+            gonum_lu_cond(B.data(), m, m, false, &kinf, &dz);
+            if (dz) kinf = std::numeric_limits<double>::infinity();
+            return;
+        }
         if (!invert(B, m, inv)) { k1 = kinf = std::numeric_limits<double>::infinity(); return; }
         k1 = norm1(B, m, m, m) * norm1(inv, m, m, m);
         kinf = norm_inf(B, m) * norm_inf(inv, m);
@@ -412,6 +422,12 @@ double inverse_norm1_estimate(const std::vector<double> &M, int n, bool transpos
 
 // exact kappa_inf of a square matrix (m == n path: any Condition of the single solve becomes lp.ErrSingular, simplex.go:109-112)
 double general_cond_inf(const std::vector<double> &A, int n) {
+    if (n <= kGonumCondMax) {   // the reference's estimate itself (gonum_cond.cpp)
+        double c = 0;
+        bool dz = false;
+        gonum_lu_cond(A.data(), n, n, false, &c, &dz);
+        return dz ? std::numeric_limits<double>::infinity() : c;
+    }
     std::vector<double> inv;
     if (!invert(A, n, inv)) return std::numeric_limits<double>::infinity();
     return norm_inf(A, n) * norm_inf(inv, n);
@@ -421,6 +437,10 @@ double general_cond_inf(const std::vector<double> &A, int n) {
 bool general_solve_basis(const std::vector<double> &A, int m, int n, const std::vector<int32_t> &basic, const std::vector<double> &b, std::vector<double> &x) {
     std::vector<double> B, inv;
     basis_matrix(A, m, n, basic, B);
+    if (m <= kGonumCondMax) {   // LU.SolveVec's own result (gonum_cond.cpp): the point the reference returns with a mat.Condition error, bit for bit
+        x.assign(m, 0.0);
+        return gonum_lu_solve(B.data(), m, m, b.data(), x.data());
+    }
     if (!invert(B, m, inv)) return false;
     x.assign(m, 0.0);
     for (int i = 0; i < m; i++) { double s2 = 0; for (int j = 0; j < m; j++) s2 += inv[(size_t)i * m + j] * b[j]; x[i] = s2; }

@@ -60,7 +60,7 @@ class FrontierStats(C.Structure):
 
 EXPORTS = [
     "gomilp_frontier_solve_warm", "gomilp_pool_release_warm",
-    "gomilp_lp_upload_child", "gomilp_pool_create", "gomilp_pool_destroy", "gomilp_pool_set", "gomilp_pool_set_root", "gomilp_frontier_solve", "gomilp_pool_add_root", "gomilp_frontier_solve_roots", "gomilp_pool_solve_root", "gomilp_debug_find_independent", "gomilp_debug_find_independent_device", "gomilp_debug_cond_estimate",
+    "gomilp_lp_upload_child", "gomilp_pool_create", "gomilp_pool_destroy", "gomilp_pool_set", "gomilp_pool_set_root", "gomilp_frontier_solve", "gomilp_pool_add_root", "gomilp_frontier_solve_roots", "gomilp_pool_solve_root", "gomilp_debug_find_independent", "gomilp_debug_find_independent_device", "gomilp_debug_cond_estimate", "gomilp_debug_gonum_lu_cond",
     "gomilp_lp_simplex", "gomilp_ctx_create", "gomilp_ctx_destroy", "gomilp_ctx_device", "gomilp_ctx_set",
     "gomilp_lp_upload", "gomilp_lp_free", "gomilp_lp_solve_resident", "gomilp_lp_last_trace", "gomilp_version",
     "gomilp_device_count", "gomilp_compiled_arch", "gomilp_comm_unique_id", "gomilp_comm_create", "gomilp_comm_destroy",
@@ -114,6 +114,8 @@ def lib():
                                               C.POINTER(FrontierStats)]
     L.gomilp_debug_cond_estimate.restype = C.c_double
     L.gomilp_debug_cond_estimate.argtypes = [dp, C.c_int64, C.c_int]
+    L.gomilp_debug_gonum_lu_cond.restype = C.c_int
+    L.gomilp_debug_gonum_lu_cond.argtypes = [dp, C.c_int64, C.c_int, C.POINTER(C.c_double)]
     L.gomilp_debug_find_independent.restype = C.c_int64
     L.gomilp_debug_find_independent_device.restype = C.c_int64
     L.gomilp_debug_find_independent_device.argtypes = [C.c_void_p, C.c_int64, ip, C.c_int64]
@@ -500,6 +502,18 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def debug_gonum_lu_cond(M, transposed: bool = False):
+    """(cond, det_is_zero) as gonum's mat.LU holds them after Factorize(M) (transposed: of M.T) — host only, n <= 64 (gonum_cond.cpp)."""
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    n = M.shape[0]
+    assert M.shape == (n, n)
+    c = C.c_double(0.0)
+    rc = lib().gomilp_debug_gonum_lu_cond(_dp(M), n, 1 if transposed else 0, C.byref(c))
+    if rc < 0:
+        raise ValueError("n out of range")
+    return float(c.value), bool(rc)
 
 
 def debug_cond_estimate(B, inf: bool = False) -> float:

@@ -270,6 +270,11 @@ int64_t gomilp_debug_find_independent_device(gomilp_ctx *ctx, int64_t problem, i
  * lapack/gonum/dgecon.go:26-81, dlacn2.go:24-136) for a row-major n x n matrix: 1-norm (inf = 0) or infinity norm (inf = 1);
  * -1 when B is singular to working precision.  Tests compare it with the checker's Dgecon. */
 double gomilp_debug_cond_estimate(const double *B, int64_t n, int inf);
+/* Diagnostic (host only): what gonum's mat.LU holds after Factorize(M) (transposed = 1: Factorize(M.T())) for a row-major n x n matrix with
+ * n <= 64 — *cond = 1 / Dgecon(MaxRowSum) on the factors of Dgetf2 (mat/lu.go:29-50,70-84), bit for bit; returns 1 when LU.Solve's
+ * Det() == 0 test fires (mat/lu.go:301), 0 when not, -1 for n out of range.  The host replay of the reference's guards for bases of up
+ * to 64 rows uses exactly this (engine_general.cpp general_condition_replay); tests compare it with the checker's restatement. */
+int gomilp_debug_gonum_lu_cond(const double *M, int64_t n, int transposed, double *cond);
 
 /* Library / device probes (no compute): used by the loader checks and by __graft_entry__. */
 const char *gomilp_version(void);

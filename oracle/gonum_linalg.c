@@ -927,3 +927,15 @@ double g_cond1(int64_t r, int64_t c, const double *a, int64_t lda) {
     free(qr); free(tau);
     return 1 / v;
 }
+
+/* what mat.LU holds after Factorize(a) (trans: Factorize(a.T())) with mat.CondNorm: its cond, and whether LU.Solve's Det() == 0 test
+ * fires (mat/lu.go:70-84, 301) — one call for tests that compare a product-side computation of the same two things */
+double g_lu_cond_rowsum(int64_t n, const double *a, int64_t lda, int trans, int *det_zero) {
+    g_lu f; g_lu_init(&f);
+    if (trans) g_lu_factorize_trans(&f, n, a, lda, G_NORM_MAXROWSUM);
+    else g_lu_factorize(&f, n, a, lda, G_NORM_MAXROWSUM);
+    const double cond = f.cond;
+    if (det_zero) *det_zero = lu_det_is_zero(&f);
+    g_lu_free(&f);
+    return cond;
+}

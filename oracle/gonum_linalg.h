@@ -37,6 +37,7 @@ int g_solve_vec_trans(int64_t n, const double *a, int64_t lda, double *x);
 
 /* mat.Cond(a, 1) for r >= c (mat/matrix.go:284-322): LU path when square, QR path when tall */
 double g_cond1(int64_t r, int64_t c, const double *a, int64_t lda);
+double g_lu_cond_rowsum(int64_t n, const double *a, int64_t lda, int trans, int *det_zero);
 
 /* exposed for unit tests */
 int g_dgetrf(int64_t m, int64_t n, double *a, int64_t lda, int64_t *ipiv);

@@ -84,6 +84,8 @@ def lib():
         _lib.g_set_threads.argtypes = [C.c_int]
         _lib.g_cond1.restype = C.c_double
         _lib.g_cond1.argtypes = [C.c_int64, C.c_int64, dp, C.c_int64]
+        _lib.g_lu_cond_rowsum.restype = C.c_double
+        _lib.g_lu_cond_rowsum.argtypes = [C.c_int64, dp, C.c_int64, C.c_int, C.POINTER(C.c_int)]
         _lib.g_dgetrf.restype = C.c_int
         _lib.g_dgetrf.argtypes = [C.c_int64, C.c_int64, dp, C.c_int64, ip]
         _lib.g_dgetf2.restype = C.c_int
@@ -189,6 +191,16 @@ def cond1(A) -> float:
     A = np.ascontiguousarray(A, dtype=np.float64)
     r, c = A.shape
     return lib().g_cond1(r, c, _dp(A), c)
+
+
+def lu_cond(A, trans: bool = False):
+    """(cond, det_is_zero) of mat.LU after Factorize(A) (trans: Factorize(A.T())): what LU.Solve's two guards look at (mat/lu.go:301,321)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    n = A.shape[0]
+    assert A.shape == (n, n)
+    dz = C.c_int(0)
+    v = lib().g_lu_cond_rowsum(n, _dp(A), n, 1 if trans else 0, C.byref(dz))
+    return float(v), bool(dz.value)
 
 
 # --------------------------------------------------------------------------------------

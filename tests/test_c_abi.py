@@ -137,3 +137,43 @@ def test_condition_estimate_is_gonums():
         einf = lp.debug_cond_estimate(B, inf=True)
         assert einf > 0 and einf <= np.linalg.cond(B, np.inf) * (1 + 1e-6)
     print("largest relative distance to the oracle's Dgecon: %.2e" % worst)
+
+
+def test_small_basis_condition_verdict_is_gonums_bit_for_bit():
+    """Bases of up to 64 rows (the range gonum's Dgetrf does not block) get the reference's OWN verdict in the host replay of its
+    LU.Solve guards: cond = 1 / Dgecon(MaxRowSum) on the factors Dgetf2 left (mat/lu.go:29-50,70-84,321) and the Det() == 0 test
+    (:301) — an estimate on rounded factors, which for kappa near 1e16 falls on either side of the exact condition number (the one
+    status difference of the badly scaled family until round 5, seed 1079).  Product code (gomilp_amd/csrc/gonum_cond.cpp) against the
+    checker's restatement on 3000 matrices of 1..64 rows: random, column-scaled over 26 decades, nearly and exactly dependent, with
+    zero columns, underflowing determinants — the same double, the same Det() verdict, for the matrix and for its transpose.
+    Host-only entry of the library: no GPU needed."""
+    from gomilp_amd import lp
+    from oracle import oracle as O
+    beyond = det = 0
+    for seed in range(3000):
+        r = np.random.default_rng(9000 + seed)
+        n = int(r.integers(1, 65))
+        B = r.standard_normal((n, n))
+        kind = seed % 6
+        if kind == 1:
+            B *= 10.0 ** r.integers(-13, 14, n)
+        elif kind == 2 and n > 1:
+            B[:, -1] = B[:, 0] * (1 + 10.0 ** -int(r.integers(6, 17))) + 10.0 ** -int(r.integers(6, 19)) * B[:, -1]
+        elif kind == 3 and n > 1:
+            B[:, int(r.integers(0, n))] = B[:, 0] if r.random() < 0.5 else 0.0      # exactly singular
+            B[[0, n - 1]] = B[[n - 1, 0]]
+        elif kind == 4:
+            B = np.where(r.random((n, n)) < 0.7, 0.0, B) + np.eye(n) * 10.0 ** r.integers(-12, 3, n)
+        elif kind == 5:
+            B *= 10.0 ** -int(r.integers(5, 40))                                     # determinants that underflow
+        for tr in (False, True):
+            got, gdz = lp.debug_gonum_lu_cond(B, tr)
+            want, wdz = O.lu_cond(B, tr)
+            assert gdz == wdz, (seed, n, tr)
+            assert (got == want) or (got != got and want != want), (seed, n, tr, got, want)
+            beyond += int(want > 1e16)
+            det += int(wdz)
+    print("matrices x 2: 6000, cond > 1e16 in %d, Det() == 0 in %d" % (beyond, det))
+    assert beyond > 300 and det > 100
+    with pytest.raises(ValueError):
+        lp.debug_gonum_lu_cond(np.eye(65))
