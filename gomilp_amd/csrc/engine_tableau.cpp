@@ -936,6 +936,14 @@ int Engine::cond_fresh(const Problem &P, const int32_t *basic_host, double *k1, 
         HIP_TRY(hipMemcpyAsync(&cols[(size_t)p * P.ld], P.dAt + (size_t)basic[p] * P.ld, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(sync_stream());
     for (int i = 0; i < m; i++) for (int p = 0; p < m; p++) B[(size_t)i * m + p] = cols[(size_t)p * P.ld + i];
+    if (m <= kGonumCondMax) {   // the reference's own estimates, bit for bit (gonum_cond.cpp): cond of ab^T for the duals' solve, of ab for x_B / computeMove
+        bool dz = false;
+        gonum_lu_cond(B.data(), m, m, true, k1, &dz);
+        if (dz) *k1 = std::numeric_limits<double>::infinity();
+        gonum_lu_cond(B.data(), m, m, false, kinf, &dz);
+        if (dz) *kinf = std::numeric_limits<double>::infinity();
+        return GOMILP_OK;
+    }
     if (!general_invert(B, m, inv)) { *k1 = *kinf = std::numeric_limits<double>::infinity(); return GOMILP_OK; }
     double n1 = 0, ninf = 0, i1 = 0, iinf = 0;
     {
