@@ -115,7 +115,8 @@ int gomilp_ctx_device(const gomilp_ctx *ctx);
  * single-workgroup block kernel), "bt_groups" (-1: single-workgroup block kernels only, 0: by shape, 2 / 4 / 8: that many
  * workgroups), "bt_old", "bt_stamps", "sample_events"; of the persistent loop kernel: "bt_lag" (0: the launch pairs of round 2),
  * "loop_chunk" (pivots per launch), "loop_g" (8 / 16 pivot workgroups), "loop_k" (8 / 12 / 16 pivots per block), "loop_upd"
- * (update workgroups that take part), "loop_grid", "poll_delay"; of the bit-exact final solve: "lu_blocked" (3 default: compressed rounds
+ * (update workgroups that take part), "loop_grid", "poll_delay", "loop_rep" (default 0, opt-in: the pivot role with replicated reduced costs, ONE exchange
+ * per pivot — bit-identical pivots, measured slower: DESIGN.md section 2.1d); of the bit-exact final solve: "lu_blocked" (3 default: compressed rounds
  * in the look-ahead schedule — one launch per round, the panel beside the previous round's update — for bases beyond 768 rows while the
  * engine holds the device's loop slots, 2: compressed rounds with the whole update behind each panel, 1: blocked panels, 0: one launch per
  * column — all bit-identical), "lu_look" (0: never the look-ahead schedule; a pool sets it on its workers).  The
