@@ -260,6 +260,14 @@ struct GsState {
     double beta_last;  // diagonal entry of R produced by the square step (0: the candidate is dependent)
 };
 
+// Record of one block of the blocked column search (general_block.hip): written by the decide kernel, read by the apply kernel
+struct GsBlock {
+    int32_t nacc;      // reflectors the block accepted
+    int32_t k0;        // columns accepted before the block (reflector i sits at position k0 + i)
+    int32_t pad0, pad1;
+    double vv[16];     // v^T v per reflector (0: H = I)
+};
+
 // Control block of the compressed LU schedule (lu_compressed.hip): written by the panel kernel of a round, read by the
 // U-solve / trailing kernels of the same round and by the host between batches of rounds.
 struct LUCtl {

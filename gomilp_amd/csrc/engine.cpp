@@ -97,6 +97,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "bt_fault") bt_fault_ = v;   // fault injection, diagnostic flavour only: 1 a workgroup of the block / loop kernels, 2 the U-solve workgroup of the look-ahead LU
 #endif
     else if (key == "general_device") general_device_ = v ? 1 : 0;
+    else if (key == "general_block") general_block_ = v ? 1 : 0;
     else if (key == "bt_groups") { if (v != -1 && v != 0 && v != 2 && v != 4 && v != 8 && v != 16) return GOMILP_ERR_BAD_SHAPE; bt_groups_ = v; }
     else if (key == "bt_stamps") bt_stamps_ = v ? 1 : 0;
     else if (key == "bt_lag") bt_lag_ = v ? 1 : 0;
@@ -1641,7 +1642,8 @@ int64_t Engine::last_trace(gomilp_pivot *out, int64_t cap) {
 }
 
 
-// findLinearlyIndependent: the column scan on the device (general_kernels.hip), five launches per candidate and one look at the
+// findLinearlyIndependent: the column scan on the device — general_block.hip: 16 / 8 / 4 candidates per four launches (default);
+// general_kernels.hip: five launches per candidate (knob general_block = 0, bases beyond 4096 rows, the square step) — one look at the
 // state block per chunk of candidates; Q^T and R^-1 live in the two B^-1 buffers of the revised pipelines (free at this point)
 int Engine::find_independent_device(const Problem &P, std::vector<int32_t> &basic, std::vector<double> *binv_out) {
     Work &w = *w_;
@@ -1701,14 +1703,29 @@ int Engine::find_independent_device(const Problem &P, std::vector<int32_t> &basi
     launches_++;
     bool scan_done = s0 >= m - 1;
     int stop_after_prefix = col;
+    // blocked form (general_block.hip): NB candidates per four launches; as many blocks per look at the state as would fill the basis
+    // if every candidate were accepted (a rejected candidate costs one more look)
+    const int nbw = general_block_ ? gs_block_width(m) : 0;
+    int k_known = s0;
     for (; !scan_done;) {
-        const int chunk = std::min(col + 1, 128);
-        for (int q = 0; q < chunk; q++, col--) launch_gs_candidate(P.dAt + (size_t)col * P.ld, QT, Rinv, ldq, m, wv, tv, yv, col, w.gs_idx, w.gs_state, stream_);
-        launches_ += 5 * chunk;
+        if (nbw) {
+            const int want = std::max(1, std::min(32, (m - 1 - k_known + nbw - 1) / nbw));
+            for (int q = 0; q < want && col >= 0; q++) {
+                const int nc = std::min(nbw, col + 1);
+                launch_gs_block(P.dAt, P.ld, col, nc, QT, Rinv, ldq, m, w.yscratch, w.gs_idx, w.gs_state, stream_);
+                col -= nc;
+                launches_ += 4;
+            }
+        } else {
+            const int chunk = std::min(col + 1, 128);
+            for (int q = 0; q < chunk; q++, col--) launch_gs_candidate(P.dAt + (size_t)col * P.ld, QT, Rinv, ldq, m, wv, tv, yv, col, w.gs_idx, w.gs_state, stream_);
+            launches_ += 5 * chunk;
+        }
         HIP_TRY(hipMemcpyAsync(w.gs_host, w.gs_state, sizeof(GsState), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(sync_stream());
         HIP_TRY(hipGetLastError());
         if (w.gs_host->done || col < 0) break;
+        k_known = w.gs_host->k;
     }
     if (scan_done) {   // the unit columns alone filled m - 1 positions: the device never scanned
         HIP_TRY(hipMemcpyAsync(w.gs_host, w.gs_state, sizeof(GsState), hipMemcpyDeviceToHost, stream_));

@@ -440,11 +440,12 @@ def find_independent(A, fast: bool = True):
     return [int(v) for v in idx[:cnt]]
 
 
-def find_independent_device(A, device: int = -1):
-    """The same search with the column scan on the GPU (general_kernels.hip; the last, square step on the host)."""
+def find_independent_device(A, device: int = -1, **knobs):
+    """The same search with the column scan on the GPU (general_block.hip: blocks of candidates; knob general_block=0:
+    general_kernels.hip, one candidate at a time; the last, square step on the host)."""
     A = np.ascontiguousarray(A, dtype=np.float64)
     m, n = A.shape
-    cx = Context(device)
+    cx = Context(device, **knobs)
     try:
         p = cx.upload(np.zeros(n), A, np.zeros(m))
         idx = np.zeros(m, dtype=np.int64)
