@@ -710,7 +710,7 @@ def main() -> int:
                                 "status": int(rdev.status), "pivots": int(rdev.stats["pivots_phase1"] + rdev.stats["pivots_phase2"]),
                                 "seconds": tdev, "seconds_pivot_loops": rdev.stats["seconds_pivot_loop"], "seconds_with_host_search": thost,
                                 "same_result_as_host_search": bool(rdev.status == rhost.status and rdev.z == rhost.z and np.array_equal(rdev.x, rhost.x)),
-                                "note": "initial-basis search on the device (general_kernels.hip: explicit Q^T, five launches per candidate column); "
+                                "note": "initial-basis search on the device (general_block.hip: explicit Q^T, 16 candidate columns per four launches, the two products on the matrix cores); "
                                         "the reference form of the search is O(m^4)"}
 
     # ---- BASELINE config 5 on one GPU (the figure the N > 1 lines scale from)

@@ -11,13 +11,13 @@ A = rng.standard_normal((m, n)); b = A @ x0
 G = rng.standard_normal((m, n)); h = G @ x0 + np.abs(rng.standard_normal(m))
 c = np.abs(rng.standard_normal(n))
 c0, A0, b0 = O.convert_to_equalities(c, A, b, G, h)
-for dev in (1, 0):
-    cx = lp.Context(general_device=dev)
+for dev, blk in ((1, 1), (1, 0), (0, 0)):
+    cx = lp.Context(general_device=dev, general_block=blk)
     p = cx.upload(c0, A0, b0)
     for i in range(3):
         t0 = time.perf_counter(); g = p.solve(0.0); dt = time.perf_counter() - t0
         s = g.stats
-        print("search on", "device" if dev else "host  ", "rows", 2 * m, "cols", n + m, "status", g.status, "total %.1f ms" % (1e3 * dt), "loop %.1f final %.1f" % (1e3 * s["seconds_pivot_loop"], 1e3 * s["seconds_final_solve"]),
+        print("search on", ("device, blocked   " if blk else "device, one by one") if dev else "host              ", "rows", 2 * m, "cols", n + m, "status", g.status, "total %.1f ms" % (1e3 * dt), "loop %.1f final %.1f" % (1e3 * s["seconds_pivot_loop"], 1e3 * s["seconds_final_solve"]),
               "pivots", s["pivots_phase1"], s["pivots_phase2"], flush=True)
     cx.close()
 t0 = time.perf_counter(); idx = lp.find_independent(A0); print("search alone %.1f ms" % (1e3 * (time.perf_counter() - t0)), len(idx))
