@@ -1267,13 +1267,16 @@ int Engine::solve_locked(int64_t id, double tol, const int64_t *initial_basic, d
     } else {
         // general case (engine_general.cpp): host search over a kept copy of A, small problems on the tableau pipelines
         if (!use_tab || !ensure_host_A(P)) return finish(GOMILP_ERR_UNSUPPORTED);
+        const double t_g0 = now_s();
         if (!initial_basic) {
             // 224 rows and more: the scan runs on the device (180 rows: host 4.2 ms, device 5.8; 256 rows: 25 / 7.7; 600: 46 / 13; 1000: 180 / 31)
             rc = (m >= 224 && general_device_) ? find_independent_device(P, basic, &binv_host) : general_find_linearly_independent(P.hA, m, n, basic, &binv_host);
             if (rc != GOMILP_OK) return finish(rc);  // ErrSingular, simplex.go:495-497
         }
+        const double t_g1 = now_s();
         if (binv_host.size() != (size_t)m * m && !general_basis_inverse(P.hA, m, n, basic, n, std::vector<double>(), binv_host))
             return finish(initial_basic ? GOMILP_ERR_PANIC : GOMILP_ERR_SINGULAR);
+        const double t_g2 = now_s();
         // xb = ab^-1 b with the reference's own arithmetic (gonum-order LU on the device): the feasibility test of
         // simplex.go:459-469 then sees the same bits
         if ((rc = upload_index_lists(basic, {})) != GOMILP_OK) return finish(rc);
@@ -1282,6 +1285,7 @@ int Engine::solve_locked(int64_t id, double tol, const int64_t *initial_basic, d
         if (sing) { feasible = false; }  // "singular" also sends the reference to Phase I (simplex.go:504-507), xb stays zero
         else { xb = xb_exact; for (int pos = 0; pos < m; pos++) if (xb[pos] < -1e-13) feasible = false; }
         if (initial_basic && !feasible) return finish(GOMILP_ERR_PANIC);  // initializeFromBasic errors panic (:156-158)
+        if (GOMILP_DBG_ENV("GOMILP_DEBUG_GS")) fprintf(stderr, "general start: search %.2f ms, host inverse %.2f ms, x_B (gonum-order LU) %.2f ms\n", 1e3 * (t_g1 - t_g0), 1e3 * (t_g2 - t_g1), 1e3 * (now_s() - t_g2));
     }
     // small bases starting feasible: record the pivots for the host replay of the reference's condition guards
     // (every pipeline: until round 5 the revised-simplex pipelines — shapes with n - m >= 2m, wide small LPs among them — went without the

@@ -728,6 +728,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         return GOMILP_OK;
     };
     int nn;
+    const double t_st0 = now_s();
     if (!feasible) {
         // ---- Phase I (simplex.go:529-606) ----
         st->phase1_used = 1;
@@ -750,7 +751,9 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         build_nonbasic(n + 1);
         nn = (int)nonbasic.size();
         if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return rc;
+        const double t_st1 = now_s();
         if ((rc = set_up_T(nn)) != GOMILP_OK) return rc;
+        if (binv_host && GOMILP_DBG_ENV("GOMILP_DEBUG_GS")) { (void)sync_stream(); fprintf(stderr, "phase I set-up: artificial column + lists %.2f ms, B^-1 upload + T = B^-1 A_N %.2f ms\n", 1e3 * (t_st1 - t_st0), 1e3 * (now_s() - t_st1)); }
         const int qa = nn - 1;  // position of the artificial
         if (!use_bt_) {   // the single-kernel pipeline's forced pivot takes the column from dvec; the block kernel reads T itself
             launch_tab_column(w.T[0], ldt_, m, qa, w.xb, w.dvec, w.move, t_tiled_, stream_);

@@ -201,6 +201,31 @@ def test_blocked_lu_equals_per_column_lu_bitwise(m, seed):
         cx.close()
 
 
+@pytest.mark.parametrize("m", [40, 150, 300, 520])
+def test_lu_schedules_agree_where_the_pivot_search_ties(m):
+    """Integer data (entries 0..3, half of them zero): most pivot searches of the final solve find several rows with the same
+    |a_ik|, and dgetf2.go:38 takes the first in LAPACK's logical row order — the order the row interchanges of every earlier
+    step, bookkeeping steps included, have produced.  The compressed schedules (lu_blocked 3 / 2: index maps in LDS) against the
+    blocked panels and the one-launch-per-column form (1 / 0: kernels with a pivot search of their own): same basis, x and z bits."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lu_ties", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lu_ties.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    for seed in range(2):
+        c, A, b = mod.integer_lp(m, seed)
+        res = {}
+        for blocked in (3, 2, 1, 0):
+            cx = lp.Context(lu_blocked=blocked)
+            try:
+                res[blocked] = cx.upload(c, A, b).solve(0.0)
+            finally:
+                cx.close()
+        ref = res[0]
+        assert ref.stats["lu_dense_steps"] >= 0
+        for k in (3, 2, 1):
+            assert res[k].status == ref.status, (m, seed, k)
+            assert np.array_equal(res[k].basis, ref.basis) and np.array_equal(res[k].x, ref.x) and res[k].z == ref.z, (m, seed, k)
+
+
 def test_full_size_properties_C2(ctx):
     """1024x2048 (BASELINE config C2): size-independent checks — primal/dual feasibility, complementary
     slackness through an independent LAPACK solve, objective against HiGHS."""

@@ -11,7 +11,7 @@ A = rng.standard_normal((m, n)); b = A @ x0
 G = rng.standard_normal((m, n)); h = G @ x0 + np.abs(rng.standard_normal(m))
 c = np.abs(rng.standard_normal(n))
 c0, A0, b0 = O.convert_to_equalities(c, A, b, G, h)
-for dev, blk in ((1, 1), (1, 0), (0, 0)):
+for dev, blk in (((1, 1),) if os.environ.get("GOMILP_DEBUG_GS") else ((1, 1), (1, 0), (0, 0))):
     cx = lp.Context(general_device=dev, general_block=blk)
     p = cx.upload(c0, A0, b0)
     for i in range(3):
