@@ -15,7 +15,7 @@
 //                 of Q^T — the rows from k0 on: a reflector is zero above its own position — in registers and applies the
 //                 reflectors one after the other (y = v^T Q^T is a column sum inside the workgroup)
 // The arithmetic is the engine's own (a threshold on a condition number, not values the reference defines bit by bit); what must
-// agree, and is tested against the oracle's restatement of the reference and against the per-candidate form, is the list of
+// agree, and is tested against the CPU restatement of the reference (tests/) and against the per-candidate form, is the list of
 // accepted columns.  The square step (the last column) stays with general_kernels.hip / the host (engine.cpp).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
