@@ -1254,6 +1254,7 @@ int Engine::solve_locked(int64_t id, double tol, const int64_t *initial_basic, d
         }
     }
     gen_start_ = !unit_basis;
+    gen_binv_dev_ = false;
     badly_scaled_ = P.scale_span > 1e9;
     const int nn_max = n + 1 - m;
     // a non-slack starting basis (equality rows, supplied basis) always takes the tableau pipelines: their set-up accepts
@@ -1270,11 +1271,11 @@ int Engine::solve_locked(int64_t id, double tol, const int64_t *initial_basic, d
         const double t_g0 = now_s();
         if (!initial_basic) {
             // 224 rows and more: the scan runs on the device (180 rows: host 4.2 ms, device 5.8; 256 rows: 25 / 7.7; 600: 46 / 13; 1000: 180 / 31)
-            rc = (m >= 224 && general_device_) ? find_independent_device(P, basic, &binv_host) : general_find_linearly_independent(P.hA, m, n, basic, &binv_host);
+            rc = (m >= 224 && general_device_) ? find_independent_device(P, basic, &binv_host, &gen_binv_dev_) : general_find_linearly_independent(P.hA, m, n, basic, &binv_host);
             if (rc != GOMILP_OK) return finish(rc);  // ErrSingular, simplex.go:495-497
         }
         const double t_g1 = now_s();
-        if (binv_host.size() != (size_t)m * m && !general_basis_inverse(P.hA, m, n, basic, n, std::vector<double>(), binv_host))
+        if (!gen_binv_dev_ && binv_host.size() != (size_t)m * m && !general_basis_inverse(P.hA, m, n, basic, n, std::vector<double>(), binv_host))
             return finish(initial_basic ? GOMILP_ERR_PANIC : GOMILP_ERR_SINGULAR);
         const double t_g2 = now_s();
         // xb = ab^-1 b with the reference's own arithmetic (gonum-order LU on the device): the feasibility test of
@@ -1581,9 +1582,10 @@ bool Engine::root_general(int64_t id, RootView *out) {
     Work &w = *w_;
     std::vector<int32_t> basic;
     std::vector<double> binv;
-    const int rc = (m >= 224 && general_device_) ? find_independent_device(P, basic, &binv) : general_find_linearly_independent(P.hA, m, n, basic, &binv);
+    bool binv_dev = false;
+    const int rc = (m >= 224 && general_device_) ? find_independent_device(P, basic, &binv, &binv_dev) : general_find_linearly_independent(P.hA, m, n, basic, &binv);
     if (rc != GOMILP_OK || (int)basic.size() != m) return false;
-    if (binv.size() != (size_t)m * m && !general_basis_inverse(P.hA, m, n, basic, n, std::vector<double>(), binv)) return false;
+    if (!binv_dev && binv.size() != (size_t)m * m && !general_basis_inverse(P.hA, m, n, basic, n, std::vector<double>(), binv)) return false;
     std::vector<char> inb(n, 0);
     for (int i = 0; i < m; i++) inb[basic[i]] = 1;
     std::vector<int32_t> nonbasic, posvar(n);
@@ -1601,7 +1603,7 @@ bool Engine::root_general(int64_t id, RootView *out) {
     auto ok = [](hipError_t e) { return e == hipSuccess; };
     if (!ok(dmalloc(&G->dT0, (size_t)m * G->ldt)) || !ok(dmalloc(&G->dxb0, (size_t)m)) || !ok(dmalloc(&G->dbasic0, (size_t)m)) ||
         !ok(dmalloc(&G->dnonbasic0, (size_t)std::max(nn, 1))) || !ok(dmalloc(&G->dposvar0, (size_t)n))) return false;
-    if (!ok(hipMemcpy2DAsync(w.binv[0], (size_t)P.ld * sizeof(double), binv.data(), (size_t)m * sizeof(double), (size_t)m * sizeof(double), m, hipMemcpyHostToDevice, stream_))) return false;
+    if (!binv_dev && !ok(hipMemcpy2DAsync(w.binv[0], (size_t)P.ld * sizeof(double), binv.data(), (size_t)m * sizeof(double), (size_t)m * sizeof(double), m, hipMemcpyHostToDevice, stream_))) return false;
     if (!ok(hipMemsetAsync(G->dT0, 0, (size_t)m * G->ldt * sizeof(double), stream_))) return false;
     launch_tab_gemm(w.binv[0], P.ld, P.dAt, P.ld, m, nn, w.nonbasic, G->dT0, G->ldt, false, stream_);
     if (!ok(hipMemcpyAsync(G->dxb0, xb.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, stream_)) ||
@@ -1649,7 +1651,8 @@ int64_t Engine::last_trace(gomilp_pivot *out, int64_t cap) {
 // findLinearlyIndependent: the column scan on the device — general_block.hip: 16 / 8 / 4 candidates per four launches (default);
 // general_kernels.hip: five launches per candidate (knob general_block = 0, bases beyond 4096 rows, the square step) — one look at the
 // state block per chunk of candidates; Q^T and R^-1 live in the two B^-1 buffers of the revised pipelines (free at this point)
-int Engine::find_independent_device(const Problem &P, std::vector<int32_t> &basic, std::vector<double> *binv_out) {
+int Engine::find_independent_device(const Problem &P, std::vector<int32_t> &basic, std::vector<double> *binv_out, bool *binv_on_device) {
+    if (binv_on_device) *binv_on_device = false;
     Work &w = *w_;
     const int m = P.m, n = P.n, ldq = P.ld;
     const double t_gs0 = now_s();
@@ -1750,28 +1753,38 @@ int Engine::find_independent_device(const Problem &P, std::vector<int32_t> &basi
     if (cand >= 0) {
         launch_gs_candidate(P.dAt + (size_t)cand * P.ld, QT, Rinv, ldq, m, wv, tv, yv, cand, w.gs_idx, w.gs_state, stream_, 1);
         launch_gs_binv(Rinv, QT, ldq, m, w.W, stream_);
-        launches_ += 6;
-        HIP_TRY(hipMemcpyAsync(w.h_W, w.W, (size_t)m * ldq * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        // the two 1-norms on the device too (absolute column sums of C^-1 in 8 row slices, of the m basis columns out of At): 72 KB
+        // come home instead of the matrix — the 8 MB copy, the host's passes over it and over a strided A, and later the upload of the
+        // same B^-1 for the tableau set-up were 1.4 of the 1000-row solve's 17.5 ms
+        double *nrm = yv, *csum = yv + 8 * (size_t)P.ld;   // (the block search's W rows: free again)
+        launch_gs_norms(w.W, ldq, m, nrm, P.dAt, P.ld, w.gs_idx, cand, csum, stream_);
+        launches_ += 7;
+        const bool keep_dev = binv_on_device != nullptr;
+        if (keep_dev) HIP_TRY(hipMemcpyAsync(QT, w.W, (size_t)m * ldq * sizeof(double), hipMemcpyDeviceToDevice, stream_));   // Q^T has served: B^-1 takes its place (the LU that follows overwrites W)
+        double *hn = w.h_W;   // (pinned; 9 rows of ld doubles)
+        HIP_TRY(hipMemcpyAsync(hn, nrm, (size_t)9 * P.ld * sizeof(double), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipMemcpyAsync(w.gs_host, w.gs_state, sizeof(GsState), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(sync_stream());
         HIP_TRY(hipGetLastError());
         double nC = 0, nI = 0;
         bool finite = w.gs_host->beta_last != 0;
-        for (int p = 0; p < m && finite; p++) {   // |C|_1: largest absolute column sum over the m basis columns
-            const int j = p < m - 1 ? basic[p] : cand;
-            double sc = 0;
-            for (int r = 0; r < m; r++) sc += fabs(P.hA[(size_t)r * n + j]);
-            nC = std::max(nC, sc);
-        }
         if (finite) {
-            std::vector<double> colsum(m, 0.0);
-            for (int r = 0; r < m; r++) { const double *row = w.h_W + (size_t)r * ldq; for (int c2 = 0; c2 < m; c2++) colsum[c2] += fabs(row[c2]); }
-            for (int c2 = 0; c2 < m; c2++) { if (!std::isfinite(colsum[c2])) finite = false; nI = std::max(nI, colsum[c2]); }
+            const double *hc = hn + 8 * (size_t)P.ld;
+            for (int p = 0; p < m; p++) nC = std::max(nC, hc[p]);   // |C|_1: largest absolute column sum over the m basis columns
+            for (int c2 = 0; c2 < m; c2++) {
+                double sc = 0;
+                for (int sl = 0; sl < 8; sl++) sc += hn[(size_t)sl * P.ld + c2];
+                if (!std::isfinite(sc)) finite = false;
+                nI = std::max(nI, sc);
+            }
         }
         const double cond = finite ? nC * nI : std::numeric_limits<double>::infinity();
         if (!(cond > 1e12)) {   // simplex.go:630
             basic.push_back(cand);
-            if (binv_out) {
+            if (keep_dev) *binv_on_device = true;
+            else if (binv_out) {   // (a caller that wants the inverse at home)
+                HIP_TRY(hipMemcpyAsync(w.h_W, w.W, (size_t)m * ldq * sizeof(double), hipMemcpyDeviceToHost, stream_));
+                HIP_TRY(sync_stream());
                 binv_out->resize((size_t)m * m);
                 for (int r = 0; r < m; r++) memcpy(binv_out->data() + (size_t)r * m, w.h_W + (size_t)r * ldq, (size_t)m * sizeof(double));
             }

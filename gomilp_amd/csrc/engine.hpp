@@ -152,7 +152,7 @@ class Engine {
     int groups_knob(const Problem &P) const;
     bool ensure_host_A(const Problem &P);
     // findLinearlyIndependent with the scan on the device (general_kernels.hip) and the last, square step on the host
-    int find_independent_device(const Problem &P, std::vector<int32_t> &basic, std::vector<double> *binv_out);
+    int find_independent_device(const Problem &P, std::vector<int32_t> &basic, std::vector<double> *binv_out, bool *binv_on_device = nullptr);
     int stage_upload(void *dst, const void *src, size_t bytes);
     hipError_t sync_stream();
     int upload_index_lists(const std::vector<int32_t> &basic, const std::vector<int32_t> &nonbasic);
@@ -188,6 +188,7 @@ class Engine {
             exact_degenerate_ = 1,   // 0 never, 1 bases of up to 256 rows and every non-slack start, 2 always: pivots whose winning ratio is (nearly) zero are decided on a fresh gonum-order x_B; 3 strict: EVERY pivot and the stop test are decided on fresh gonum-order solves
             cond_guard_ = 1;   // replay the condition guards of the reference on the host for bases of up to 64 rows
     bool badly_scaled_ = false;   // the current problem's entries span more than nine decades (Problem::scale_span): guard on, tableau checked
+    bool gen_binv_dev_ = false;   // the searched basis' B^-1 = R^-1 Q^T is resident in the first B^-1 buffer (the device judged the square step): no upload
     bool gen_start_ = false;      // the current solve starts from a searched (non-slack) basis: the degenerate-pivot guard stays on
     bool xchg_timeout_ = false;   // the last pivot loop ended in ST_XCHG_TIMEOUT (Engine::solve repeats the solve once)
     bool shadow_trace_ = false;   // this solve records its pivots for the replay even when the caller did not ask for a trace   // developer knobs of the block kernels (per context: tests force the 1024-thread instance)
@@ -265,6 +266,7 @@ int gs_block_width(int m);
 int gs_block_scratch_rows();
 void launch_gs_block(const double *At, int ld, int col0, int ncand, double *QT, double *Rinv, int ldq, int m, double *scratch, int32_t *idxs, GsState *st, hipStream_t s);
 void launch_gs_binv(const double *Rinv, const double *QT, int ldq, int m, double *C, hipStream_t s);
+void launch_gs_norms(const double *C, int ldq, int m, double *out, const double *At, int ld, const int32_t *idxs, int cand, double *colsum, hipStream_t s);
 // bt_kernels.hip
 bool bt_supported(int m, int nn);
 int bt_max_k();

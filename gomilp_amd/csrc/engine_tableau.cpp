@@ -704,7 +704,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
     if (!binv_host && (rc = stage_upload(w.rho, rho.data(), (size_t)m * sizeof(int32_t))) != GOMILP_OK) return rc;
     // (x_B itself was uploaded by Engine::solve)
     std::vector<double> art(P.ld, 0.0);  // Phase-I artificial column (simplex.go:533-542)
-    bool binv_on_device = false;
+    bool binv_on_device = gen_binv_dev_;   // (the device search left B^-1 = R^-1 Q^T in place: engine.cpp find_independent_device)
     auto set_up_T = [&](int nn) -> int {  // T = B^-1 A_N
         ldt_ = tab_ld(nn);
         if (!binv_host) {  // slack basis: B^-1 is the permutation rho
@@ -761,7 +761,12 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         }
         double dp = 0;  // pivot element of the forced pivot: (B^-1 a_art)[minidx]
         if (!binv_host) dp = art[rho[minidx]];
-        else for (int i = 0; i < m; i++) dp += (*binv_host)[(size_t)minidx * m + i] * art[i];
+        else if (!use_bt_) {   // (only the single-kernel pipeline's forced pivot takes it from the host)
+            std::vector<double> brow(m);
+            if (gen_binv_dev_) { HIP_TRY(hipMemcpyAsync(brow.data(), w.binv[0] + (size_t)minidx * P.ld, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream_)); HIP_TRY(sync_stream()); }
+            else for (int i = 0; i < m; i++) brow[i] = (*binv_host)[(size_t)minidx * m + i];
+            for (int i = 0; i < m; i++) dp += brow[i] * art[i];
+        }
         const int slack = basic[minidx];
         // the register-resident block kernel exchanges the two list entries itself (uncounted), which saves the second
         // upload of the lists when no re-sort follows

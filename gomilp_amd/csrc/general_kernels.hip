@@ -222,6 +222,33 @@ __global__ __launch_bounds__(256) void k_gs_binv(const double *__restrict__ Rinv
         if (i0 + ty + 8 * u < m && j0 + tx < m) C[(size_t)(i0 + ty + 8 * u) * ldq + j0 + tx] = acc[u];
 }
 
+// the square step's two 1-norms without a trip of the matrices to the host: out[sl][c] = sum over the rows r = sl, sl + 8, ... of
+// |C[r][c]| (8 row slices: the host adds them in a fixed order), and colsum[p] = sum_r |A[r][idx(p)]| for the m basis columns (rows
+// of At; position m - 1 is the candidate)
+__global__ __launch_bounds__(256) void k_gs_norms(const double *__restrict__ C, int ldq, int m, double *__restrict__ out, const double *__restrict__ At, int ld,
+                                                  const int32_t *__restrict__ idxs, int cand, double *__restrict__ colsum) {
+    const int c = blockIdx.x * 256 + threadIdx.x, sl = blockIdx.y;
+    if (c < m) {
+        double s0 = 0, s1 = 0;
+        int r = sl;
+        for (; r + 8 < m; r += 16) { s0 += fabs(C[(size_t)r * ldq + c]); s1 += fabs(C[(size_t)(r + 8) * ldq + c]); }
+        if (r < m) s0 += fabs(C[(size_t)r * ldq + c]);
+        out[(size_t)sl * ldq + c] = s0 + s1;
+    }
+    // basis columns: one wave per position, the workgroups of slice 0 .. 7 share them
+    const int lane = threadIdx.x & 63;
+    for (int p = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6); p < m; p += gridDim.x * gridDim.y * 4) {
+        const double *col = At + (size_t)(p < m - 1 ? idxs[p] : cand) * ld;
+        double sc = 0;
+        for (int r = lane; r < m; r += 64) sc += fabs(col[r]);
+        sc = wave_sum_f64(sc);
+        if (lane == 0) colsum[p] = sc;
+    }
+}
+void launch_gs_norms(const double *C, int ldq, int m, double *out, const double *At, int ld, const int32_t *idxs, int cand, double *colsum, hipStream_t s) {
+    hipLaunchKernelGGL(k_gs_norms, dim3((m + 255) / 256, 8), dim3(256), 0, s, C, ldq, m, out, At, ld, idxs, cand, colsum);
+}
+
 void launch_gs_init(double *QT, int ldq, int m, GsState *st, hipStream_t s) { hipLaunchKernelGGL(k_gs_init, dim3(m), dim3(256), 0, s, QT, ldq, m, st); }
 void launch_gs_init_perm(double *QT, double *Rinv, int ldq, int m, const int32_t *perm, const double *sgn, const double *beta, int s0, GsState *st, hipStream_t s) {
     hipLaunchKernelGGL(k_gs_init_perm, dim3(m), dim3(256), 0, s, QT, Rinv, ldq, m, perm, sgn, beta, s0, st);

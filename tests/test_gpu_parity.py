@@ -201,29 +201,61 @@ def test_blocked_lu_equals_per_column_lu_bitwise(m, seed):
         cx.close()
 
 
-@pytest.mark.parametrize("m", [40, 150, 300, 520])
+def _lu_ties():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lu_ties", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lu_ties.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("m", [40, 150, 300])
 def test_lu_schedules_agree_where_the_pivot_search_ties(m):
     """Integer data (entries 0..3, half of them zero): most pivot searches of the final solve find several rows with the same
     |a_ik|, and dgetf2.go:38 takes the first in LAPACK's logical row order — the order the row interchanges of every earlier
     step, bookkeeping steps included, have produced.  The compressed schedules (lu_blocked 3 / 2: index maps in LDS) against the
-    blocked panels and the one-launch-per-column form (1 / 0: kernels with a pivot search of their own): same basis, x and z bits."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("lu_ties", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lu_ties.py"))
-    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
-    for seed in range(2):
+    blocked panels and the one-launch-per-column form (1 / 0: kernels with a pivot search of their own): same basis, x and z bits;
+    and the oracle's.  (Seeds on which the reference's rule terminates: see the next test.  The pivot budget only guards the run.)"""
+    mod = _lu_ties()
+    for seed in (0, 2):
         c, A, b = mod.integer_lp(m, seed)
+        want = O.simplex(c, A, b, stop_after_pivots=5000)
+        assert not want.truncated
         res = {}
         for blocked in (3, 2, 1, 0):
-            cx = lp.Context(lu_blocked=blocked)
+            cx = lp.Context(lu_blocked=blocked, max_pivots=5000)
             try:
                 res[blocked] = cx.upload(c, A, b).solve(0.0)
             finally:
                 cx.close()
         ref = res[0]
-        assert ref.stats["lu_dense_steps"] >= 0
         for k in (3, 2, 1):
             assert res[k].status == ref.status, (m, seed, k)
             assert np.array_equal(res[k].basis, ref.basis) and np.array_equal(res[k].x, ref.x) and res[k].z == ref.z, (m, seed, k)
+        assert ref.status == want.status == lp.OK
+        if m <= 256:   # (exact steps on fresh gonum-order solves up to 256 rows: the reference's path through the degenerate vertices, bit for bit)
+            assert ref.stats["pivots_phase1"] + ref.stats["pivots_phase2"] == want.pivots_phase1 + want.pivots_phase2
+            assert np.array_equal(ref.x, np.asarray(want.x)) and ref.z == want.z, (m, seed)
+
+
+def test_engine_follows_the_reference_into_its_cycle():
+    """lp.Simplex has no iteration limit (simplex.go:233), and on the 40-row integer LP of seed 1 its rule does not terminate: from
+    pivot 24 on two columns trade places at position 14 for ever — each exchange a NON-degenerate step by a rounding-size amount, so
+    the Bland branch (:268-277) never takes over.  The oracle shows it (3000 pivots, truncated); the engine, which takes the same
+    decisions, walks the same cycle: with a budget of 400 pivots both traces are equal pivot by pivot.  (A caller that wants an end
+    sets `max_pivots`; the reference offers none.)"""
+    mod = _lu_ties()
+    c, A, b = mod.integer_lp(40, 1)
+    want = O.simplex(c, A, b, trace=True, stop_after_pivots=400)
+    assert want.truncated and len(want.pivots) == 400
+    assert list(want.pivots[398][4:6]) == list(want.pivots[396][4:6]) and list(want.pivots[399][4:6]) == list(want.pivots[397][4:6])   # the cycle of two
+    cx = lp.Context(max_pivots=400)
+    try:
+        got = cx.upload(c, A, b).solve(0.0, trace=True)
+    finally:
+        cx.close()
+    assert got.status == lp.ERR_UNSUPPORTED and len(got.pivots) == 400      # the pivot budget ran out, as asked
+    five = lambda tr: [(p[0], p[2], p[3], p[4], p[5]) for p in tr]   # phase, minIdx, replace, entering, leaving (as every trace test: the flag of the step that found them is the engine's own)
+    assert five(got.pivots) == five(want.pivots)
 
 
 def test_full_size_properties_C2(ctx):

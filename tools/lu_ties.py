@@ -31,6 +31,7 @@ if __name__ == "__main__":
                 cx = lp.Context(lu_blocked=blocked)
                 p = cx.upload(c, A, b)
                 t0 = time.perf_counter(); res[blocked] = p.solve(0.0); dt = time.perf_counter() - t0
+                if os.environ.get("LU_TIES_VERBOSE"): print("  m %d seed %d lu_blocked %d: %.1f ms, status %d, pivots %d + %d" % (m, seed, blocked, 1e3 * dt, res[blocked].status, res[blocked].stats["pivots_phase1"], res[blocked].stats["pivots_phase2"]), flush=True)
                 cx.close()
             ref = res[0]
             same = all(res[k].status == ref.status and np.array_equal(res[k].basis, ref.basis) and np.array_equal(res[k].x, ref.x) and res[k].z == ref.z for k in (3, 2, 1))
