@@ -623,15 +623,16 @@ def main() -> int:
         lps = [synth.dense_lp_standard_form(m, seed + 100 + i) for i in range(args.concurrent)]
         poolb.set_root(*lps[0])
         roots = [0] + [poolb.add_root(*q) for q in lps[1:]]
-        tb, resb = 0.0, None
-        for rep in range(3):  # first rounds = warm-up
+        tbs, resb = [], None
+        for rep in range(6):  # first round = warm-up; the MEDIAN of the other five is reported (one sample swung between 24 and 38 ms from run to run: r5b / r5e / r5f)
             torch.cuda.synchronize()
             tb0 = time.perf_counter()
             resb = poolb.solve([[] for _ in roots], roots=roots)
             torch.cuda.synchronize()
-            tb = time.perf_counter() - tb0
+            if rep: tbs.append(time.perf_counter() - tb0)
+        tb = sorted(tbs)[len(tbs) // 2]
         pb = resb.stats["pivots_phase1"] + resb.stats["pivots_phase2"]
-        out["batched"] = {"concurrent_lps": len(roots), "pivots": int(pb), "seconds": tb, "pivots_per_s": pb / tb, "vs_single": pb / tb / value,
+        out["batched"] = {"concurrent_lps": len(roots), "pivots": int(pb), "seconds": tb, "seconds_all": tbs, "pivots_per_s": pb / tb, "vs_single": pb / tb / value,
                           "all_ok": bool((resb.status == lp.OK).all()), "device_batched": int(resb.stats["batched_relaxations"]),
                           "host_round_trips": int(resb.stats["supersteps"]),
                           "note": ("independent %dx%d LPs (seeds +100..) through gomilp_frontier_solve_roots on one GPU: " % (m, n)) +

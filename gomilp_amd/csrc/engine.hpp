@@ -266,6 +266,7 @@ int gs_block_width(int m);
 int gs_block_scratch_rows();
 void launch_gs_block(const double *At, int ld, int col0, int ncand, double *QT, double *Rinv, int ldq, int m, double *scratch, int32_t *idxs, GsState *st, hipStream_t s);
 void launch_gs_binv(const double *Rinv, const double *QT, int ldq, int m, double *C, hipStream_t s);
+void launch_gs_art(const double *At, int ld, int m, const int32_t *basic, int minidx, const double *b, double *art, hipStream_t s);
 void launch_gs_norms(const double *C, int ldq, int m, double *out, const double *At, int ld, const int32_t *idxs, int cand, double *colsum, hipStream_t s);
 // bt_kernels.hip
 bool bt_supported(int m, int nn);

@@ -733,24 +733,31 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         // ---- Phase I (simplex.go:529-606) ----
         st->phase1_used = 1;
         const int64_t minidx = min_idx(xb.data(), m);
+        const bool art_on_device = binv_host && m >= 224;   // (large general starts: the same subtractions, element by element, by k_gs_art)
         for (int k = 0; k < m; k++) art[k] = P.hb[k];
         if (!binv_host) {
             for (int i = 0; i < m; i++) { if (i == minidx) continue; art[rho[i]] = -1 * 1.0 + art[rho[i]]; }  // floats.Sub, :536-542
-        } else {
+        } else if (!art_on_device) {
             for (int i = 0; i < m; i++) {  // same loop over full columns
                 if (i == minidx) continue;
                 for (int k = 0; k < m; k++) art[k] = -1 * P.hA[(size_t)k * n + basic[i]] + art[k];
             }
         }
-        bool art_zero = true;
-        for (int k = 0; k < m; k++) if (art[k] != 0) { art_zero = false; break; }
-        if (art_zero) { st->wrapped_status = GOMILP_ERR_ZERO_COLUMN; return GOMILP_ERR_PHASE1_WRAPPED; }
-        if ((rc = stage_upload(P.dAt + (size_t)n * P.ld, art.data(), (size_t)P.ld * sizeof(double))) != GOMILP_OK) return rc;
         // tableau over the n+1-m columns that are nonbasic w.r.t. the slack basis (the artificial is the last one),
         // then one forced pivot brings the artificial into position minidx (the basis of simplex.go:551)
         build_nonbasic(n + 1);
         nn = (int)nonbasic.size();
         if ((rc = upload_index_lists(basic, nonbasic)) != GOMILP_OK) return rc;
+        if (art_on_device) {
+            launch_gs_art(P.dAt, P.ld, m, w.basic, (int)minidx, P.db, P.dAt + (size_t)n * P.ld, stream_);
+            launches_++;
+            HIP_TRY(hipMemcpyAsync(art.data(), P.dAt + (size_t)n * P.ld, (size_t)P.ld * sizeof(double), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(sync_stream());
+        }
+        bool art_zero = true;
+        for (int k = 0; k < m; k++) if (art[k] != 0) { art_zero = false; break; }
+        if (art_zero) { st->wrapped_status = GOMILP_ERR_ZERO_COLUMN; return GOMILP_ERR_PHASE1_WRAPPED; }
+        if (!art_on_device && (rc = stage_upload(P.dAt + (size_t)n * P.ld, art.data(), (size_t)P.ld * sizeof(double))) != GOMILP_OK) return rc;
         const double t_st1 = now_s();
         if ((rc = set_up_T(nn)) != GOMILP_OK) return rc;
         if (binv_host && GOMILP_DBG_ENV("GOMILP_DEBUG_GS")) { (void)sync_stream(); fprintf(stderr, "phase I set-up: artificial column + lists %.2f ms, B^-1 upload + T = B^-1 A_N %.2f ms\n", 1e3 * (t_st1 - t_st0), 1e3 * (now_s() - t_st1)); }

@@ -249,6 +249,26 @@ void launch_gs_norms(const double *C, int ldq, int m, double *out, const double 
     hipLaunchKernelGGL(k_gs_norms, dim3((m + 255) / 256, 8), dim3(256), 0, s, C, ldq, m, out, At, ld, idxs, cand, colsum);
 }
 
+// Phase-I artificial column of a start from a searched basis (simplex.go:536-542): a_{n+1} = b - sum_{i != minidx} a_{basic_i}, every
+// element taking its subtractions in ascending i as `-1 * a + art` (floats.Sub per column: the host loop's operation order — which walked
+// a row-major A with stride n, 0.6 ms at 1000 rows); one thread per row, the basis columns are rows of At
+__global__ __launch_bounds__(256) void k_gs_art(const double *__restrict__ At, int ld, int m, const int32_t *__restrict__ basic, int minidx, const double *__restrict__ b,
+                                                double *__restrict__ art) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ld) return;
+    double acc = k < m ? b[k] : 0.0;
+    if (k < m) {
+        for (int i = 0; i < m; i++) {
+            if (i == minidx) continue;
+            acc = __dadd_rn(__dmul_rn(-1.0, At[(size_t)basic[i] * ld + k]), acc);
+        }
+    }
+    art[k] = acc;
+}
+void launch_gs_art(const double *At, int ld, int m, const int32_t *basic, int minidx, const double *b, double *art, hipStream_t s) {
+    hipLaunchKernelGGL(k_gs_art, dim3((ld + 255) / 256), dim3(256), 0, s, At, ld, m, basic, minidx, b, art);
+}
+
 void launch_gs_init(double *QT, int ldq, int m, GsState *st, hipStream_t s) { hipLaunchKernelGGL(k_gs_init, dim3(m), dim3(256), 0, s, QT, ldq, m, st); }
 void launch_gs_init_perm(double *QT, double *Rinv, int ldq, int m, const int32_t *perm, const double *sgn, const double *beta, int s0, GsState *st, hipStream_t s) {
     hipLaunchKernelGGL(k_gs_init_perm, dim3(m), dim3(256), 0, s, QT, Rinv, ldq, m, perm, sgn, beta, s0, st);
