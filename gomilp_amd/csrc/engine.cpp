@@ -867,6 +867,7 @@ int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_hos
             int batch = a.slots ? std::max(1, (std::min(m, (5 * nonunit) / 2) + nb - 1) / nb) : std::max(1, (3 * nonunit + nb - 1) / nb + 1);
             if (oneshot && GOMILP_DBG_ENV("GOMILP_DEBUG_LU_SHORT")) batch = 1;   // (diagnostic flavour: a first batch that is too short — the small-basis block comes too early and the general path takes over)
             int enq = 0;   // rounds enqueued so far: the look-ahead schedule keeps two control blocks, by round parity
+            int k_seen = -1;   // steps done when the control block was last read
             const LUCtl *last = w.luctl_host;
             for (;;) {
                 launches_ += launch_luc_rounds(a, w.rho, batch, enq, stream_);
@@ -893,6 +894,10 @@ int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_hos
                 }
                 last = w.luctl_host + (a.look ? ((enq - 1) & 1) : 0);
                 if (w.luctl_host[0].fault || last->k_next >= m) break;
+                // (every round performs at least the step it starts at — a listed column or a bookkeeping step; a batch that moved nothing
+                // would repeat for ever: report it instead)
+                if (last->k_next <= k_seen) return GOMILP_ERR_DEVICE;
+                k_seen = last->k_next;
                 oneshot = false;   // (the batch was too short: that pack came too early)
                 batch = std::max(4, (int)(((int64_t)(m - last->k_next) * last->rounds) / std::max(1, last->k_next)) + 2);
                 if (batch > 64) batch = 64;
