@@ -98,6 +98,7 @@ int Engine::set(const std::string &key, int64_t v) {
 #endif
     else if (key == "general_device") general_device_ = v ? 1 : 0;
     else if (key == "general_block") general_block_ = v ? 1 : 0;
+    else if (key == "general_min_rows") general_min_rows_ = v < 2 ? 2 : v;
     else if (key == "bt_groups") { if (v != -1 && v != 0 && v != 2 && v != 4 && v != 8 && v != 16) return GOMILP_ERR_BAD_SHAPE; bt_groups_ = v; }
     else if (key == "bt_stamps") bt_stamps_ = v ? 1 : 0;
     else if (key == "bt_lag") bt_lag_ = v ? 1 : 0;
@@ -1275,8 +1276,10 @@ int Engine::solve_locked(int64_t id, double tol, const int64_t *initial_basic, d
         if (!use_tab || !ensure_host_A(P)) return finish(GOMILP_ERR_UNSUPPORTED);
         const double t_g0 = now_s();
         if (!initial_basic) {
-            // 224 rows and more: the scan runs on the device (180 rows: host 4.2 ms, device 5.8; 256 rows: 25 / 7.7; 600: 46 / 13; 1000: 180 / 31)
-            rc = (m >= 224 && general_device_) ? find_independent_device(P, basic, &binv_host, &gen_binv_dev_) : general_find_linearly_independent(P.hA, m, n, basic, &binv_host);
+            // 96 rows and more (knob general_min_rows): the scan runs on the device — whole solves with the host / the blocked device search,
+            // tools/general_small.py: 64 rows 0.96 / 1.08 ms, 96: 1.54 / 1.51, 128: 2.28 / 1.85, 180: 4.5 / 2.9, 224: 6.8 / 3.4, 300: 11.1 / 4.5
+            // (until round 5, five launches per candidate: 224 rows)
+            rc = (m >= general_min_rows_ && general_device_) ? find_independent_device(P, basic, &binv_host, &gen_binv_dev_) : general_find_linearly_independent(P.hA, m, n, basic, &binv_host);
             if (rc != GOMILP_OK) return finish(rc);  // ErrSingular, simplex.go:495-497
         }
         const double t_g1 = now_s();
@@ -1588,7 +1591,7 @@ bool Engine::root_general(int64_t id, RootView *out) {
     std::vector<int32_t> basic;
     std::vector<double> binv;
     bool binv_dev = false;
-    const int rc = (m >= 224 && general_device_) ? find_independent_device(P, basic, &binv, &binv_dev) : general_find_linearly_independent(P.hA, m, n, basic, &binv);
+    const int rc = (m >= general_min_rows_ && general_device_) ? find_independent_device(P, basic, &binv, &binv_dev) : general_find_linearly_independent(P.hA, m, n, basic, &binv);
     if (rc != GOMILP_OK || (int)basic.size() != m) return false;
     if (!binv_dev && binv.size() != (size_t)m * m && !general_basis_inverse(P.hA, m, n, basic, n, std::vector<double>(), binv)) return false;
     std::vector<char> inb(n, 0);

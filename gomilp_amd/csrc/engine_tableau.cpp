@@ -733,7 +733,7 @@ int Engine::solve_tableau(const Problem &P, double tol, std::vector<int32_t> &ba
         // ---- Phase I (simplex.go:529-606) ----
         st->phase1_used = 1;
         const int64_t minidx = min_idx(xb.data(), m);
-        const bool art_on_device = binv_host && m >= 224;   // (large general starts: the same subtractions, element by element, by k_gs_art)
+        const bool art_on_device = binv_host && m >= general_min_rows_;   // (large general starts: the same subtractions, element by element, by k_gs_art)
         for (int k = 0; k < m; k++) art[k] = P.hb[k];
         if (!binv_host) {
             for (int i = 0; i < m; i++) { if (i == minidx) continue; art[rho[i]] = -1 * 1.0 + art[rho[i]]; }  // floats.Sub, :536-542
