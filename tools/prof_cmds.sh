@@ -15,6 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_C5 -- python3
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_wide -- python3 tools/wave_prof.py 6 4 0 11 > $OUT/wide_profiled.out 2> $OUT/stats_wide.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_xwide -- python3 tools/wave_prof.py 4 4 0 13 > $OUT/xwide_profiled.out 2> $OUT/stats_xwide.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_C4 -- python3 bench.py --workload C4 --steps 2 --warmup 1 $HEAD > $OUT/bench_C4_profiled.json 2> $OUT/stats_C4.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_general -- python3 tools/general_prof.py > $OUT/general_profiled.out 2> $OUT/stats_general.err
 # 3. PMC passes (separate runs; counters only)
 SMALL="--steps 1 --warmup 0 --no-cpu-baseline --concurrent 0 --milp-nodes 0 --c4 0 --general 0 --frontier-vars 0"   # (the metric LP alone: the frontier legs have PMC passes of their own below)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $SMALL > $OUT/pmc_f.json 2> $OUT/pmc_f.err
