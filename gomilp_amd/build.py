@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 DEBUG = os.environ.get("GOMILP_DEBUG_BUILD", "") not in ("", "0")
 OBJ = os.path.join(HERE, "build_debug" if DEBUG else "build")
 LIB = os.path.join(HERE, "libgomilp_hip_debug.so" if DEBUG else "libgomilp_hip.so")
-SOURCES = ["simplex_kernels.hip", "fused_kernels.hip", "lu_kernels.hip", "lu_compressed.hip", "tableau_kernels.hip", "bt_kernels.hip", "btg_kernels.hip", "btr_kernels.hip",
+SOURCES = ["simplex_kernels.hip", "fused_kernels.hip", "lu_kernels.hip", "lu_compressed.hip", "lu_cross.hip", "tableau_kernels.hip", "bt_kernels.hip", "btg_kernels.hip", "btr_kernels.hip",
            "batch_kernels.hip", "res_kernels.hip", "general_kernels.hip", "general_block.hip", "engine.cpp", "engine_batch.cpp", "engine_tableau.cpp", "engine_general.cpp", "gonum_cond.cpp", "c_api.cpp", "comm.cpp"]
 HEADERS = ["device_types.h", "kernels_common.h", "bt_loop.h", "batch_dev.h", "engine.hpp", "engine_work.hpp", "engine_batch.hpp", os.path.join(ROOT, "include", "gomilp_lp.h")]
 # -ffp-contract=off: the final basis solve must round every multiply and add separately, like the

@@ -135,7 +135,7 @@ struct gomilp_pool {
 };
 
 #ifdef GOMILP_DEBUG
-namespace gomilp { void luc_stamps_read(unsigned long long *out); void res_stamps_read(unsigned long long *out); }
+namespace gomilp { void luc_stamps_read(unsigned long long *out); void res_stamps_read(unsigned long long *out); void lux_stamps_read(unsigned long long *out); }
 #endif
 
 extern "C" {
@@ -713,6 +713,7 @@ long long gomilp_debug_loop_rep_launches(void) { return gomilp::bt_loop_rep_laun
 #ifdef GOMILP_DEBUG
 // diagnostic flavour only: cycle sums of the final-solve panel kernel (lu_compressed.hip), 4 waves x 16 segments
 void gomilp_debug_luc_stamps(unsigned long long *out) { gomilp::luc_stamps_read(out); }
+void gomilp_debug_lux_stamps(unsigned long long *out) { gomilp::lux_stamps_read(out); }
 void gomilp_debug_res_stamps(unsigned long long *out) { gomilp::res_stamps_read(out); }
 #endif
 

@@ -97,6 +97,7 @@ int Engine::set(const std::string &key, int64_t v) {
     else if (key == "bt_fault") bt_fault_ = v;   // fault injection, diagnostic flavour only: 1 a workgroup of the block / loop kernels, 2 the U-solve workgroup of the look-ahead LU
 #endif
     else if (key == "general_device") general_device_ = v ? 1 : 0;
+    else if (key == "lu_cross") lu_cross_ = v ? 1 : 0;
     else if (key == "general_block") general_block_ = v ? 1 : 0;
     else if (key == "general_min_rows") general_min_rows_ = v < 2 ? 2 : v;
     else if (key == "bt_groups") { if (v != -1 && v != 0 && v != 2 && v != 4 && v != 8 && v != 16) return GOMILP_ERR_BAD_SHAPE; bt_groups_ = v; }
@@ -823,6 +824,15 @@ int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_hos
         void drop() { if (held) Engine::loop_release(dev, 4, 0); held = false; }
     } look_slot(device_, a.look != 0);
     if (!look_slot.held) a.look = 0;
+    // opt-in: the rows of a panel on the workgroups of one XCD (lu_cross.hip) — the plain schedule with that panel
+    int cross_G = (lu_cross_ && compressed) ? luc_cross_groups(m, 1) : 0;
+    if (cross_G) {
+        if (!w.luxrec) {
+            HIP_TRY(dmalloc(&w.luxrec, luc_cross_doubles()));
+            HIP_TRY(hipMemsetAsync(w.luxrec, 0, luc_cross_doubles() * sizeof(double), stream_));
+        }
+        a.look = 0; look_slot.drop();
+    }
     a.ctl_prev = a.ctl; a.Lp_prev = a.Lp; a.Up_prev = a.Up;
     a.rowsnap = w.rowstep + w.cap_m; a.rowsnap_prev = a.rowsnap;   // (launch_luc_rounds sets the round's parity)
     a.ctl_base = a.ctl; a.round = 0; a.pad3 = bt_fault_ == 2 ? 1 : 0;
@@ -871,7 +881,7 @@ int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_hos
             int k_seen = -1;   // steps done when the control block was last read
             const LUCtl *last = w.luctl_host;
             for (;;) {
-                launches_ += launch_luc_rounds(a, w.rho, batch, enq, stream_);
+                launches_ += cross_G ? launch_luc_rounds_cross(a, w.rho, batch, w.luxrec, cross_G, stream_) : launch_luc_rounds(a, w.rho, batch, enq, stream_);
                 enq += batch;
                 if (oneshot) {
                     launch_luc_pack_small(a, w.Wd, stream_);
@@ -908,8 +918,8 @@ int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_hos
             if (!w.luctl_host[0].fault) break;
             // a wait inside a look-ahead launch ran out of patience (its workgroups never became resident together): once more, from the
             // basis, with the whole update behind each panel
-            if (attempt > 0 || !a.look) return GOMILP_ERR_DEVICE;
-            a.look = 0; oneshot = false;
+            if (attempt > 0 || !(a.look || cross_G)) return GOMILP_ERR_DEVICE;
+            a.look = 0; cross_G = 0; oneshot = false;
             lu_look_faults_++; lu_look_fault_ = true;
             if (GOMILP_DBG_ENV("GOMILP_DEBUG_LOOP")) fprintf(stderr, "final_solve: a look-ahead launch gave up a wait (m %d, rounds enqueued %d, cnt_x %u cnt_u %u cnt_s %u): plain schedule\n", m, enq, w.luctl_host[0].cnt_x, w.luctl_host[0].cnt_u, w.luctl_host[0].cnt_s);
             if (compressed != transpose) launch_luc_gather(P.dAt, P.ld, m, w.basic, w.W, ldw, stream_);

@@ -176,7 +176,7 @@ class Engine {
     bool lu_look_fault_ = false;   // ... in the running solve (stats.device_retries)
     int64_t lu_look_ = 1;          // knob lu_look: 0 = never the look-ahead schedule (the workers of a pool)
     int64_t chunk_ = 32, refresh_ = 0, trace_on_ = 0, max_pivots_ = 0, sample_events_ = 0, fused_ = 1, lu_blocked_ = 3, tableau_ = 1, blocked_ = 1, block_k_ = 0,  // block_k_ 0 = auto
-            bt_nt_ = 0, bt_old_ = 0, bt_stamps_ = 0, bt_upd_valu_ = 0, bt_fault_ = 0, general_device_ = 1, general_block_ = 1, general_min_rows_ = 96, bt_groups_ = 0,   // bt_groups_: -1 never, 0 by shape, 2 / 4 / 8 forced
+            bt_nt_ = 0, bt_old_ = 0, bt_stamps_ = 0, bt_upd_valu_ = 0, bt_fault_ = 0, general_device_ = 1, general_block_ = 1, general_min_rows_ = 96, lu_cross_ = 0, bt_groups_ = 0,   // bt_groups_: -1 never, 0 by shape, 2 / 4 / 8 forced
             bt_lag_ = 1,       // persistent loop kernel where the multi-workgroup block kernel runs (0: block kernel + update launches)
             loop_chunk_ = 512, // pivots per launch of the persistent loop kernel
             loop_grid_ = 0,    // its workgroups (0: one per CU)
@@ -261,6 +261,9 @@ void launch_gs_init(double *QT, int ldq, int m, GsState *st, hipStream_t s);
 void launch_gs_init_perm(double *QT, double *Rinv, int ldq, int m, const int32_t *perm, const double *sgn, const double *beta, int s0, GsState *st, hipStream_t s);
 void launch_gs_candidate(const double *acol, double *QT, double *Rinv, int ldq, int m, double *w, double *t, double *ypart, int cand, int32_t *idxs, GsState *st, hipStream_t s,
                          int last = 0);
+int launch_luc_rounds_cross(const LUArgs &base, int32_t *pivrow, int nrounds, double *xrec, int G, hipStream_t s);
+size_t luc_cross_doubles();
+int luc_cross_groups(int m, int want);
 int gs_scratch_rows();
 int gs_block_width(int m);
 int gs_block_scratch_rows();

@@ -84,6 +84,7 @@ struct Engine::Work {
     double *btU = nullptr, *btV = nullptr;  // blocked tableau: rank-1 terms of the running block
     double *xbuf = nullptr;                 // multi-workgroup block kernel: exchange records (btg_kernels.hip)
     int64_t loop_launches = 0;              // launches of the persistent loop kernel so far (launch parity)
+    double *luxrec = nullptr;   // exchange records of the cross-workgroup LU panel (lu_cross.hip), zeroed once
     GsState *gs_state = nullptr, *gs_host = nullptr;   // device column search (general_kernels.hip): state block + pinned mirror
     int32_t *gs_idx = nullptr; int cap_gs_idx = 0;
     int32_t *srcpos = nullptr;
@@ -139,6 +140,7 @@ struct Engine::Work {
         for (double **p : {&T[0], &T[1], &R[0], &R[1], &tscratch, &btU, &btV, &xbuf}) { if (*p) hipFree(*p); *p = nullptr; }
         if (srcpos) hipFree(srcpos); srcpos = nullptr;
         cap_T = 0; cap_ldt = 0; cap_btU = 0;
+        if (luxrec) hipFree(luxrec); luxrec = nullptr;
         if (gs_state) hipFree(gs_state); gs_state = nullptr;
         if (gs_host) hipHostFree(gs_host); gs_host = nullptr;
         if (gs_idx) hipFree(gs_idx); gs_idx = nullptr; cap_gs_idx = 0;

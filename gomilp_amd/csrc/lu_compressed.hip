@@ -1028,6 +1028,21 @@ static void luc_rounds_slots(const LUArgs &base, int32_t *pivrow, int nrounds, i
     }
 }
 
+// the rows of a round's panel on G workgroups of one XCD (lu_cross.hip, knob lu_cross): the plain schedule with that panel
+void launch_luc_cross_panel(const LUArgs &a, int32_t *pivrow, double *xrec, int G, hipStream_t s);
+int launch_luc_rounds_cross(const LUArgs &base, int32_t *pivrow, int nrounds, double *xrec, int G, hipStream_t s) {
+    const int nt = (base.m + 63) / 64;
+    LUArgs a = base;
+    a.look = 0;
+    a.ctl_prev = a.ctl; a.Lp_prev = a.Lp; a.Up_prev = a.Up; a.rowsnap_prev = a.rowsnap;
+    for (int r = 0; r < nrounds; r++) {
+        launch_luc_cross_panel(a, pivrow, xrec, G, s);
+        hipLaunchKernelGGL((k_luc_usolve<kLucSlotSteps>), dim3(nt), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_luc_trail<kLucSlotSteps>), dim3(nt, nt), dim3(256), 0, s, a);
+    }
+    return 3 * nrounds;
+}
+
 bool lu_compressed_supported(int m) { return m <= 4096; }
 // dense steps a round can take (the host sizes its batches of rounds with it)
 int lu_compressed_nb(int, bool) { return kLucSlotSteps; }
