@@ -277,7 +277,7 @@ struct LUCtl {
     int32_t ndrop;      // register columns the panel dropped un-eliminated (a newly dense column took their slot)
     int32_t rounds;     // rounds that did work
     int32_t nnext;      // look-ahead schedule: the columns the NEXT round's panel loads (the first dense columns >= k1, as the panel's own scan finds them)
-    int32_t pad;
+    int32_t ksync;      // cross-workgroup panel (lu_cross.hip): its index maps hold the row interchanges of the steps < ksync (the rest waits in pivrow: replayed when a pivot search ties)
     int32_t steps[32];  // step (= column) index of each dense step, ascending
     int32_t prow[32];   // its pivot row
     // dropped column d was in the register list for the rows that left the active set at steps [dropin, dropout):

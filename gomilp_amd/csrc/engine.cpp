@@ -846,7 +846,7 @@ int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_hos
     // diagonal, the row positions, the flags and both control blocks behind them (k_luc_pack_small).  An exact step factors twice and
     // small trees are made of round trips and 3 us copies (60 per relaxation before this).  Should the batch of rounds turn out too
     // short, the general path takes over from where the rounds stand.
-    bool oneshot = compressed && m <= 128 && luc_pack_small_bytes(m) <= ((size_t)w.cap_m * w.cap_ld + 512) * sizeof(double);   // (the block fits Wd / h_W: ensure_work)
+    bool oneshot = compressed && !cross_G && m <= 128 && luc_pack_small_bytes(m) <= ((size_t)w.cap_m * w.cap_ld + 512) * sizeof(double);   // (the block fits Wd / h_W: ensure_work)
     std::vector<int32_t> dl;
     auto enqueue_pack = [&](int nd2) -> int {
         int rcd = stage_upload(w.dlist, dl.data(), (size_t)nd2 * sizeof(int32_t));
@@ -914,6 +914,7 @@ int Engine::lu_factor(const Problem &P, bool *singular, const int32_t *basic_hos
                 if (batch > 64) batch = 64;
             }
             lu_rounds_ = last->rounds;
+            if (cross_G && !w.luctl_host[0].fault) { launch_luc_lpos_final(a, stream_); launches_++; }   // (that panel keeps its maps up to the last tied search only)
             look_slot.drop();   // (the rounds are behind the last sync)
             if (!w.luctl_host[0].fault) break;
             // a wait inside a look-ahead launch ran out of patience (its workgroups never became resident together): once more, from the

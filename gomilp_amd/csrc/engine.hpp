@@ -263,6 +263,7 @@ void launch_gs_candidate(const double *acol, double *QT, double *Rinv, int ldq, 
                          int last = 0);
 int launch_luc_rounds_cross(const LUArgs &base, int32_t *pivrow, int nrounds, double *xrec, int G, hipStream_t s);
 size_t luc_cross_doubles();
+void launch_luc_lpos_final(const LUArgs &a, hipStream_t s);
 int luc_cross_groups(int m, int want);
 int gs_scratch_rows();
 int gs_block_width(int m);

@@ -901,7 +901,7 @@ __global__ void k_luc_init(LUArgs a) {
         a.st->lu_singular = 0;   // (the host resets its copy; small bases skip the upload of the state block)
         for (int t = 0; t < 2; t++) {   // (two: by round parity)
             LUCtl *c = a.ctl + t;
-            c->k_next = 0; c->k0 = 0; c->k1 = 0; c->nsteps = 0; c->ndrop = 0; c->rounds = 0; c->nnext = 0;
+            c->k_next = 0; c->k0 = 0; c->k1 = 0; c->nsteps = 0; c->ndrop = 0; c->rounds = 0; c->nnext = 0; c->ksync = 0;
             c->cnt_x = 0; c->cnt_u = 0; c->cnt_s = 0; c->fault = 0;
         }
     }

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_luc_panel_x(LUArgs a, int32_t *__restri
     const size_t ldw = (size_t)a.ldw;
     const int k0 = a.ctl_prev->k_next;
     if (k0 >= m) {
-        if (g == 0 && tid == 0) { ctl->nsteps = 0; ctl->ndrop = 0; ctl->nnext = 0; ctl->k_next = k0; ctl->k0 = k0; ctl->k1 = k0; ctl->rounds = a.ctl_prev->rounds; }
+        if (g == 0 && tid == 0) { ctl->nsteps = 0; ctl->ndrop = 0; ctl->nnext = 0; ctl->k_next = k0; ctl->k0 = k0; ctl->k1 = k0; ctl->rounds = a.ctl_prev->rounds; ctl->ksync = a.ctl_prev->ksync; }
         return;
     }
     for (int R = tid; R < MAXM; R += T) {
@@ -96,7 +96,14 @@ __global__ __launch_bounds__(256) void k_luc_panel_x(LUArgs a, int32_t *__restri
     __syncthreads();
     for (int R = tid; R < m; R += T) {
         s_rowat[s_lpos[R]] = (idx_t)R;
-        if (s_unit[R] != NONE) s_ucol[s_unit[R]] = (idx_t)R;
+        if (s_unit[R] != NONE && R >= k0) s_ucol[s_unit[R]] = (idx_t)R;   // column R (still to come) is the unit vector of row s_unit[R]
+    }
+    for (;;) {   // (two unit columns with the same row — a singular basis —: the FIRST of them is the one whose step retires the row)
+        __syncthreads();
+        bool again = false;
+        for (int R = tid; R < m; R += T)
+            if (s_unit[R] != NONE && R >= k0 && R < (int)s_ucol[s_unit[R]]) { s_ucol[s_unit[R]] = (idx_t)R; again = true; }
+        if (!__syncthreads_or(again)) break;
     }
     if (w == 0) {
         int n = 0;
@@ -121,6 +128,8 @@ __global__ __launch_bounds__(256) void k_luc_panel_x(LUArgs a, int32_t *__restri
     unsigned int live = nload >= 32 ? 0xFFFFFFFFu : ((1u << nload) - 1u);
     const int R = g * T + tid;   // this lane's row
     bool act = (R < m) && s_active[R < m ? R : 0];
+    const idx_t uc0 = s_ucol[R < m ? R : 0];
+    const int myucol = (act && uc0 != NONE) ? (int)uc0 : 0x7FFFFFFF;   // the step that retires this row unless a dense step takes it first
     vec v;
     {
         const double *src = a.W + (act ? R : 0);
@@ -142,6 +151,7 @@ __global__ __launch_bounds__(256) void k_luc_panel_x(LUArgs a, int32_t *__restri
 #endif
     LUX_STAMP(-1);
     int kcur = k0, s = 0, k1 = m;
+    int ksync = a.ctl_prev->ksync;   // the index maps (lpos / rowat) hold the interchanges of the steps < ksync: the rest waits in the log (pivrow)
     bool fault = false;
 #pragma unroll 1
     for (;;) {
@@ -153,23 +163,17 @@ __global__ __launch_bounds__(256) void k_luc_panel_x(LUArgs a, int32_t *__restri
             const int limit = listed ? (int)mn : m;
             const unsigned long long hit = __ballot(key == mn && lane < NB);
             const int sigma = hit ? (int)__builtin_ctzll(hit) : 0;
-            // run of bookkeeping steps [kcur, limit): every workgroup replays the same interchanges on its own copy of the maps
+            // run of bookkeeping steps [kcur, limit): only its END is needed on the chain — the first column whose step needs arithmetic.  A row
+            // knows the step that retires it (myucol); LAPACK's logical row order — all the index maps are for — matters only when two rows tie in
+            // a pivot search, and then every workgroup replays the interchanges since the last replay from the log of pivot rows (below).  With
+            // ONE wave per SIMD the serial replay (1.8 k cycles per dense step) was on the chain: nobody to hide behind (section 2.3, "Round 5")
             int k = kcur;
             for (;;) {
                 const int kk = k + lane;
                 const idx_t ur = kk < limit ? s_unit[kk] : NONE;
-                const bool triv = ur != NONE && s_active[ur];
+                const bool triv = ur != NONE && s_active[ur] && (int)s_ucol[ur] == kk;   // (a second unit column of the same row finds it used: arithmetic)
                 const unsigned long long nt = __ballot(!triv);
                 const int cnt = nt ? (int)__builtin_ctzll(nt) : 64;
-                for (int j = 0; j < cnt; j++) {
-                    const int urj = __builtin_amdgcn_readlane((int)ur, j);
-                    if (lane == 0) {
-                        const idx_t jp = s_lpos[urj], Q = s_rowat[k + j];
-                        s_lpos[Q] = jp; s_rowat[jp] = Q;
-                        s_lpos[urj] = (idx_t)(k + j); s_rowat[k + j] = (idx_t)urj;
-                        s_active[urj] = 0;
-                    }
-                }
                 k += cnt;
                 if (cnt < 64) break;
             }
@@ -180,9 +184,11 @@ __global__ __launch_bounds__(256) void k_luc_panel_x(LUArgs a, int32_t *__restri
         LUX_STAMP(1);
         const int kstop = s_stop, limit = s_limit;
         const int sigma = __builtin_amdgcn_readfirstlane(s_sigma) & (NB - 1);
-        // this lane's row retired by the run: its entries in the listed columns are final U entries
-        if (act && !s_active[R]) {
-            const int kt = s_lpos[R];
+        // the rows of the run leave the active set on every workgroup's copy of the map (every column of the run is the unit column of an active row)
+        for (int c = kcur + tid; c < kstop; c += T) s_active[s_unit[c]] = 0;
+        // this lane's row retired by the run (the step of its unit column lies in it): its entries in the listed columns are final U entries
+        if (act && myucol >= kcur && myucol < kstop) {
+            const int kt = myucol;
             a.rowstep[R] = kt; pivrow[kt] = R;
             double *dst = a.W + R;
 #pragma unroll
@@ -196,82 +202,118 @@ __global__ __launch_bounds__(256) void k_luc_panel_x(LUArgs a, int32_t *__restri
         // ---- dense step k on slot sigma: this workgroup's candidate
         const double x = v[sigma];
         const double xm = act ? -fabs(x) : __builtin_inf();
+        // one exchange: the wave that holds the workgroup's candidate hands the record {h0, h1, row, 1 / a_ik, XCC id | the row's entries in the NB
+        // slots} to its lanes (LDS, no barrier: one wave), which post it with ONE store instruction; every wave then polls the G records —
+        // lane l reads the slots (l & 7), + 8, + 16 of record l >> 3
+        xpair rv[3];
+        auto exchange = [&](bool poster, double h0, double h1) {
+            const double seq = seq0 + (double)(nx + 1);
+            xpair *mine = recs + ((size_t)((nx + 1) & 1) * G + g) * kLxSlots;
+            if (__any(poster)) {   // (uniform per wave)
+                double *sp = s_post[w];
+                if (poster) {
+                    sp[0] = h0; sp[1] = h1; sp[2] = (double)R;
+                    sp[3] = act ? 1.0 / x : 0.0;   // dgetf2.go:54-56 scales by the reciprocal
+#pragma unroll
+                    for (int c = 0; c < NB; c++) sp[4 + c] = v[c];
+                    sp[20] = (double)myxcc;
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the candidate's LDS writes have landed (same wave: in order)
+                if (lane < 21) xstore(mine + lane, xpair{seq, sp[lane]}, fast);
+            }
+            const xpair *base = recs + (size_t)((nx + 1) & 1) * G * kLxSlots;
+            const int g2 = lane >> 3, j0 = lane & 7;
+            const bool mineok = g2 < G;
+            const xpair *q0 = base + (size_t)(mineok ? g2 : 0) * kLxSlots + j0;
+            for (int it = 0;; it++) {
+                if (fast) lx_load3_fast(q0, q0 + 8, q0 + 16, rv); else lx_load3(q0, q0 + 8, q0 + 16, rv);
+                const bool ok = !mineok || (rv[0][0] == seq && rv[1][0] == seq && (j0 + 16 > 20 || rv[2][0] == seq));   // the slots a record uses: 0 .. 20
+                if (__all(ok)) break;
+                if (it >= kLxSpinLimit) { fault = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            nx++;
+        };
+        const bool head = (lane & 7) == 0 && (lane >> 3) < G;   // a record's header sits in the lanes 8 g2 .. 8 g2 + 4
+        // ---- this workgroup's candidate: its maximum, how many of its rows attain it, and one of them (the smallest physical row)
         const double wm = wave_min_f64(xm);
-        unsigned int lk = 0xFFFFFFFFu;
         const bool hitw = act && xm == wm;
-        const int lpr = hitw ? (int)s_lpos[R] : -1;
-        if (hitw) lk = (unsigned int)lpr;
+        const unsigned int cntw = (unsigned int)__popcll(__ballot(hitw));
+        unsigned int lk = hitw ? (unsigned int)R : 0xFFFFFFFFu;
         lk = row_min_u32(lk);
         lk = min(min((unsigned int)__builtin_amdgcn_readlane((int)lk, 15), (unsigned int)__builtin_amdgcn_readlane((int)lk, 31)),
                  min((unsigned int)__builtin_amdgcn_readlane((int)lk, 47), (unsigned int)__builtin_amdgcn_readlane((int)lk, 63)));
         double *rm = redM[s & 1];
         unsigned int *rl = redL[s & 1];
-        if (lane == 0) { rm[w] = wm; rl[w] = lk; }
+        if (lane == 0) { rm[w] = wm; rl[w] = (min(cntw, 2u) << 16) | (lk & 0xFFFFu); }
         LUX_STAMP(3);   // own search
         __syncthreads();
         LUX_STAMP(4);
         const double bx = lane < NW ? rm[lane] : __builtin_inf();
         const double bml = readlane_f64(row_min_f64(bx), 15);
-        const unsigned int bkl = (lane < NW && bx == bml) ? rl[lane] : 0xFFFFFFFFu;
-        const int jpl = (int)(unsigned int)__builtin_amdgcn_readlane((int)row_min_u32(bkl), 15);
-        // the workgroup's candidate hands the record to the lanes of its wave (LDS, no barrier: one wave), which post it with ONE store
-        // instruction: {max, logical position, physical row, 1 / a_ik, XCC id | the row's entries in the NB slots}
-        // (a workgroup without an active row: wave 0 posts +inf)
-        const double seq = seq0 + (double)(nx + 1);
-        xpair *mine = recs + ((size_t)((nx + 1) & 1) * G + g) * kLxSlots;
-        const bool real = jpl >= 0;
-        const bool poster = real ? (act && lpr == jpl) : (tid == 0);
-        if (__any(poster)) {   // (uniform per wave: the wave that holds the candidate)
-            double *sp = s_post[w];
-            if (poster) {
-                sp[0] = real ? bml : __builtin_inf();
-                sp[1] = (double)(real ? jpl : 0x7FFFFFFF);
-                sp[2] = (double)R;
-                sp[3] = real ? 1.0 / x : 0.0;   // dgetf2.go:54-56 scales by the reciprocal
-#pragma unroll
-                for (int c = 0; c < NB; c++) sp[4 + c] = v[c];
-                sp[20] = (double)myxcc;
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the candidate's LDS writes have landed (same wave: in order)
-            if (lane < 21) xstore(mine + lane, xpair{seq, sp[lane]}, fast);
-        }
-        LUX_STAMP(5);   // local pick + post
-        // ---- every wave polls the G records of this exchange: lane l reads the slots (l & 7), + 8, + 16 of record l >> 3
-        xpair rv[3];
-        {
-            const xpair *base = recs + (size_t)((nx + 1) & 1) * G * kLxSlots;
-            const int g2 = lane >> 3, j0 = lane & 7;
-            const bool mineok = g2 < G;
-            const xpair *q0 = base + (size_t)(mineok ? g2 : 0) * kLxSlots + j0;
-            int it = 0;
-            for (;; it++) {
-                if (fast) lx_load3_fast(q0, q0 + 8, q0 + 16, rv); else lx_load3(q0, q0 + 8, q0 + 16, rv);
-                // the slots a record uses: 0 .. 20
-                const bool ok = !mineok || (rv[0][0] == seq && rv[1][0] == seq && (j0 + 16 > 20 || rv[2][0] == seq));
-                if (__all(ok)) break;
-                if (it >= kLxSpinLimit) { fault = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        nx++;
+        const unsigned int infol = (lane < NW && bx == bml) ? rl[lane] : 0u;
+        const unsigned int cntl = (unsigned int)__popcll(__ballot((infol >> 16) >= 1u)) + (unsigned int)__popcll(__ballot((infol >> 16) >= 2u));   // (0 without an active row)
+        const unsigned int rowl = (unsigned int)__builtin_amdgcn_readlane((int)row_min_u32((lane < NW && (infol >> 16) >= 1u) ? (infol & 0xFFFFu) : 0xFFFFFFFFu), 15);
+        exchange(cntl ? (act && (unsigned int)R == rowl) : (tid == 0), cntl ? bml : __builtin_inf(), (double)min(cntl, 2u));
         if (fault) break;
-        LUX_STAMP(6);   // poll
-        // the lexicographic minimum (-|a|, logical position) over the records, lane-parallel: a record's header sits in the lanes 8 g2 .. 8 g2 + 3
-        const bool head = (lane & 7) == 0 && (lane >> 3) < G;
-        const double wmL = head ? rv[0][1] : __builtin_inf();
-        const double bm = wave_min_f64(wmL);
-        const double jpL = __shfl(rv[0][1], (lane & ~7) + 1);
-        const double cand = (head && wmL == bm) ? jpL : __builtin_inf();
-        const double bjp = wave_min_f64(cand);
-        const unsigned long long won = __ballot(head && wmL == bm && jpL == bjp);
-        const int gw = won ? ((int)__builtin_ctzll(won) >> 3) : 0;
-        const int jp = (int)bjp;
-        const int P = (int)readlane_f64(rv[0][1], 8 * gw + 2);
-        const double rinv = readlane_f64(rv[0][1], 8 * gw + 3);
+        LUX_STAMP(5);   // local pick + post + poll
         if (!fast) {   // every record carries its workgroup's XCC id: all equal -> the XCD's L2 is the coherence point, plain stores / nt loads from here on
-            const double xc = __shfl(rv[2][1], (lane & ~7) + 4);   // slot 20 = (4) + 16
+            const double xc = __shfl(rv[2][1], (lane & ~7) + 4);   // slot 20 = 4 + 16
             fast = __all(!head || xc == (double)myxcc);
         }
+        const double wmL = head ? rv[0][1] : __builtin_inf();
+        const double bm = wave_min_f64(wmL);
+        const double cnL = __shfl(rv[0][1], (lane & ~7) + 1);
+        const unsigned long long at1 = __ballot(head && wmL == bm && cnL >= 1.0), at2 = __ballot(head && wmL == bm && cnL >= 2.0);
+        int gw;
+        if (__popcll(at1) == 1 && at2 == 0) {
+            gw = (int)__builtin_ctzll(at1) >> 3;   // ONE row in the whole panel attains the maximum: the pivot row, whatever its logical position
+        } else {
+            // several rows with the same |a_ik| (or none): dgetf2.go:38 takes the first in LAPACK's logical row order.  (1) an exchange behind
+            // which every workgroup's stores to the log have landed; (2) every workgroup replays the interchanges of the steps [ksync, k) on its
+            // copy of the maps — the pivot row of step j is pivrow[j], whoever performed it (dlaswp.go); (3) the positions decide: a second
+            // exchange of {smallest logical position among the workgroup's tied rows, ...}
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            exchange(tid == 0, 0.0, 0.0);
+            if (fault) break;
+            if (w == 0) {
+                for (int j0 = ksync; j0 < k; j0 += 64) {
+                    const int jj = j0 + lane;
+                    const int pj = jj < k ? __hip_atomic_load(&pivrow[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                    const int nrep = min(64, k - j0);
+                    for (int t = 0; t < nrep; t++) {
+                        const int Pj = __builtin_amdgcn_readlane(pj, t);
+                        if (lane == 0) {
+                            const idx_t jq = s_lpos[Pj], Q = s_rowat[j0 + t];   // dlaswp.go: the row at logical j trades places with the pivot row
+                            s_lpos[Q] = jq; s_rowat[jq] = Q;
+                            s_lpos[Pj] = (idx_t)(j0 + t); s_rowat[j0 + t] = (idx_t)Pj;
+                        }
+                    }
+                }
+            }
+            ksync = k;
+            __syncthreads();
+            const bool tied = act && xm == bm;
+            unsigned int lp = tied ? (unsigned int)s_lpos[R] : 0xFFFFFFFFu;
+            const unsigned int lpmine = lp;
+            lp = row_min_u32(lp);
+            lp = min(min((unsigned int)__builtin_amdgcn_readlane((int)lp, 15), (unsigned int)__builtin_amdgcn_readlane((int)lp, 31)),
+                     min((unsigned int)__builtin_amdgcn_readlane((int)lp, 47), (unsigned int)__builtin_amdgcn_readlane((int)lp, 63)));
+            unsigned int *rt = redL[(s & 1) ^ 1];
+            if (lane == 0) rt[w] = lp;
+            __syncthreads();
+            const unsigned int lpl = (unsigned int)__builtin_amdgcn_readlane((int)row_min_u32(lane < NW ? rt[lane] : 0xFFFFFFFFu), 15);
+            const bool any_l = lpl != 0xFFFFFFFFu;
+            exchange(any_l ? (tied && lpmine == lpl) : (tid == 0), any_l ? (double)lpl : __builtin_inf(), 0.0);
+            if (fault) break;
+            const double lpL = head ? rv[0][1] : __builtin_inf();
+            const double blp = wave_min_f64(lpL);
+            const unsigned long long won = __ballot(head && lpL == blp);
+            gw = won ? ((int)__builtin_ctzll(won) >> 3) : 0;
+        }
+        const int P = (int)readlane_f64(rv[0][1], 8 * gw + 2);
+        const double rinv = readlane_f64(rv[0][1], 8 * gw + 3);
         // lane c: the pivot row's value in slot c = record slot 4 + c: lane 8 gw + ((4 + c) & 7), register (4 + c) >> 3
         double prl;
         {
@@ -280,14 +322,10 @@ __global__ __launch_bounds__(256) void k_luc_panel_x(LUArgs a, int32_t *__restri
             const double b0 = __shfl(rv[0][1], src), b1 = __shfl(rv[1][1], src), b2 = __shfl(rv[2][1], src);
             prl = rr == 0 ? b0 : (rr == 1 ? b1 : b2);
         }
+        LUX_STAMP(6);   // pick
         const bool owner = act && R == P;
-        // the interchange of the dense step, on every workgroup's copy of the maps (wave 0 replays the next run: the same wave writes)
-        if (tid == 0 && jp >= 0 && jp < MAXM && P >= 0 && P < MAXM) {
-            const idx_t Q = s_rowat[k];   // dlaswp.go: the row at logical k moves to jp
-            s_lpos[Q] = (idx_t)jp; s_rowat[jp] = Q;
-            s_lpos[P] = (idx_t)k; s_rowat[k] = (idx_t)P;
-            s_active[P] = 0;
-        }
+        // the pivot row leaves the active set on every workgroup's copy of the map; the interchange itself (dlaswp.go) waits in the log
+        if (tid == 0 && P >= 0 && P < MAXM) s_active[P] = 0;
         if (owner) {
             act = false;
             a.rowstep[P] = k; pivrow[k] = P;
@@ -356,10 +394,18 @@ __global__ __launch_bounds__(256) void k_luc_panel_x(LUArgs a, int32_t *__restri
     }
     if (tid == 0) {
         ctl->k0 = k0; ctl->k1 = k1; ctl->k_next = k1; ctl->nsteps = s; ctl->ndrop = ndl;
-        ctl->rounds = a.ctl_prev->rounds + 1;
+        ctl->rounds = a.ctl_prev->rounds + 1; ctl->ksync = ksync;
         xrec[0] = xpair{seq0 + (double)nx, 0.0};
     }
 }
+
+// once every step is done a row's logical position is the step that took it — what the solves and the host read (the panel's maps hold the
+// interchanges up to its last replay only)
+__global__ void k_luc_lpos_final(LUArgs a) {
+    const int R = blockIdx.x * blockDim.x + threadIdx.x;
+    if (R < a.m) a.lpos[R] = a.rowstep[R];
+}
+void launch_luc_lpos_final(const LUArgs &a, hipStream_t s) { hipLaunchKernelGGL(k_luc_lpos_final, dim3((a.m + 255) / 256), dim3(256), 0, s, a); }
 
 // ---- host side
 size_t luc_cross_doubles() { return (size_t)kLxHeader + 2 * 2 * 8 * kLxSlots; }   // header + two parities of eight records (xpairs = 2 doubles)

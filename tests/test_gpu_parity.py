@@ -237,6 +237,31 @@ def test_lu_schedules_agree_where_the_pivot_search_ties(m):
             assert np.array_equal(ref.x, np.asarray(want.x)) and ref.z == want.z, (m, seed)
 
 
+@pytest.mark.parametrize("name", ["ties150", "ties300", "C3", "C2", "M"])
+def test_cross_workgroup_lu_panel_equals_the_one_workgroup_panel_bitwise(name):
+    """lu_cross.hip (opt-in, knob lu_cross): a round's rows on 2 / 4 / 8 workgroups of one XCD — replicated index maps and slot tables, one
+    exchange per dense step whose record carries the candidate's pivot-row entries, the bookkeeping runs off the chain (a row knows the
+    step that retires it; the maps are replayed from the log of pivot rows when a pivot search ties: the integer cases, most of their
+    steps) — against the one-workgroup panel: same pivots, basis, x and z bits, same dense steps, no fall-back."""
+    if name.startswith("ties"):
+        c, A, b = _lu_ties().integer_lp(int(name[4:]), 0)
+    else:
+        m, seed = synth.CONFIGS[name]
+        c, A, b = synth.dense_lp_standard_form(m, seed)
+    res = {}
+    for cross in (0, 1):
+        cx = lp.Context(lu_cross=cross, lu_blocked=2, max_pivots=20000)
+        try:
+            res[cross] = cx.upload(c, A, b).solve(0.0)
+        finally:
+            cx.close()
+    a, x = res[0], res[1]
+    assert a.status == x.status == lp.OK
+    assert np.array_equal(a.basis, x.basis) and np.array_equal(a.x, x.x) and a.z == x.z
+    assert a.stats["lu_dense_steps"] == x.stats["lu_dense_steps"] and x.stats["lu_rounds"] >= a.stats["lu_rounds"] > 0
+    assert x.stats.get("device_retries", 0) == 0
+
+
 def test_engine_follows_the_reference_into_its_cycle():
     """lp.Simplex has no iteration limit (simplex.go:233), and on the 40-row integer LP of seed 1 its rule does not terminate: from
     pivot 24 on two columns trade places at position 14 for ever — each exchange a NON-degenerate step by a rounding-size amount, so

@@ -13,7 +13,7 @@ buf = (ctypes.c_ulonglong * 64)()
 lp.lib().gomilp_debug_lux_stamps(buf)
 a = np.array(buf[:], dtype=np.float64).reshape(4, 16)
 steps = a[0, 15]
-names = ["wave0 top", "barrier1", "retire", "own search", "barrier2", "local pick+post", "poll", "pick+bookkeeping", "elimination"]
+names = ["wave0 top", "barrier1", "retire", "own search", "barrier2", "local pick+post+poll", "pick", "bookkeeping", "elimination"]
 print(name, "dense steps", int(steps), "final solve %.3f ms, rounds %d" % (1e3 * r.stats["seconds_final_solve"], r.stats["lu_rounds"]))
 for w in range(4):
     print("wave", w, " ".join("%s %.0f" % (names[i], a[w, i] / steps) for i in range(9)), "| sum %.0f cycles per dense step" % (a[w, :9].sum() / steps))
