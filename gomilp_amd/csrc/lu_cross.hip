@@ -3,13 +3,15 @@
 // k_luc_panel_slots runs a round's dense steps on ONE workgroup of sixteen waves: a dense step is the issue time of those waves on the four
 // SIMDs of one CU (7.7 k cycles, DESIGN.md section 2.3 "Round 5").  Here G workgroups of four waves (one per SIMD) hold 256 rows each, one
 // row per lane, the same NB register slots; everything a step decides is decided by every workgroup from the same values:
-//   * the index maps (lpos / rowat / unit / ucol / active), the slot tables and the serial replay of the bookkeeping runs are REPLICATED —
-//     every workgroup keeps all m rows' maps in LDS and wave 0 of each replays the same interchanges;
+//   * the index maps (lpos / rowat / unit / ucol / active) and the slot tables are REPLICATED — every workgroup keeps all m rows' maps in LDS;
+//     the bookkeeping runs are off the chain: a row knows the step that retires it, and the interchanges are replayed on the maps (from the
+//     log of pivot rows, by every workgroup alike) only when a pivot search finds two rows with the same |a_ik|;
 //   * the pivot search is local (four waves), then ONE exchange through the XCD's L2 (bt_loop.h: records of {sequence number, value}
 //     slots, sequence-tagged so that no flag separates data from "ready"): the workgroup's candidate posts
-//     {max |a_ik|, its logical position, its physical row, 1 / a_ik, the candidate row's entries in the NB slots}; every wave polls the G
-//     records, takes the lexicographic minimum (-|a|, logical position) — dgetf2.go:38: the first maximum in LAPACK's row order — and has
-//     the pivot row's entries for its elimination in the same load;
+//     {max |a_ik|, how many of its rows attain it, one of them, 1 / a_ik, the XCC id, that row's entries in the NB slots}; every wave polls
+//     the G records; ONE row in the whole panel attaining the maximum is the pivot row — otherwise (dgetf2.go:38: the first maximum in
+//     LAPACK's row order) the maps are brought up to date and a further exchange of logical positions decides — and the pivot row's entries
+//     for the elimination came with the same load;
 //   * the owner of the pivot row does the global bookkeeping (rowstep, pivrow, the control block's step list, the U row's stores).
 // Same arithmetic, same step order, same round structure as the one-workgroup panel (k_luc_usolve / k_luc_trail follow unchanged): the
 // schedules are compared bit for bit (tests/test_gpu_parity.py).  Waits are bounded: a workgroup that runs out of patience raises the
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void k_luc_panel_x(LUArgs a, int32_t *__restri
     __shared__ double redM[2][NW];
     __shared__ unsigned int redL[2][NW];
     __shared__ int s_slotcol[NB];
-    __shared__ int s_nload, s_stop, s_limit, s_sigma, s_ok;
+    __shared__ int s_nload, s_stop, s_limit, s_sigma;
     __shared__ __attribute__((aligned(16))) double s_post[NW][kLxSlots];   // a wave's candidate hands its record to the wave's lanes: one store instruction posts it
     if (a.ctl_base->fault) return;
     LUCtl *ctl = a.ctl;
